@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X-native TecoGAN/FRVSR recurrent frame (FRNet.step).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1
+it is launched under torch.distributed.run with one rank per GPU.  Rank 0
+prints ONE JSON line.
+
+Workload = BASELINE.json configs[1]: TecoGAN 4xSR BD generator-only inference,
+synthetic 3x134x320 LR clip (the shape the reference's published 27 FPS is
+quoted on, profile.sh / main.py:210-264).  A "step" is one recurrent frame
+(FNet -> pad/upsample/warp/space_to_depth -> SRNet) for one clip per GPU on
+fresh uniform-random inputs, random-init weights (seeded), fp32 end to end.
+Clips are independent, so N GPUs run N clips with no data-path collective
+(weak scaling); value = N*K frames / max-over-ranks wall time.
+
+Extra objects on the same line:
+  roofline      dominant kernel class (fp32-MFMA conv3x3): algorithmic FLOPs of
+                its launches in one frame / their summed duration measured with
+                HIP events around a masked replay of exactly those launches.
+  cpu_baseline  the CPU oracle (torch-CPU restatement of the reference path,
+                bit-checked against the reference in the authoring container)
+                timed on this host's cores on a bounded sample (N == 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--lr-size', default='3x134x320')
+    ap.add_argument('--scale', type=int, default=4)
+    ap.add_argument('--degradation', default='BD')
+    ap.add_argument('--cpu-frames', type=int, default=16,
+                    help='max frames of the CPU baseline sample (0 disables)')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def kernel_table(net, plan, bufs, reps=20):
+    """Per kernel class: launches/frame, algorithmic flops & bytes, measured ms
+    per frame (HIP events around a masked replay on the launch stream)."""
+    from tecogan_pytorch_amd import _lib as L
+    lib = L.lib()
+    lr_c, lr_p, hr_p, out = bufs
+    stream = torch.cuda.current_stream().cuda_stream
+    rows = []
+    nk = lib.tg_frnet_plan_kinds()
+    for k in range(nk):
+        nl, fl, by = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        L.check(lib.tg_frnet_plan_kind_stats(plan.handle, k, ctypes.byref(nl), ctypes.byref(fl),
+                                             ctypes.byref(by)), 'kind_stats')
+        name = lib.tg_frnet_kind_name(k).decode()
+        if nl.value == 0 or name.startswith('quantize'):
+            continue
+        mask = 1 << k
+
+        def run():
+            L.check(lib.tg_frnet_step_masked(plan.handle, lr_c.data_ptr(), lr_p.data_ptr(),
+                                             hr_p.data_ptr(), out.data_ptr(), None, mask, stream),
+                    'step_masked')
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        rows.append(dict(kernel=name, launches=nl.value, gflop=fl.value / 1e9,
+                         mbytes=by.value / 1e6, ms_per_frame=ms,
+                         tflops=(fl.value / 1e12) / (ms / 1e3) if fl.value else None,
+                         gbs=(by.value / 1e9) / (ms / 1e3)))
+    return rows
+
+
+def cpu_baseline(sd, scale, deg, c, h, w, max_frames, max_seconds):
+    """Reference-protocol FPS of the CPU oracle: fresh rand inputs per frame
+    (generated outside the timer), eval/no_grad, FPS = frames / sum(step time)
+    (codes/main.py:249-262 minus the CUDA sync)."""
+    from oracle import tecogan_oracle as O
+    torch.manual_seed(1)
+    tot, frames = 0.0, 0
+    with torch.no_grad():
+        # one untimed warm-up (thread pool / oneDNN primitive creation)
+        O.frnet_step(sd, torch.rand(1, c, h, w), torch.rand(1, c, h, w),
+                     torch.rand(1, c, scale * h, scale * w), scale, deg)
+        while frames < max_frames and tot < max_seconds:
+            a = [torch.rand(1, c, h, w), torch.rand(1, c, h, w),
+                 torch.rand(1, c, scale * h, scale * w)]
+            t0 = time.perf_counter()
+            O.frnet_step(sd, a[0], a[1], a[2], scale, deg)
+            tot += time.perf_counter() - t0
+            frames += 1
+    return dict(value=frames / tot, unit='frames/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{frames} frames of the same {c}x{h}x{w} workload, oracle/tecogan_oracle.py '
+                       f'(torch-CPU fp32, oneDNN), nproc={os.cpu_count()}')
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local_rank if dist_on else 0)
+
+    from tecogan_pytorch_amd.models.networks import FRNet
+    from tecogan_pytorch_amd import _lib as L
+    L.lib()   # loud failure if the HIP library is missing
+
+    c, h, w = [int(v) for v in args.lr_size.split('x')]
+    s, deg = args.scale, args.degradation
+    torch.manual_seed(0)                      # same random-init weights on every rank
+    net = FRNet(c, c, 64, 10, deg, s).to(dev).eval()
+
+    # per-rank clip data (base_utils.py:46: seed + rank)
+    gen = torch.Generator(device='cpu').manual_seed(1234 + rank)
+    pool = []
+    for _ in range(4):
+        pool.append([torch.rand(1, c, h, w, generator=gen).to(dev),
+                     torch.rand(1, c, h, w, generator=gen).to(dev),
+                     torch.rand(1, c, s * h, s * w, generator=gen).to(dev)])
+    outs = [torch.empty(1, c, s * h, s * w, device=dev) for _ in range(2)]
+
+    def barrier():
+        if dist_on:
+            dist.barrier(device_ids=[local_rank])
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            net.step(*pool[i % 4], out=outs[i & 1])
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            net.step(*pool[i % 4], out=outs[i & 1])
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+
+        # reference protocol: synchronise after every frame (main.py:257-259)
+        tsync = 0.0
+        nsync = min(args.steps, 30)
+        for i in range(nsync):
+            t1 = time.perf_counter()
+            net.step(*pool[i % 4], out=outs[i & 1])
+            torch.cuda.synchronize()
+            tsync += time.perf_counter() - t1
+
+    if dist_on:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    result = None
+    if rank == 0:
+        gf, _ = net.profile((c, h, w))
+        plan = net._get_plan(1, h, w, dev)
+        result = {
+            'metric': 'HR frames/sec/GPU at 4xSR 3x134x320 LR; Vid4 PSNR vs reference',
+            'value': world * args.steps / elapsed,
+            'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'TecoGAN {s}xSR {deg} generator-only inference, FRNet.step on a '
+                                   f'synthetic {c}x{h}x{w} LR clip -> {c}x{s*h}x{s*w} HR, 1 clip/GPU, '
+                                   f'random-init weights (BASELINE configs[1])',
+                       'parallelism': f'clip-sharded x{world}, no data-path collective',
+                       'algorithmic_gflop_per_frame': gf['FNet'] + gf['SRNet'],
+                       'launches_per_frame': L.lib().tg_frnet_plan_launches(plan.handle)},
+            'fps_sync_every_frame': nsync / tsync,
+            'published_reference': '27 FPS on 1x GTX 1080 Ti (README benchmark.png); other hardware, '
+                                   'not a baseline for vs_baseline',
+        }
+        if not args.no_roofline:
+            with torch.no_grad():
+                rows = kernel_table(net, plan, (*pool[0], outs[0]))
+            dom = max(rows, key=lambda r: r['ms_per_frame'])
+            mf = [r for r in rows if r['kernel'].startswith('conv3x3_mfma')]
+            dom_mf = max(mf, key=lambda r: r['ms_per_frame'])
+            ach = dom_mf['tflops']
+            result['roofline'] = {
+                'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                'kernel': dom_mf['kernel'], 'launches_per_frame': dom_mf['launches'],
+                'avg_launch_us': 1e3 * dom_mf['ms_per_frame'] / dom_mf['launches'],
+                'algorithmic_gflop_per_launch': dom_mf['gflop'] / dom_mf['launches'],
+            }
+            warp = [r for r in rows if r['kernel'].startswith('flowup_warp')]
+            if warp:
+                wk = warp[0]
+                result['roofline_warp'] = {
+                    'bound': 'hbm', 'achieved': wk['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': wk['gbs'] / HBM_PEAK_GBS, 'traffic': None,
+                    'kernel': wk['kernel'], 'avg_launch_us': 1e3 * wk['ms_per_frame'],
+                    'algorithmic_mbytes_per_launch': wk['mbytes']}
+            result['kernels'] = rows
+            result['gpu_ms_per_frame_sum_of_kernels'] = sum(r['ms_per_frame'] for r in rows)
+            result['slowest_kernel_class'] = dom['kernel']
+        if world == 1 and args.cpu_frames > 0:
+            sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+            result['cpu_baseline'] = cpu_baseline(sd, s, deg, c, h, w, args.cpu_frames,
+                                                  args.cpu_seconds)
+            result['gpu_vs_cpu'] = result['value'] / result['cpu_baseline']['value']
+        else:
+            result['cpu_baseline'] = None
+        print(json.dumps(result), flush=True)
+    if dist_on:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,202 @@
+/*
+ * tecogan_hip.h -- C ABI of libtecogan_hip.so (MI355X / gfx950 only).
+ *
+ * The upstream reference (skycrapers/TecoGAN-PyTorch) has NO native code and
+ * therefore no FFI of its own: its hot path is Python calling stock ATen ops.
+ * This header is the boundary a maintainer binds instead of those ATen calls;
+ * each entry cites the reference call site it replaces (paths relative to the
+ * upstream repo root).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous NCHW unless a batch stride is given;
+ *     pointers are DEVICE pointers owned by the caller (PyTorch allocates);
+ *     the library never retains them past the call and never allocates;
+ *   - `*_nstride` = distance in floats between consecutive batch items, so a
+ *     channel-slice of a larger buffer can be read / written in place (this is
+ *     how every torch.cat on the path is folded away);
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues
+ *     kernels on it (no hidden synchronisation, hipGraph-capturable);
+ *   - every entry returns 0 (TG_OK) or a negative TG_E_* code;
+ *     tg_last_error_string() describes the last failure on this thread.
+ *     No C++ exception crosses the boundary.
+ */
+#ifndef TECOGAN_HIP_H
+#define TECOGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tg_stream_t;
+
+enum {
+  TG_OK = 0,
+  TG_E_SHAPE = -1, /* unsupported / inconsistent shape */
+  TG_E_ARG = -2,   /* null pointer, bad enum */
+  TG_E_HIP = -3    /* HIP runtime error at launch */
+};
+
+/* fused epilogue activation of the conv kernels */
+enum {
+  TG_ACT_NONE = 0,
+  TG_ACT_RELU = 1,    /* nn.ReLU                 tecogan_nets.py:96,113,121,125 */
+  TG_ACT_LRELU02 = 2, /* nn.LeakyReLU(0.2)       tecogan_nets.py:24-64, 369   */
+  TG_ACT_TANH24 = 3   /* torch.tanh(.) * 24      tecogan_nets.py:80           */
+};
+
+/* up-sampling flavour: get_upsampling_func, codes/utils/net_utils.py:85-97 */
+enum {
+  TG_UP_NONE = 0,
+  TG_UP_BICUBIC = 1, /* BicubicUpsampler (BD), net_utils.py:101-156 */
+  TG_UP_BILINEAR = 2 /* F.interpolate bilinear align_corners=False (BI), :86-89 */
+};
+
+int tg_version(void);
+const char* tg_last_error_string(void);
+
+/* ------------------------------------------------------------------------
+ * 3x3 stride-1 pad-1 convolution, fp32 MFMA implicit GEMM.
+ * Replaces every nn.Conv2d(.,.,3,1,1) on the path:
+ *   FNet tecogan_nets.py:23-65, SRNet conv_in :111-113, ResidualBlock :92-98,
+ *   D conv_in :367-369.
+ * Fused: channel-concat of two sources (torch.cat :71, :141), bias,
+ * activation, residual add (`self.conv(x) + x` :98).
+ *
+ * Weights must be pre-packed with tg_conv3x3_pack (layout private to the
+ * kernel: [oc-group][cin-chunk][tap][8 cin][ocb oc], zero padded).
+ *   ocb: output channels per workgroup, 32 or 64 (use tg_conv3x3_pick_ocb).
+ * ---------------------------------------------------------------------- */
+int tg_conv3x3_pick_ocb(int cout);
+size_t tg_conv3x3_packed_floats(int cin, int cout, int ocb);
+/* w_oihw: (cout, cin, 3, 3) as nn.Conv2d.weight.  transposed=1: w is
+ * (cin, cout, 3, 3) as nn.ConvTranspose2d.weight (used by tg_convt3x3s2_fwd). */
+int tg_conv3x3_pack(const float* w, float* w_packed, int cin, int cout, int ocb,
+                    int transposed, tg_stream_t stream);
+
+int tg_conv3x3_fwd(
+    const float* x, int64_t x_nstride, int c1,   /* channels [0,c1) from x          */
+    const float* x2, int64_t x2_nstride,         /* channels [c1,cin) from x2 (or NULL) */
+    const float* w_packed, int ocb, const float* bias /* may be NULL */,
+    const float* res, int64_t res_nstride,       /* optional residual, added after act */
+    float* y, int64_t y_nstride,
+    int n, int cin, int cout, int h, int w, int act, tg_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) + bias
+ * + activation, as 4 sub-pixel phase GEMMs (no zero MACs), fp32 MFMA.
+ * Replaces SRNet.conv_up, tecogan_nets.py:119-126.   y is (n, cout, 2h, 2w).
+ * Weights packed with tg_conv3x3_pack(..., ocb=64, transposed=1).
+ * ---------------------------------------------------------------------- */
+int tg_convt3x3s2_fwd(const float* x, int64_t x_nstride, const float* w_packed,
+                      const float* bias, float* y, int64_t y_nstride, int n,
+                      int cin, int cout, int h, int w, int act,
+                      tg_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * 3x3 conv with a tiny output-channel count (cout <= 4), direct fp32 VALU
+ * kernel (an MFMA tile would be >90 % padding).  Replaces FNet.flow[2]
+ * (32->2, +tanh*24, tecogan_nets.py:65,80) and SRNet.conv_out (64->3,
+ * tecogan_nets.py:131) with the `out += upsample_func(lr_curr)` residual
+ * (:145) fused: up_mode/up_scale describe how `up_src` (n, cout, h/up_scale,
+ * w/up_scale) is up-sampled and added.  w_oihw is the plain (cout,cin,3,3).
+ * ---------------------------------------------------------------------- */
+int tg_conv3x3_small_fwd(const float* x, int64_t x_nstride, const float* w_oihw,
+                         const float* bias, const float* up_src, int up_mode,
+                         int up_scale, float* y, int64_t y_nstride, int n,
+                         int cin, int cout, int h, int w, int act,
+                         tg_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Fused: reflect-pad(bottom/right) -> scale * upsample -> backward_warp ->
+ * space_to_depth.   Replaces tecogan_nets.py:238-250 (step) / :189,203,208
+ * (forward_sequence):
+ *   lr_flow (n, 2, fh, fw) with fh = h/8*8, fw = w/8*8 (FNet output);
+ *   hr_prev (n, c, s*h, s*w);
+ *   out[n, (sy*s+sx)*c + ch, oy, ox] = warp(hr_prev, s*up(pad(lr_flow)))[n, ch, oy*s+sy, ox*s+sx]
+ * written at out + n*out_nstride (so it can land in the channel slice of the
+ * SRNet input buffer).  hr_flow_out (n,2,s*h,s*w) may be NULL; when given the
+ * up-sampled flow is also stored (training needs it for D and for backward).
+ * ---------------------------------------------------------------------- */
+int tg_flowup_warp_s2d_fwd(const float* lr_flow, int fh, int fw,
+                           const float* hr_prev, float* out,
+                           int64_t out_nstride, float* hr_flow_out, int n,
+                           int c, int h, int w, int scale, int up_mode,
+                           tg_stream_t stream);
+
+/* backward_warp(x, flow): codes/utils/net_utils.py:50-82 (grid_sample bilinear,
+ * border, align_corners=True; flow ch0 = x, ch1 = y, in pixels). */
+int tg_backward_warp_fwd(const float* x, const float* flow, float* y, int n,
+                         int c, int h, int w, tg_stream_t stream);
+
+/* space_to_depth(x, s): net_utils.py:36-47.  x (n,c,h,w) -> y (n,s*s*c,h/s,w/s) */
+int tg_space_to_depth(const float* x, float* y, int64_t y_nstride, int n, int c,
+                      int h, int w, int scale, tg_stream_t stream);
+
+/* upsample_func: BicubicUpsampler.forward net_utils.py:133-156 /
+ * F.interpolate bilinear :86-89.  x (nc,h,w) -> y (nc, s*h, s*w), y = mul * up(x). */
+int tg_upsample_fwd(const float* x, float* y, int nc, int h, int w, int scale,
+                    int up_mode, float mul, tg_stream_t stream);
+
+/* nn.MaxPool2d(2,2) floor mode: tecogan_nets.py:28,35,42.  y (nc, h/2, w/2) */
+int tg_maxpool2_fwd(const float* x, float* y, int nc, int h, int w,
+                    tg_stream_t stream);
+
+/* float32_to_uint8 + CHW->HWC: codes/utils/data_utils.py:80-87 and the
+ * transpose at tecogan_nets.py:281.  x (c,h,w) fp32 -> y (h,w,c) uint8,
+ * y = uint8(clip(rint(x*255), 0, 255)), rint = round-half-even. */
+int tg_quantize_u8_hwc(const float* x, uint8_t* y, int c, int h, int w,
+                       tg_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Whole-frame plan: one call = FRNet.step (tecogan_nets.py:227-252).  The plan
+ * holds only launch geometry and pointers into a caller-owned workspace and
+ * caller-owned packed weights; it owns no device memory.
+ * ---------------------------------------------------------------------- */
+typedef struct tg_frnet_plan tg_frnet_plan;
+
+typedef struct {
+  int in_nc, out_nc, nf, nb, scale, up_mode; /* FRNet ctor, tecogan_nets.py:154 */
+  int n, h, w;                               /* LR batch / size */
+} tg_frnet_cfg;
+
+/* Weight table handed to the plan: device pointers to packed weights / biases
+ * in the order documented in tecogan-pytorch_amd/models/networks/tecogan_nets.py
+ * (FNet 14 convs, SRNet conv_in, 2*nb resblock convs, 1-2 conv_up, conv_out). */
+typedef struct {
+  const float* w;
+  const float* b;
+} tg_layer_weights;
+
+size_t tg_frnet_workspace_floats(const tg_frnet_cfg* cfg);
+int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weights* layers,
+                         int n_layers, float* workspace, tg_frnet_plan** out);
+void tg_frnet_plan_destroy(tg_frnet_plan* plan);
+/* hr_out may alias nothing else; lr_curr/lr_prev (n,c,h,w), hr_prev/hr_out (n,c,s*h,s*w).
+ * u8_out (optional, n==1 only): (s*h, s*w, c) uint8 quantised frame. */
+int tg_frnet_step(tg_frnet_plan* plan, const float* lr_curr, const float* lr_prev,
+                  const float* hr_prev, float* hr_out, uint8_t* u8_out,
+                  tg_stream_t stream);
+/* number of kernel launches one tg_frnet_step enqueues (for reporting) */
+int tg_frnet_plan_launches(const tg_frnet_plan* plan);
+
+/* Measurement support: launches are grouped in `kinds` = distinct kernel symbols
+ * (what `rocprofv3 --kernel-trace --stats` groups by).  tg_frnet_step_masked
+ * enqueues only the launches whose kind bit is set in kind_mask (buffers keep
+ * the contents of the last full step), so bench.py can bracket one kernel
+ * class with HIP events; tg_frnet_plan_kind_stats returns that class's launch
+ * count and ALGORITHMIC flops / bytes per frame. */
+int tg_frnet_plan_kinds(void);
+const char* tg_frnet_kind_name(int kind);
+int tg_frnet_plan_kind_stats(const tg_frnet_plan* plan, int kind, int* launches,
+                             double* flops, double* bytes);
+int tg_frnet_step_masked(tg_frnet_plan* plan, const float* lr_curr, const float* lr_prev,
+                         const float* hr_prev, float* hr_out, uint8_t* u8_out,
+                         unsigned kind_mask, tg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TECOGAN_HIP_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libtecogan_hip.so (the C ABI in include/tecogan_hip.h).
+
+The library is built in-tree by `csrc/build.sh` (or __graft_entry__.build()).
+Loading failures are loud: there is no fallback path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtecogan_hip.so')
+
+TG_OK = 0
+ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_TANH24 = 0, 1, 2, 3
+UP_NONE, UP_BICUBIC, UP_BILINEAR = 0, 1, 2
+
+P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class FrnetCfg(C.Structure):
+    _fields_ = [(k, C.c_int) for k in
+                ('in_nc', 'out_nc', 'nf', 'nb', 'scale', 'up_mode', 'n', 'h', 'w')]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('b', C.c_void_p)]
+
+
+# name -> (restype, argtypes); must list every symbol include/tecogan_hip.h declares
+SIGNATURES = {
+    'tg_version': (I, []),
+    'tg_last_error_string': (C.c_char_p, []),
+    'tg_conv3x3_pick_ocb': (I, [I]),
+    'tg_conv3x3_packed_floats': (SZ, [I, I, I]),
+    'tg_conv3x3_pack': (I, [P, P, I, I, I, I, P]),
+    'tg_conv3x3_fwd': (I, [P, I64, I, P, I64, P, I, P, P, I64, P, I64, I, I, I, I, I, I, P]),
+    'tg_convt3x3s2_fwd': (I, [P, I64, P, P, P, I64, I, I, I, I, I, I, P]),
+    'tg_conv3x3_small_fwd': (I, [P, I64, P, P, P, I, I, P, I64, I, I, I, I, I, I, P]),
+    'tg_flowup_warp_s2d_fwd': (I, [P, I, I, P, P, I64, P, I, I, I, I, I, I, P]),
+    'tg_backward_warp_fwd': (I, [P, P, P, I, I, I, I, P]),
+    'tg_space_to_depth': (I, [P, P, I64, I, I, I, I, I, P]),
+    'tg_upsample_fwd': (I, [P, P, I, I, I, I, I, F, P]),
+    'tg_maxpool2_fwd': (I, [P, P, I, I, I, P]),
+    'tg_quantize_u8_hwc': (I, [P, P, I, I, I, P]),
+    'tg_frnet_workspace_floats': (SZ, [C.POINTER(FrnetCfg)]),
+    'tg_frnet_plan_create': (I, [C.POINTER(FrnetCfg), C.POINTER(LayerWeights), I, P,
+                                 C.POINTER(C.c_void_p)]),
+    'tg_frnet_plan_destroy': (None, [P]),
+    'tg_frnet_step': (I, [P, P, P, P, P, P, P]),
+    'tg_frnet_plan_launches': (I, [P]),
+    'tg_frnet_plan_kinds': (I, []),
+    'tg_frnet_kind_name': (C.c_char_p, [I]),
+    'tg_frnet_plan_kind_stats': (I, [P, I, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]),
+    'tg_frnet_step_masked': (I, [P, P, P, P, P, P, C.c_uint, P]),
+}
+
+_lib = None
+
+
+class TecoganHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the .so is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise TecoganHipError(
+                f'{LIB_PATH} not found: build it with '
+                f'`bash {os.path.join(_HERE, "csrc", "build.sh")}` '
+                '(hipcc --offload-arch=gfx950).  There is no CPU/ATen fallback.')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if a symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != TG_OK:
+        msg = lib().tg_last_error_string().decode('utf-8', 'replace')
+        raise TecoganHipError(f'{what} failed (code {rc}): {msg}')

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libtecogan_hip.so for gfx950 (MI355X).  Cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=on -Wall -Wno-unused-function"
+OBJS=()
+for f in tg_*.hip; do
+  o="${f%.hip}.o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ tg_common.h -nt "$o" ] || [ ../../include/tecogan_hip.h -nt "$o" ]; then
+    echo "hipcc $f"
+    $HIPCC $FLAGS ${EXTRA_FLAGS:-} -c "$f" -o "$o" &
+  fi
+  OBJS+=("$o")
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libtecogan_hip.so "${OBJS[@]}"
+echo "built $(cd .. && pwd)/libtecogan_hip.so"

@@ -1,0 +1,281 @@
+// Error channel, version, and the whole-frame FRNet.step plan.
+#include <new>
+#include <vector>
+
+#include "tg_common.h"
+
+namespace tg {
+static thread_local char g_err[512] = "ok";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace tg
+
+extern "C" int tg_version(void) { return 100; }
+extern "C" const char* tg_last_error_string(void) { return tg::g_err; }
+
+// ---------------------------------------------------------------------------
+// FRNet.step plan (codes/models/networks/tecogan_nets.py:227-252): the launch
+// list of one recurrent frame, resolved once per (shape, weights).  Owns no
+// device memory: activations live in the caller's workspace.
+// ---------------------------------------------------------------------------
+struct tg_frnet_plan {
+  tg_frnet_cfg cfg;
+  std::vector<tg_layer_weights> L;
+  float *A, *B, *FLOW, *S2D, *U1, *U2;
+  int fh, fw, launches;
+  int st_launch[16];
+  double st_flops[16], st_bytes[16];
+};
+
+static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
+                     const float* hr_prev, float* hr_out, uint8_t* u8_out, tg_stream_t st,
+                     unsigned mask, bool dry);
+
+static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+static void carve(const tg_frnet_cfg* c, size_t off[7]) {
+  size_t hw = (size_t)c->h * c->w, n = c->n;
+  size_t o = 0;
+  off[0] = o; o += align64(n * 64 * hw);                       // A
+  off[1] = o; o += align64(n * 64 * hw);                       // B
+  off[2] = o; o += align64(n * 2 * hw);                        // FLOW
+  off[3] = o; o += align64(n * c->scale * c->scale * c->in_nc * hw);  // S2D
+  off[4] = o; o += align64(n * c->nf * 4 * hw);                // U1
+  off[5] = o; o += (c->scale == 4) ? align64(n * c->nf * 16 * hw) : 0;  // U2
+  off[6] = o;
+}
+
+static int cfg_ok(const tg_frnet_cfg* c) {
+  return c && c->in_nc == 3 && c->out_nc >= 1 && c->out_nc <= 4 && c->nf >= 1 && c->nf <= 64 &&
+         c->nb >= 0 && (c->scale == 2 || c->scale == 4) &&
+         (c->up_mode == TG_UP_BICUBIC || c->up_mode == TG_UP_BILINEAR) && c->n >= 1 &&
+         c->h >= 8 && c->w >= 8;
+}
+
+extern "C" size_t tg_frnet_workspace_floats(const tg_frnet_cfg* cfg) {
+  if (!cfg_ok(cfg)) return 0;
+  size_t off[7];
+  carve(cfg, off);
+  return off[6];
+}
+
+extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weights* layers,
+                                    int n_layers, float* workspace, tg_frnet_plan** out) {
+  TG_REQUIRE(cfg && layers && workspace && out, TG_E_ARG, "frnet_plan_create: null pointer");
+  TG_REQUIRE(cfg_ok(cfg), TG_E_SHAPE,
+             "frnet_plan_create: unsupported cfg (in_nc=3, out_nc<=4, nf<=64, scale 2|4, h,w>=8)");
+  int nup = cfg->scale == 4 ? 2 : 1;
+  int need = 14 + 1 + 2 * cfg->nb + nup + 1;
+  TG_REQUIRE(n_layers == need, TG_E_ARG, "frnet_plan_create: %d layers given, %d expected",
+             n_layers, need);
+  for (int i = 0; i < n_layers; ++i)
+    TG_REQUIRE(layers[i].w && layers[i].b, TG_E_ARG, "frnet_plan_create: layer %d null", i);
+  tg_frnet_plan* p = new (std::nothrow) tg_frnet_plan();
+  TG_REQUIRE(p, TG_E_ARG, "frnet_plan_create: out of host memory");
+  p->cfg = *cfg;
+  p->L.assign(layers, layers + n_layers);
+  size_t off[7];
+  carve(cfg, off);
+  p->A = workspace + off[0]; p->B = workspace + off[1]; p->FLOW = workspace + off[2];
+  p->S2D = workspace + off[3]; p->U1 = workspace + off[4];
+  p->U2 = cfg->scale == 4 ? workspace + off[5] : nullptr;
+  p->fh = cfg->h / 8 * 8; p->fw = cfg->w / 8 * 8;
+  for (int k = 0; k < 16; ++k) { p->st_launch[k] = 0; p->st_flops[k] = 0; p->st_bytes[k] = 0; }
+  // dry run: per-kernel-class launch counts, algorithmic flops and bytes of one frame
+  // (dummy non-null pointers; nothing is dereferenced or launched)
+  static float dummy;
+  step_impl(p, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, 0, true);
+  p->launches = 0;
+  for (int k = 0; k < 16; ++k) p->launches += p->st_launch[k];
+  p->launches -= p->st_launch[8];  // quantise only runs when a u8 output is requested
+  *out = p;
+  return TG_OK;
+}
+
+extern "C" void tg_frnet_plan_destroy(tg_frnet_plan* plan) { delete plan; }
+extern "C" int tg_frnet_plan_launches(const tg_frnet_plan* plan) { return plan ? plan->launches : 0; }
+
+// Launch classes = distinct kernel symbols (what rocprofv3 --stats groups by).
+enum {
+  K_CONV64_R2 = 0,  // conv3x3_mfma_kernel<2,2,1>
+  K_CONV64_R4 = 1,  // conv3x3_mfma_kernel<4,1,2>
+  K_CONV32 = 2,     // conv3x3_mfma_kernel<4,1,1>
+  K_CONVT = 3,      // convt3x3s2_mfma_kernel<4,2>
+  K_SMALL = 4,      // conv3x3_small_kernel<COUT>
+  K_WARP = 5,       // flowup_warp_s2d_kernel<S,3>
+  K_POOL = 6,
+  K_UPSAMPLE = 7,
+  K_QUANT = 8,
+  K_COUNT = 9
+};
+
+static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
+                     const float* hr_prev, float* hr_out, uint8_t* u8_out, tg_stream_t st,
+                     unsigned mask, bool dry) {
+  const tg_frnet_cfg& c = p->cfg;
+  const int n = c.n, h = c.h, w = c.w, s = c.scale;
+  const int64_t hw = (int64_t)h * w;
+  int li = 0;
+  float *A = p->A, *B = p->B;
+  int rc = TG_OK;
+  // account + (unless dry / masked out) launch
+  auto go = [&](int kind, double flops, double bytes, auto&& fn) {
+    if (rc != TG_OK) return;
+    if (dry) {
+      p->st_launch[kind] += 1; p->st_flops[kind] += flops; p->st_bytes[kind] += bytes;
+      return;
+    }
+    if (mask & (1u << kind)) rc = fn();
+  };
+  auto conv = [&](const float* x, int64_t xns, int c1, const float* x2, int64_t x2ns, int cin,
+                  int cout, int hh, int ww, int act, const float* res, int64_t rns, float* y,
+                  int64_t yns) {
+    const tg_layer_weights lw = p->L[li++];
+    int ocb = tg_conv3x3_pick_ocb(cout);
+    int kind = ocb == 32 ? K_CONV32
+                         : (tg::conv3x3_rows_per_wg(ocb, (long long)n * hh * ww) == 4 ? K_CONV64_R4
+                                                                                       : K_CONV64_R2);
+    double px = (double)n * hh * ww;
+    double fl = 2.0 * cin * 9 * cout * px;
+    double by = 4.0 * px * (cin + cout + (res ? cout : 0)) + 4.0 * 9 * cin * cout;
+    go(kind, fl, by, [&] {
+      return tg_conv3x3_fwd(x, xns, c1, x2, x2ns, lw.w, ocb, lw.b, res, rns, y, yns, n, cin, cout,
+                            hh, ww, act, st);
+    });
+  };
+  // ---- FNet (tecogan_nets.py:67-82) ------------------------------------------
+  int hh = h, ww = w;
+  const int enc[3] = {32, 64, 128};
+  int cin = 2 * c.in_nc;
+  const float* src = nullptr;
+  for (int e = 0; e < 3; ++e) {
+    int co = enc[e];
+    if (e == 0)
+      conv(lr_curr, c.in_nc * hw, c.in_nc, lr_prev, c.in_nc * hw, cin, co, hh, ww, TG_ACT_LRELU02,
+           nullptr, 0, A, (int64_t)co * hh * ww);
+    else
+      conv(src, (int64_t)cin * hh * ww, cin, nullptr, 0, cin, co, hh, ww, TG_ACT_LRELU02, nullptr,
+           0, A, (int64_t)co * hh * ww);
+    conv(A, (int64_t)co * hh * ww, co, nullptr, 0, co, co, hh, ww, TG_ACT_LRELU02, nullptr, 0, B,
+         (int64_t)co * hh * ww);
+    {
+      float *pi = B, *po = A; int ph = hh, pw = ww;
+      go(K_POOL, 0, 4.0 * n * co * (ph * pw + (ph / 2) * (pw / 2)),
+         [&] { return tg_maxpool2_fwd(pi, po, n * co, ph, pw, st); });
+    }
+    hh /= 2; ww /= 2; cin = co;
+    float* t = A; A = B; B = t;   // pooled result now in B
+    src = B;
+  }
+  const int dec[3] = {256, 128, 64};
+  for (int d = 0; d < 3; ++d) {
+    int co = dec[d];
+    conv(src, (int64_t)cin * hh * ww, cin, nullptr, 0, cin, co, hh, ww, TG_ACT_LRELU02, nullptr, 0,
+         A, (int64_t)co * hh * ww);
+    conv(A, (int64_t)co * hh * ww, co, nullptr, 0, co, co, hh, ww, TG_ACT_LRELU02, nullptr, 0, B,
+         (int64_t)co * hh * ww);
+    {
+      float *pi = B, *po = A; int ph = hh, pw = ww;
+      go(K_UPSAMPLE, 0, 4.0 * n * co * ph * pw * 5.0,
+         [&] { return tg_upsample_fwd(pi, po, n * co, ph, pw, 2, TG_UP_BILINEAR, 1.0f, st); });
+    }
+    hh *= 2; ww *= 2; cin = co;
+    float* t = A; A = B; B = t;
+    src = B;
+  }
+  conv(src, (int64_t)cin * hh * ww, cin, nullptr, 0, cin, 32, hh, ww, TG_ACT_LRELU02, nullptr, 0, A,
+       (int64_t)32 * hh * ww);
+  {
+    const tg_layer_weights lw = p->L[li++];
+    float* ai = A; int fh_ = hh, fw_ = ww;
+    go(K_SMALL, 2.0 * 32 * 9 * 2 * n * fh_ * fw_, 4.0 * n * fh_ * fw_ * 34, [&] {
+      return tg_conv3x3_small_fwd(ai, (int64_t)32 * fh_ * fw_, lw.w, lw.b, nullptr, TG_UP_NONE, 1,
+                                  p->FLOW, (int64_t)2 * fh_ * fw_, n, 32, 2, fh_, fw_,
+                                  TG_ACT_TANH24, st);
+    });
+  }
+  // ---- pad + upsample + warp + space_to_depth (tecogan_nets.py:238-250) -------
+  const int s2dc = s * s * c.in_nc;
+  go(K_WARP, 0,
+     4.0 * n * ((double)c.in_nc * s * s * hw * 2 + 2.0 * p->fh * p->fw), [&] {
+       return tg_flowup_warp_s2d_fwd(p->FLOW, p->fh, p->fw, hr_prev, p->S2D, s2dc * hw, nullptr, n,
+                                     c.in_nc, h, w, s, c.up_mode, st);
+     });
+  // ---- SRNet (tecogan_nets.py:136-147) ----------------------------------------
+  A = p->A; B = p->B;
+  const int nf = c.nf;
+  conv(lr_curr, c.in_nc * hw, c.in_nc, p->S2D, s2dc * hw, c.in_nc + s2dc, nf, h, w, TG_ACT_RELU,
+       nullptr, 0, A, nf * hw);
+  for (int b = 0; b < c.nb; ++b) {
+    conv(A, nf * hw, nf, nullptr, 0, nf, nf, h, w, TG_ACT_RELU, nullptr, 0, B, nf * hw);
+    conv(B, nf * hw, nf, nullptr, 0, nf, nf, h, w, TG_ACT_NONE, A, nf * hw, A, nf * hw);
+  }
+  {
+    const tg_layer_weights lw = p->L[li++];
+    float* ai = A;
+    go(K_CONVT, 2.0 * nf * 9 * nf * n * hw, 4.0 * n * hw * nf * 5.0, [&] {
+      return tg_convt3x3s2_fwd(ai, nf * hw, lw.w, lw.b, p->U1, nf * 4 * hw, n, nf, nf, h, w,
+                               TG_ACT_RELU, st);
+    });
+  }
+  const float* top = p->U1;
+  if (s == 4) {
+    const tg_layer_weights lw = p->L[li++];
+    go(K_CONVT, 2.0 * nf * 9 * nf * n * 4 * hw, 4.0 * n * 4 * hw * nf * 5.0, [&] {
+      return tg_convt3x3s2_fwd(p->U1, nf * 4 * hw, lw.w, lw.b, p->U2, nf * 16 * hw, n, nf, nf,
+                               2 * h, 2 * w, TG_ACT_RELU, st);
+    });
+    top = p->U2;
+  }
+  {
+    const tg_layer_weights lw = p->L[li++];
+    double hpx = (double)n * s * s * hw;
+    go(K_SMALL, 2.0 * nf * 9 * c.out_nc * hpx, 4.0 * hpx * (nf + c.out_nc), [&] {
+      return tg_conv3x3_small_fwd(top, (int64_t)nf * s * s * hw, lw.w, lw.b, lr_curr, c.up_mode, s,
+                                  hr_out, (int64_t)c.out_nc * s * s * hw, n, nf, c.out_nc, s * h,
+                                  s * w, TG_ACT_NONE, st);
+    });
+  }
+  if (u8_out || dry) {
+    go(K_QUANT, 0, 5.0 * c.out_nc * s * s * hw,
+       [&] { return tg_quantize_u8_hwc(hr_out, u8_out, c.out_nc, s * h, s * w, st); });
+  }
+  return rc;
+}
+
+extern "C" int tg_frnet_step(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
+                             const float* hr_prev, float* hr_out, uint8_t* u8_out,
+                             tg_stream_t st) {
+  return tg_frnet_step_masked(p, lr_curr, lr_prev, hr_prev, hr_out, u8_out, 0xFFFFFFFFu, st);
+}
+
+extern "C" int tg_frnet_step_masked(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
+                                    const float* hr_prev, float* hr_out, uint8_t* u8_out,
+                                    unsigned kind_mask, tg_stream_t st) {
+  TG_REQUIRE(p && lr_curr && lr_prev && hr_prev && hr_out, TG_E_ARG, "frnet_step: null pointer");
+  TG_REQUIRE(!u8_out || p->cfg.n == 1, TG_E_ARG, "frnet_step: u8 output needs n == 1");
+  return step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, u8_out, st, kind_mask, false);
+}
+
+extern "C" int tg_frnet_plan_kinds(void) { return K_COUNT; }
+
+extern "C" const char* tg_frnet_kind_name(int kind) {
+  static const char* names[K_COUNT] = {
+      "conv3x3_mfma_kernel<2,2,1>", "conv3x3_mfma_kernel<4,1,2>", "conv3x3_mfma_kernel<4,1,1>",
+      "convt3x3s2_mfma_kernel<4,2>", "conv3x3_small_kernel",       "flowup_warp_s2d_kernel",
+      "maxpool2_kernel",             "upsample_kernel",            "quantize_u8_hwc_kernel"};
+  return (kind >= 0 && kind < K_COUNT) ? names[kind] : "?";
+}
+
+extern "C" int tg_frnet_plan_kind_stats(const tg_frnet_plan* p, int kind, int* launches,
+                                        double* flops, double* bytes) {
+  TG_REQUIRE(p && kind >= 0 && kind < K_COUNT, TG_E_ARG, "plan_kind_stats: bad argument");
+  if (launches) *launches = p->st_launch[kind];
+  if (flops) *flops = p->st_flops[kind];
+  if (bytes) *bytes = p->st_bytes[kind];
+  return TG_OK;
+}

@@ -1,0 +1,100 @@
+// Shared helpers for libtecogan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tecogan_hip.h"
+
+namespace tg {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return TG_E_HIP;
+  }
+  return TG_OK;
+}
+
+#define TG_REQUIRE(cond, code, ...) \
+  do {                              \
+    if (!(cond)) {                  \
+      tg::set_error(__VA_ARGS__);   \
+      return (code);                \
+    }                               \
+  } while (0)
+
+// rows of the image one conv3x3 workgroup covers (selects the kernel variant):
+// 64-oc blocks use the 4-row / 2-tile-per-wave variant on big images and the
+// 2-row variant (twice the workgroups) where tile quantisation dominates.
+inline int conv3x3_rows_per_wg(int ocb, long long pixels) {
+  if (ocb == 32) return 4;
+  return pixels >= 200000 ? 4 : 2;
+}
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// input-channel chunk streamed through LDS per K-step group
+constexpr int CK = 8;
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case TG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case TG_ACT_LRELU02: return v >= 0.f ? v : v * 0.2f;
+    case TG_ACT_TANH24: return tanhf(v) * 24.f;
+    default: return v;
+  }
+}
+
+// ---- shared sampling arithmetic (device) ---------------------------------
+// BicubicUpsampler weights (net_utils.py:113-127), a = -0.75, fp32, evaluated
+// exactly as cubic @ [1, s, s^2, s^3] with s = d/f.
+__device__ __forceinline__ void bicubic_w(int d, int f, float k[4]) {
+  const float a = -0.75f;
+  float s = (float)d / (float)f;  // 1.0*d/f in double then fp32 in the reference; d/f exact for f in {2,4}
+  float s2 = s * s, s3 = s2 * s;
+  // rows of the Keys matrix times [1, s, s2, s3], left-to-right accumulation
+  k[0] = ((0.f * 1.f + a * s) + (-2.f * a) * s2) + a * s3;
+  k[1] = ((1.f * 1.f + 0.f * s) + (-(a + 3.f)) * s2) + (a + 2.f) * s3;
+  k[2] = ((0.f * 1.f + (-a) * s) + (2.f * a + 3.f) * s2) + (-(a + 2.f)) * s3;
+  k[3] = ((0.f * 1.f + 0.f * s) + a * s2) + (-a) * s3;
+}
+
+// F.interpolate(bilinear, align_corners=False), integer scale: source taps.
+__device__ __forceinline__ void bilinear_src(int dst, int scale, int in_size,
+                                             int& i0, int& i1, float& l0,
+                                             float& l1) {
+  float src = ((float)dst + 0.5f) * (1.0f / (float)scale) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)floorf(src);
+  i1 = i0 + 1 < in_size ? i0 + 1 : in_size - 1;
+  l1 = src - (float)i0;
+  l0 = 1.0f - l1;
+}
+
+// fp32 torch.linspace(-1, 1, n)[i] (ATen CPU: two fused multiply-adds)
+__device__ __forceinline__ float linspace_m1p1(int i, int n, float step) {
+  return (i < n / 2) ? __builtin_fmaf(step, (float)i, -1.0f)
+                     : __builtin_fmaf(-step, (float)(n - 1 - i), 1.0f);
+}
+
+// Sampling position of backward_warp along one axis (net_utils.py:62-78 +
+// grid_sample align_corners=True, padding_mode='border').
+__device__ __forceinline__ float warp_coord(int i, int n, float flow) {
+  float step = 2.0f / (float)(n - 1);
+  float half = (float)(n - 1) / 2.0f;
+  float g = linspace_m1p1(i, n, step) + flow / half;
+  float p = (g + 1.0f) * half;
+  p = p < 0.f ? 0.f : p;  // clip_coordinates; also maps NaN->0 like fmax
+  p = p > (float)(n - 1) ? (float)(n - 1) : p;
+  return p;
+}
+
+}  // namespace tg

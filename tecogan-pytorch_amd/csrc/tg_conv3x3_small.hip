@@ -1,0 +1,226 @@
+// 3x3 conv with <= 4 output channels: direct fp32 VALU kernel for gfx950.
+//
+// An MFMA tile has at least 16 (32) output rows; with cout = 2 or 3 more than
+// 80-90 % of the matrix core would multiply padding, so this layer type runs
+// on the vector ALU instead: each lane owns 4 consecutive pixels x COUT
+// channels (<= 12 accumulators); per (cin, ky) it reads 6 input floats from
+// the LDS halo patch (one b128 + one b64) and issues 3*4*COUT FMAs against
+// wave-uniform weights (scalar registers / LDS broadcast).
+//
+// Fused epilogue: bias, activation (tanh*24 for the flow head), and the
+// `out += upsample_func(lr_curr)` residual of SRNet.forward
+// (codes/models/networks/tecogan_nets.py:145) evaluated per output pixel from
+// the low-resolution source (bicubic: net_utils.py:133-156, bilinear: :86-89).
+//
+// Replaces FNet.flow[2] (tecogan_nets.py:65,80) and SRNet.conv_out (:131,145).
+#include "tg_common.h"
+
+namespace tg {
+
+constexpr int S_TH = 16;          // tile rows
+constexpr int S_TWT = 16;         // thread columns
+constexpr int S_PXT = 4;          // pixels per thread along x
+constexpr int S_TW = S_TWT * S_PXT;   // 64
+constexpr int S_PH = S_TH + 2;
+constexpr int S_PW = S_TW + 2;    // 66
+constexpr int S_RS = 68;          // LDS row stride (16-byte aligned rows)
+constexpr int S_CK = 4;           // cin chunk
+
+struct SmallArgs {
+  const float* x;
+  const float* wt;     // OIHW
+  const float* bias;
+  const float* up;     // (n, cout, h/us, w/us) or null
+  float* y;
+  long long x_ns, y_ns;
+  int cin, cout, h, w, act, up_mode, up_scale;
+  int tiles_x, tiles_y;
+};
+
+template <int COUT>
+__device__ __forceinline__ void add_upsampled(const SmallArgs& a, int n, int py, int px,
+                                              float v[COUT]) {
+  const int us = a.up_scale;
+  const int lh = a.h / us, lw = a.w / us;
+  const float* src = a.up + (long long)n * COUT * lh * lw;
+  if (a.up_mode == TG_UP_BICUBIC) {
+    const int i = py / us, dy = py - i * us, j = px / us, dx = px - j * us;
+    float ky[4], kx[4];
+    bicubic_w(dy, us, ky);
+    bicubic_w(dx, us, kx);
+    int ri[4], ci[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      int r = i - 1 + p; ri[p] = r < 0 ? 0 : (r > lh - 1 ? lh - 1 : r);
+      int c = j - 1 + p; ci[p] = c < 0 ? 0 : (c > lw - 1 ? lw - 1 : c);
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      const float* s = src + (long long)o * lh * lw;
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float vq = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) vq += ky[p] * s[ri[p] * lw + ci[q]];
+        acc += kx[q] * vq;
+      }
+      v[o] += acc;
+    }
+  } else {  // bilinear, align_corners=False
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    bilinear_src(py, us, lh, y0, y1, ly0, ly1);
+    bilinear_src(px, us, lw, x0, x1, lx0, lx1);
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      const float* s = src + (long long)o * lh * lw;
+      float top = lx0 * s[y0 * lw + x0] + lx1 * s[y0 * lw + x1];
+      float bot = lx0 * s[y1 * lw + x0] + lx1 * s[y1 * lw + x1];
+      v[o] += ly0 * top + ly1 * bot;
+    }
+  }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(SmallArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_in[2][S_CK][S_PH][S_RS];
+  __shared__ float s_w[COUT * 9 * 64];   // [cin][tap][COUT], cin <= 64
+
+  const int tid = threadIdx.x;
+  const int tcx = tid % S_TWT, tcy = tid / S_TWT;
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int x0 = tx * S_TW, y0 = ty * S_TH;
+  const long long hw = (long long)a.h * a.w;
+  const float* xb = a.x + (long long)n * a.x_ns;
+
+  // weights -> LDS as [cin][tap][COUT]
+  for (int i = tid; i < a.cin * 9 * COUT; i += 256) {
+    int o = i % COUT, t = (i / COUT) % 9, c = i / (COUT * 9);
+    s_w[i] = a.wt[((size_t)o * a.cin + c) * 9 + t];
+  }
+
+  constexpr int PATCH = S_PH * S_PW;                       // 1188 per channel
+  constexpr int PER_T = (S_CK * PATCH + 255) / 256;        // 19
+  float rin[PER_T];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      int idx = tid + i * 256;
+      int c = idx / PATCH, rem = idx - c * PATCH;
+      int r = rem / S_PW, col = rem - r * S_PW;
+      int gy = y0 - 1 + r, gx = x0 - 1 + col;
+      float v = 0.f;
+      if (c < S_CK && c0 + c < a.cin && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w)
+        v = xb[(long long)(c0 + c) * hw + (long long)gy * a.w + gx];
+      rin[i] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+      int idx = tid + i * 256;
+      int c = idx / PATCH, rem = idx - c * PATCH;
+      int r = rem / S_PW, col = rem - r * S_PW;
+      if (c < S_CK) s_in[buf][c][r][col] = rin[i];
+    }
+  };
+
+  float acc[COUT][S_PXT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o)
+#pragma unroll
+    for (int p = 0; p < S_PXT; ++p) acc[o][p] = 0.f;
+
+  const int nchunk = cdiv(a.cin, S_CK);
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    const bool more = ch + 1 < nchunk;
+    if (more) load_chunk((ch + 1) * S_CK);
+#pragma unroll
+    for (int c = 0; c < S_CK; ++c) {
+      const int cg = ch * S_CK + c;
+      if (cg < a.cin) {
+        const float* wc = s_w + cg * 9 * COUT;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* row = &s_in[buf][c][tcy + ky][tcx * S_PXT];
+          float4 v4 = *reinterpret_cast<const float4*>(row);
+          float2 v2 = *reinterpret_cast<const float2*>(row + 4);
+          float in6[6] = {v4.x, v4.y, v4.z, v4.w, v2.x, v2.y};
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+              float wv = wc[(ky * 3 + kx) * COUT + o];
+#pragma unroll
+              for (int p = 0; p < S_PXT; ++p) acc[o][p] += wv * in6[p + kx];
+            }
+          }
+        }
+      }
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int py = y0 + tcy;
+  if (py < a.h) {
+#pragma unroll
+    for (int p = 0; p < S_PXT; ++p) {
+      const int px = x0 + tcx * S_PXT + p;
+      if (px < a.w) {
+        float v[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+          v[o] = apply_act(acc[o][p] + (a.bias ? a.bias[o] : 0.f), a.act);
+        if (a.up) add_upsampled<COUT>(a, n, py, px, v);
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+          a.y[(long long)n * a.y_ns + (long long)o * hw + (long long)py * a.w + px] = v[o];
+      }
+    }
+  }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" int tg_conv3x3_small_fwd(const float* x, int64_t x_nstride, const float* w_oihw,
+                                    const float* bias, const float* up_src, int up_mode,
+                                    int up_scale, float* y, int64_t y_nstride, int n, int cin,
+                                    int cout, int h, int w, int act, tg_stream_t stream) {
+  TG_REQUIRE(x && w_oihw && y, TG_E_ARG, "conv3x3_small_fwd: null pointer");
+  TG_REQUIRE(n > 0 && cin > 0 && cin <= 64 && cout >= 1 && cout <= 4 && h > 0 && w > 0,
+             TG_E_SHAPE, "conv3x3_small_fwd: n=%d cin=%d (<=64) cout=%d (<=4) h=%d w=%d", n, cin,
+             cout, h, w);
+  TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_TANH24, TG_E_ARG, "conv3x3_small: act=%d", act);
+  if (up_src) {
+    TG_REQUIRE((up_mode == TG_UP_BICUBIC || up_mode == TG_UP_BILINEAR) && up_scale >= 1 &&
+                   h % up_scale == 0 && w % up_scale == 0,
+               TG_E_SHAPE, "conv3x3_small_fwd: up_mode=%d up_scale=%d", up_mode, up_scale);
+  }
+  SmallArgs a{};
+  a.x = x; a.wt = w_oihw; a.bias = bias; a.up = up_src; a.y = y; a.x_ns = x_nstride;
+  a.y_ns = y_nstride; a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
+  a.up_mode = up_mode; a.up_scale = up_scale;
+  a.tiles_x = cdiv(w, S_TW); a.tiles_y = cdiv(h, S_TH);
+  long long blocks = (long long)a.tiles_x * a.tiles_y * n;
+  TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "conv3x3_small: grid %lld", blocks);
+  dim3 g((unsigned)blocks), t(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (cout) {
+    case 1: hipLaunchKernelGGL(conv3x3_small_kernel<1>, g, t, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(conv3x3_small_kernel<2>, g, t, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(conv3x3_small_kernel<3>, g, t, 0, s, a); break;
+    default: hipLaunchKernelGGL(conv3x3_small_kernel<4>, g, t, 0, s, a); break;
+  }
+  return check_launch("conv3x3_small");
+}

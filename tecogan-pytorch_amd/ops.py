@@ -1,0 +1,168 @@
+"""Tensor-level wrappers over the C ABI.  PyTorch is plumbing here: it owns the
+device memory and the stream; every computation is a HIP kernel from
+libtecogan_hip.so.  All tensors must be CUDA(HIP) fp32 and contiguous."""
+import torch
+
+from . import _lib as L
+from ._lib import (ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_TANH24,  # noqa: F401
+                   UP_NONE, UP_BICUBIC, UP_BILINEAR)
+
+UP_MODE = {'BD': UP_BICUBIC, 'BI': UP_BILINEAR}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise L.TecoganHipError(f'{name}: expected a CUDA/HIP tensor (no CPU path exists)')
+    if t.dtype != dtype:
+        raise L.TecoganHipError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise L.TecoganHipError(f'{name}: tensor must be contiguous')
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def pick_ocb(cout):
+    return L.lib().tg_conv3x3_pick_ocb(int(cout))
+
+
+def pack_conv3x3(weight, transposed=False, ocb=None):
+    """nn.Conv2d.weight (cout,cin,3,3) [or ConvTranspose2d (cin,cout,3,3)] ->
+    kernel layout.  Returns (packed, cin, cout, ocb)."""
+    w = _chk(weight.detach(), 'weight')
+    if w.dim() != 4 or w.shape[2:] != (3, 3):
+        raise L.TecoganHipError(f'pack_conv3x3: weight shape {tuple(w.shape)}')
+    if transposed:
+        cin, cout = w.shape[0], w.shape[1]
+        ocb = 64
+    else:
+        cout, cin = w.shape[0], w.shape[1]
+        ocb = ocb or pick_ocb(cout)
+    nfl = L.lib().tg_conv3x3_packed_floats(cin, cout, ocb)
+    out = torch.empty(nfl, dtype=torch.float32, device=w.device)
+    L.check(L.lib().tg_conv3x3_pack(w.data_ptr(), out.data_ptr(), cin, cout, ocb,
+                                    1 if transposed else 0, _stream()), 'tg_conv3x3_pack')
+    return out, cin, cout, ocb
+
+
+def conv3x3(x, wpk, bias, cin, cout, ocb, act=ACT_NONE, x2=None, res=None, out=None):
+    """y = act(conv3x3(cat[x, x2]) + bias) (+ res).  x: (n,c1,h,w), x2: (n,cin-c1,h,w)."""
+    _chk(x, 'x')
+    n, c1, h, w = x.shape
+    if x2 is not None:
+        _chk(x2, 'x2')
+        if x2.shape[0] != n or x2.shape[2:] != x.shape[2:] or c1 + x2.shape[1] != cin:
+            raise L.TecoganHipError(f'conv3x3: x {tuple(x.shape)} x2 {tuple(x2.shape)} cin {cin}')
+    elif c1 != cin:
+        raise L.TecoganHipError(f'conv3x3: x has {c1} channels, weights expect {cin}')
+    if out is None:
+        out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    _chk(out, 'out')
+    if res is not None:
+        _chk(res, 'res')
+        if res.shape != out.shape:
+            raise L.TecoganHipError('conv3x3: residual shape mismatch')
+    hw = h * w
+    L.check(L.lib().tg_conv3x3_fwd(
+        x.data_ptr(), c1 * hw, c1, _ptr(x2), 0 if x2 is None else x2.shape[1] * hw,
+        wpk.data_ptr(), ocb, _ptr(bias), _ptr(res), cout * hw, out.data_ptr(), cout * hw,
+        n, cin, cout, h, w, act, _stream()), 'tg_conv3x3_fwd')
+    return out
+
+
+def convt3x3s2(x, wpk, bias, cout, act=ACT_NONE, out=None):
+    _chk(x, 'x')
+    n, cin, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, cout, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_convt3x3s2_fwd(x.data_ptr(), cin * h * w, wpk.data_ptr(), _ptr(bias),
+                                      out.data_ptr(), cout * 4 * h * w, n, cin, cout, h, w, act,
+                                      _stream()), 'tg_convt3x3s2_fwd')
+    return out
+
+
+def conv3x3_small(x, weight, bias, act=ACT_NONE, up_src=None, up_mode=UP_NONE, up_scale=1,
+                  out=None):
+    _chk(x, 'x')
+    w_ = _chk(weight.detach(), 'weight')
+    n, cin, h, w = x.shape
+    cout = w_.shape[0]
+    if out is None:
+        out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    if up_src is not None:
+        _chk(up_src, 'up_src')
+    L.check(L.lib().tg_conv3x3_small_fwd(
+        x.data_ptr(), cin * h * w, w_.data_ptr(), _ptr(bias), _ptr(up_src), up_mode, up_scale,
+        out.data_ptr(), cout * h * w, n, cin, cout, h, w, act, _stream()), 'tg_conv3x3_small_fwd')
+    return out
+
+
+def flowup_warp_s2d(lr_flow, hr_prev, h, w, scale, up_mode, out=None, want_hr_flow=False):
+    _chk(lr_flow, 'lr_flow')
+    _chk(hr_prev, 'hr_prev')
+    n, c = hr_prev.shape[:2]
+    fh, fw = lr_flow.shape[2:]
+    if out is None:
+        out = torch.empty(n, scale * scale * c, h, w, dtype=torch.float32, device=hr_prev.device)
+    hr_flow = (torch.empty(n, 2, scale * h, scale * w, dtype=torch.float32, device=hr_prev.device)
+               if want_hr_flow else None)
+    L.check(L.lib().tg_flowup_warp_s2d_fwd(
+        lr_flow.data_ptr(), fh, fw, hr_prev.data_ptr(), out.data_ptr(), scale * scale * c * h * w,
+        _ptr(hr_flow), n, c, h, w, scale, up_mode, _stream()), 'tg_flowup_warp_s2d_fwd')
+    return (out, hr_flow) if want_hr_flow else out
+
+
+def backward_warp(x, flow):
+    _chk(x, 'x')
+    _chk(flow, 'flow')
+    n, c, h, w = x.shape
+    if flow.shape != (n, 2, h, w):
+        raise L.TecoganHipError(f'backward_warp: flow {tuple(flow.shape)} vs x {tuple(x.shape)}')
+    out = torch.empty_like(x)
+    L.check(L.lib().tg_backward_warp_fwd(x.data_ptr(), flow.data_ptr(), out.data_ptr(), n, c, h, w,
+                                         _stream()), 'tg_backward_warp_fwd')
+    return out
+
+
+def space_to_depth(x, scale):
+    _chk(x, 'x')
+    n, c, h, w = x.shape
+    oh, ow = h // scale, w // scale
+    out = torch.empty(n, scale * scale * c, oh, ow, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_space_to_depth(x.data_ptr(), out.data_ptr(), scale * scale * c * oh * ow,
+                                      n, c, h, w, scale, _stream()), 'tg_space_to_depth')
+    return out
+
+
+def upsample(x, scale, up_mode, mul=1.0):
+    _chk(x, 'x')
+    n, c, h, w = x.shape
+    out = torch.empty(n, c, h * scale, w * scale, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_upsample_fwd(x.data_ptr(), out.data_ptr(), n * c, h, w, scale, up_mode,
+                                    float(mul), _stream()), 'tg_upsample_fwd')
+    return out
+
+
+def maxpool2(x):
+    _chk(x, 'x')
+    n, c, h, w = x.shape
+    out = torch.empty(n, c, h // 2, w // 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_maxpool2_fwd(x.data_ptr(), out.data_ptr(), n * c, h, w, _stream()),
+            'tg_maxpool2_fwd')
+    return out
+
+
+def quantize_u8_hwc(x):
+    """(c,h,w) fp32 -> (h,w,c) uint8 on device."""
+    _chk(x, 'x')
+    c, h, w = x.shape
+    out = torch.empty(h, w, c, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().tg_quantize_u8_hwc(x.data_ptr(), out.data_ptr(), c, h, w, _stream()),
+            'tg_quantize_u8_hwc')
+    return out

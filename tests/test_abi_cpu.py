@@ -1,0 +1,103 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/tecogan_hip.h declares, argument validation returns error
+codes (no crash, no exception across the boundary), and the host-side mirror
+keeps the reference's state-dict layout and profile() numbers.  No kernel is
+launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import tecogan_pytorch_amd  # noqa: F401
+from tecogan_pytorch_amd import _lib as L
+from tecogan_pytorch_amd.models.networks import FRNet, define_generator
+from procedural_weights import generator_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'tecogan_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(tg_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.isfile(L.LIB_PATH):
+        pytest.fail(f'{L.LIB_PATH} missing: run __graft_entry__.build()')
+    handle = ctypes.CDLL(L.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(handle, s), f'{s} declared in tecogan_hip.h but not exported'
+    # and the Python binding table covers the header exactly
+    assert sorted(L.SIGNATURES) == syms
+
+
+def test_error_codes_not_exceptions():
+    lib = L.lib()
+    assert lib.tg_version() >= 100
+    # null pointers -> TG_E_ARG with a message
+    rc = lib.tg_conv3x3_fwd(None, 0, 3, None, 0, None, 64, None, None, 0, None, 0,
+                            1, 3, 64, 8, 8, 0, None)
+    assert rc == -2 and b'null' in lib.tg_last_error_string()
+    rc = lib.tg_backward_warp_fwd(None, None, None, 1, 3, 8, 8, None)
+    assert rc == -2
+    assert lib.tg_conv3x3_packed_floats(3, 64, 48) == 0          # bad ocb
+    assert lib.tg_conv3x3_packed_floats(51, 64, 64) == 7 * 9 * 8 * 64
+    assert lib.tg_conv3x3_pick_ocb(32) == 32 and lib.tg_conv3x3_pick_ocb(64) == 64
+    bad = L.FrnetCfg(4, 3, 64, 10, 4, 1, 1, 134, 320)            # in_nc must be 3
+    assert lib.tg_frnet_workspace_floats(ctypes.byref(bad)) == 0
+    ok = L.FrnetCfg(3, 3, 64, 10, 4, 1, 1, 134, 320)
+    assert lib.tg_frnet_workspace_floats(ctypes.byref(ok)) > 64 * 16 * 134 * 320
+
+
+def test_ops_refuse_cpu_tensors():
+    from tecogan_pytorch_amd import ops
+    with pytest.raises(L.TecoganHipError):
+        ops.backward_warp(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))
+    with pytest.raises(L.TecoganHipError):
+        ops.space_to_depth(torch.zeros(1, 3, 8, 8), 2)
+
+
+@pytest.mark.parametrize('deg,s,nkeys', [('BD', 4, 78), ('BI', 2, 74), ('BD', 2, 76)])
+def test_state_dict_layout_and_strict_load(deg, s, nkeys):
+    g = FRNet(3, 3, 64, 10, deg, s)
+    sd = generator_state_dict(scale=s, degradation=deg)
+    assert len(g.state_dict()) == nkeys
+    assert set(g.state_dict()) == set(sd)
+    for k, v in g.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    g.load_state_dict(sd, strict=True)
+
+
+def test_profile_matches_reference_counts(golden):
+    g = golden('fullsize')
+    for tag, deg, s, size in (('A', 'BD', 4, (3, 134, 320)), ('E', 'BI', 2, (3, 268, 640))):
+        net = FRNet(3, 3, 64, 10, deg, s)
+        gf, pr = net.profile(size)
+        assert list(gf) == ['FNet', 'SRNet'] and list(pr) == ['FNet', 'SRNet']
+        assert np.allclose([gf['FNet'], gf['SRNet']], g[f'profile_{tag}_gflops'], rtol=1e-9)
+        assert [pr['FNet'], pr['SRNet']] == list(g[f'profile_{tag}_params'])
+
+
+def test_define_generator_contract():
+    opt = {'scale': 4, 'dataset': {'degradation': {'type': 'BD'}},
+           'model': {'generator': {'name': 'FRNet', 'in_nc': 3, 'out_nc': 3, 'nf': 64, 'nb': 10}}}
+    net = define_generator(opt)
+    assert isinstance(net, FRNet) and net.scale == 4
+    opt['model']['generator']['name'] = 'nope'
+    with pytest.raises(ValueError):
+        define_generator(opt)
+
+
+def test_default_init_statistics_match_torch_conv():
+    """Random-init parity with the reference = PyTorch default Conv2d init."""
+    torch.manual_seed(0)
+    net = FRNet(3, 3, 64, 10, 'BD', 4)
+    w = net.srnet.resblocks[0].conv['0'].weight
+    bound = 1 / (64 * 9) ** 0.5
+    assert w.abs().max() <= bound + 1e-7 and w.std() > 0.5 * bound

@@ -1,0 +1,337 @@
+"""GPU parity tests: the HIP path (through the C ABI) against
+  (a) golden vectors produced by the upstream reference (tests/golden/*.npz),
+  (b) the CPU oracle on seeded inputs,
+  (c) size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (fp32, stated per test): single ops 1e-5 abs on O(1) data
+(different summation order only); flow outputs 2e-4 (tanh*24 amplifies);
+whole frames 1e-4 abs and |dPSNR| <= 1e-3 dB as BASELINE.json asks."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tecogan_oracle as O
+from procedural_weights import generator_state_dict, smooth_clip
+
+T = torch.from_numpy
+
+
+def dev(x):
+    if isinstance(x, np.ndarray):
+        x = T(x)
+    return x.cuda().contiguous()
+
+
+def err(a, b):
+    a = a.detach().cpu().double() if torch.is_tensor(a) else T(np.asarray(a)).double()
+    b = b.detach().cpu().double() if torch.is_tensor(b) else T(np.asarray(b)).double()
+    return (a - b).abs().max().item()
+
+
+def rs(seed, shape, lo=0.0, hi=1.0):
+    return T(np.random.RandomState(seed).uniform(lo, hi, shape).astype(np.float32))
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import tecogan_pytorch_amd.ops as ops_
+    from tecogan_pytorch_amd import _lib
+    _lib.lib()
+    return ops_
+
+
+def make_net(deg, s):
+    from tecogan_pytorch_amd.models.networks import FRNet
+    net = FRNet(3, 3, 64, 10, deg, s)
+    sd = generator_state_dict(scale=s, degradation=deg)
+    net.load_state_dict(sd, strict=True)
+    return net.cuda().eval(), sd
+
+
+# ------------------------------------------------------------------ single ops
+@pytest.mark.parametrize('case', ['', '_big', '_int', '_zero'])
+def test_warp_vs_reference(golden, ops, case):
+    g = golden('ops')
+    x = g['warp_x']
+    flow = np.zeros((2, 2, 17, 23), np.float32) if case == '_zero' else g['warp_flow' + case]
+    out = ops.backward_warp(dev(x), dev(flow))
+    assert err(out, g['warp_out' + case]) <= 5e-6
+    if case == '_zero':
+        assert torch.equal(out.cpu(), T(x))          # identity, exactly
+
+
+def test_warp_small_width(golden, ops):
+    g = golden('ops')
+    out = ops.backward_warp(dev(g['warp_x_small']), dev(g['warp_flow_small']))
+    assert err(out, g['warp_out_small']) <= 5e-6
+
+
+@pytest.mark.parametrize('s', [2, 4])
+def test_space_to_depth_bit_exact(golden, ops, s):
+    g = golden('ops')
+    out = ops.space_to_depth(dev(g[f's2d{s}_x']), s)
+    assert torch.equal(out.cpu(), T(g[f's2d{s}_out']))
+
+
+@pytest.mark.parametrize('s', [2, 4])
+def test_upsamplers_vs_reference(golden, ops, s):
+    g = golden('ops')
+    x = dev(g['up_x'])
+    assert err(ops.upsample(x, s, ops.UP_BICUBIC), g[f'bicubic{s}_out']) <= 2e-6
+    assert err(ops.upsample(x, s, ops.UP_BILINEAR), g[f'bilinear{s}_out']) <= 2e-6
+    assert err(ops.upsample(x, s, ops.UP_BICUBIC, mul=float(s)), s * g[f'bicubic{s}_out']) <= 8e-6
+
+
+def test_quantise_bit_exact(golden, ops):
+    g = golden('ops')
+    q = g['quant_x']
+    n = q.size // 3 * 3
+    x = dev(q[:n].reshape(3, 1, n // 3))
+    out = ops.quantize_u8_hwc(x).cpu().numpy()          # (1, n/3, 3) hwc
+    ref = g['quant_out'][:n].reshape(3, 1, n // 3).transpose(1, 2, 0)
+    assert np.array_equal(out, ref)
+
+
+def test_maxpool_floor_mode(ops):
+    x = rs(5, (2, 5, 9, 13), -1, 1)
+    out = ops.maxpool2(dev(x))
+    ref = torch.nn.functional.max_pool2d(x, 2, 2)
+    assert out.shape == ref.shape and torch.equal(out.cpu(), ref)
+
+
+CONV_CASES = [
+    # n, cin, cout, h, w, act, split(c1), residual
+    (1, 64, 64, 22, 40, 1, None, False),
+    (2, 64, 64, 13, 37, 0, None, True),       # ragged tile edges + residual
+    (1, 6, 32, 22, 40, 2, 3, False),          # two-source cat, ocb 32, cin < chunk
+    (1, 51, 64, 12, 20, 1, 3, False),         # SRNet conv_in: 3 + 48 channels
+    (1, 32, 32, 9, 33, 2, None, False),
+    (1, 128, 256, 5, 9, 2, None, False),      # FNet bottleneck: 4 oc groups, tiny map
+    (1, 256, 128, 6, 10, 2, None, False),
+    (1, 27, 64, 16, 16, 2, None, False),      # discriminator conv_in shape
+    (1, 64, 64, 70, 96, 0, None, False),
+    (3, 64, 64, 300, 260, 1, None, False),    # > 200k pixels: 4-row variant
+    (1, 64, 48, 10, 34, 0, None, False),      # cout not a multiple of 32
+]
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,act,c1,use_res', CONV_CASES)
+def test_conv3x3_mfma(ops, n, cin, cout, h, w, act, c1, use_res):
+    """Asymmetric random weights: a transposed MFMA fragment mapping cannot pass."""
+    import torch.nn.functional as F
+    x = rs(1, (n, cin, h, w), -1, 1)
+    wt = rs(2, (cout, cin, 3, 3), -1, 1) / (3.0 * cin ** 0.5)
+    b = rs(3, (cout,), -0.5, 0.5)
+    res = rs(4, (n, cout, h, w), -1, 1) if use_res else None
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    ref = {0: ref, 1: torch.relu(ref), 2: torch.where(ref >= 0, ref, ref * 0.2)}[act]
+    if use_res:
+        ref = ref + res.double()
+    pk, ci_, co_, ocb = ops.pack_conv3x3(dev(wt))
+    assert (ci_, co_) == (cin, cout)
+    if c1:
+        out = ops.conv3x3(dev(x[:, :c1]), pk, dev(b), cin, cout, ocb, act, x2=dev(x[:, c1:]),
+                          res=None if res is None else dev(res))
+    else:
+        out = ops.conv3x3(dev(x), pk, dev(b), cin, cout, ocb, act,
+                          res=None if res is None else dev(res))
+    assert err(out, ref) <= 1e-5, err(out, ref)
+
+
+def test_conv3x3_inplace_residual(ops):
+    """The resblock tail writes `conv(t) + x` over x (plan does this)."""
+    import torch.nn.functional as F
+    x = rs(1, (1, 64, 20, 40), -1, 1)
+    t = rs(5, (1, 64, 20, 40), -1, 1)
+    wt = rs(2, (64, 64, 3, 3), -1, 1) / 24.0
+    b = rs(3, (64,), -0.5, 0.5)
+    ref = F.conv2d(t.double(), wt.double(), b.double(), padding=1) + x.double()
+    pk, _, _, ocb = ops.pack_conv3x3(dev(wt))
+    xd = dev(x)
+    ops.conv3x3(dev(t), pk, dev(b), 64, 64, ocb, 0, res=xd, out=xd)
+    assert err(xd, ref) <= 1e-5
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(1, 64, 64, 12, 20), (2, 64, 64, 7, 35),
+                                            (1, 64, 64, 33, 64), (1, 16, 40, 5, 6)])
+def test_convt3x3s2_mfma(ops, n, cin, cout, h, w):
+    import torch.nn.functional as F
+    x = rs(1, (n, cin, h, w), -1, 1)
+    wt = rs(2, (cin, cout, 3, 3), -1, 1) / (1.5 * cin ** 0.5)
+    b = rs(3, (cout,), -0.5, 0.5)
+    ref = torch.relu(F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=1,
+                                        output_padding=1))
+    pk, ci_, co_, ocb = ops.pack_conv3x3(dev(wt), transposed=True)
+    assert (ci_, co_, ocb) == (cin, cout, 64)
+    out = ops.convt3x3s2(dev(x), pk, dev(b), cout, 1)
+    assert out.shape == ref.shape and err(out, ref) <= 1e-5, err(out, ref)
+
+
+@pytest.mark.parametrize('cin,cout,h,w,act,up', [
+    (32, 2, 16, 40, 3, None), (64, 3, 48, 80, 0, ('BD', 4)), (64, 3, 44, 132, 0, ('BI', 2)),
+    (64, 3, 20, 36, 0, ('BD', 2)), (9, 4, 7, 5, 1, None), (64, 1, 17, 70, 0, None)])
+def test_conv3x3_small(ops, cin, cout, h, w, act, up):
+    import torch.nn.functional as F
+    x = rs(1, (2, cin, h, w), -1, 1)
+    wt = rs(2, (cout, cin, 3, 3), -1, 1) / (3.0 * cin ** 0.5)
+    b = rs(3, (cout,), -0.5, 0.5)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    ref = {0: ref, 1: torch.relu(ref), 3: torch.tanh(ref) * 24}[act]
+    kw = {}
+    if up:
+        deg, s = up
+        src = rs(6, (2, cout, h // s, w // s))
+        ref = ref + O.upsample(src, s, deg).double()
+        kw = dict(up_src=dev(src), up_mode=ops.UP_MODE[deg], up_scale=s)
+    out = ops.conv3x3_small(dev(x), dev(wt), dev(b), act, **kw)
+    tol = 2e-4 if act == 3 else 1e-5
+    assert err(out, ref) <= tol, err(out, ref)
+
+
+@pytest.mark.parametrize('deg,s,h,w', [('BD', 4, 22, 40), ('BD', 4, 21, 37), ('BI', 2, 22, 40),
+                                       ('BD', 2, 19, 33), ('BI', 4, 16, 24)])
+def test_fused_flowup_warp_s2d_vs_oracle(ops, deg, s, h, w):
+    """= space_to_depth(backward_warp(hr_prev, s*up(reflect_pad(lr_flow)))) of the oracle."""
+    fh, fw = h // 8 * 8, w // 8 * 8
+    lr_flow = rs(1, (2, 2, fh, fw), -5, 5)
+    hr_prev = rs(2, (2, 3, s * h, s * w))
+    pad = O.reflect_pad_br(lr_flow, h - fh, w - fw)
+    hr_flow = s * O.upsample(pad, s, deg)
+    ref = O.space_to_depth(O.backward_warp(hr_prev, hr_flow), s)
+    out, hf = ops.flowup_warp_s2d(dev(lr_flow), dev(hr_prev), h, w, s, ops.UP_MODE[deg],
+                                  want_hr_flow=True)
+    assert err(hf, hr_flow) <= 2e-5
+    # white-noise image: a 1-ulp difference in the sampling position is worth ~|grad| * 4e-6
+    assert err(out, ref) <= 5e-5, err(out, ref)
+
+
+# ------------------------------------------------------------------- networks
+CFGS = [('BD', 4), ('BI', 2), ('BD', 2)]
+
+
+@pytest.mark.parametrize('deg,s', CFGS)
+def test_fnet_vs_reference(golden, deg, s):
+    g = golden(f'gen_{deg}{s}')
+    net, _ = make_net(deg, s)
+    for hw in ('22x40', '16x24'):
+        out = net.fnet(dev(g[f'fnet_{hw}_x1']), dev(g[f'fnet_{hw}_x2']))
+        assert err(out, g[f'fnet_{hw}_out']) <= 2e-4, hw
+
+
+@pytest.mark.parametrize('deg,s', CFGS)
+def test_srnet_vs_reference(golden, deg, s):
+    g = golden(f'gen_{deg}{s}')
+    net, _ = make_net(deg, s)
+    out = net.srnet(dev(g['srnet_lr']), dev(g['srnet_tran']))
+    assert err(out, g['srnet_out']) <= 5e-5
+
+
+@pytest.mark.parametrize('deg,s', CFGS)
+@pytest.mark.parametrize('path', ['plan', 'ops'])
+def test_step_vs_reference(golden, deg, s, path):
+    g = golden(f'gen_{deg}{s}')
+    net, _ = make_net(deg, s)
+    for hw in ('22x40', '21x37'):
+        args = [dev(g[f'step_{hw}_{k}']) for k in ('lr_curr', 'lr_prev', 'hr_prev')]
+        with torch.no_grad():
+            out = net.step(*args) if path == 'plan' else net.step_ops(*args)
+        ref = g[f'step_{hw}_out']
+        assert err(out, ref) <= 1e-4, (hw, err(out, ref))
+        dpsnr = O.psnr_float(out.cpu().numpy(), ref)
+        assert dpsnr > 80, dpsnr      # i.e. the two outputs differ by < -80 dB
+
+
+@pytest.mark.parametrize('deg,s', CFGS)
+def test_infer_sequence_u8_vs_reference(golden, deg, s):
+    g = golden(f'gen_{deg}{s}')
+    net, _ = make_net(deg, s)
+    out = net.infer_sequence(T(g['infer_lr']), 'cuda')
+    ref = g['infer_out_u8']
+    assert out.shape == ref.shape and out.dtype == np.uint8
+    diff = np.abs(out.astype(np.int16) - ref.astype(np.int16))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3, ((diff != 0).mean(), diff.max())
+    # BASELINE metric: PSNR of build vs reference output (Y channel) -- identical up to ties
+    for t in range(out.shape[0]):
+        p = O.psnr(ref[t], out[t])
+        assert p == np.inf or p > 60
+
+
+# --------------------------------------------------- BASELINE full-size checks
+def test_fullsize_A_digest_vs_reference(golden):
+    """config 1/2 shape: 4xBD, LR 1x3x134x320, seeded uniform inputs."""
+    g = golden('fullsize')
+    net, _ = make_net('BD', 4)
+    h, w, s = 134, 320, 4
+    with torch.no_grad():
+        out = net.step(dev(rs(100, (1, 3, h, w))), dev(rs(101, (1, 3, h, w))),
+                       dev(rs(102, (1, 3, s * h, s * w))))
+    flat = out.double().cpu().reshape(-1)
+    idx = T(g['full_A_sample_idx'])
+    assert (flat[idx].float().numpy() - g['full_A_samples']).__abs__().max() <= 3e-4
+    assert abs(flat.mean().item() - float(g['full_A_mean'])) <= 1e-5
+    assert abs(flat.norm().item() - float(g['full_A_l2'])) <= 1e-4 * flat.numel() ** 0.5
+
+
+@pytest.mark.parametrize('deg,s,h,w', [('BD', 4, 134, 320), ('BI', 2, 268, 640)])
+def test_fullsize_step_vs_oracle_and_psnr(deg, s, h, w):
+    """Full BASELINE sizes against the oracle on a smooth (flow-like) clip:
+    frame 0 from zero state, frame 1 recurrent; fp32 tolerance 2e-4 abs and the
+    north-star bound |PSNR(build) - PSNR(reference)| <= 1e-3 dB against a
+    common pseudo ground truth."""
+    net, sd = make_net(deg, s)
+    clip = smooth_clip(2, 3, h, w, seed=11)
+    with torch.no_grad():
+        z_lr, z_hr = torch.zeros(1, 3, h, w), torch.zeros(1, 3, s * h, s * w)
+        o0 = O.frnet_step(sd, clip[0:1], z_lr, z_hr, s, deg)
+        o1 = O.frnet_step(sd, clip[1:2], clip[0:1], o0, s, deg)
+        g0 = net.step(dev(clip[0:1]), dev(z_lr), dev(z_hr))
+        g1 = net.step(dev(clip[1:2]), dev(clip[0:1]), g0)
+    assert err(g0, o0) <= 2e-4 and err(g1, o1) <= 2e-4, (err(g0, o0), err(g1, o1))
+    gt = O.upsample(clip[1:2], s, deg).numpy()
+    d = abs(O.psnr_float(g1.cpu().numpy(), gt) - O.psnr_float(o1.numpy(), gt))
+    assert d <= 1e-3, d
+
+
+def test_fullsize_properties(ops):
+    """Size-independent properties at HR 536x1280."""
+    H, W = 536, 1280
+    x = dev(rs(7, (1, 3, H, W)))
+    # zero flow is the identity; integer flow is a pure shift
+    assert torch.equal(ops.backward_warp(x, torch.zeros(1, 2, H, W, device='cuda')), x)
+    fl = torch.zeros(1, 2, H, W, device='cuda'); fl[:, 0] = 3.0; fl[:, 1] = -2.0
+    y = ops.backward_warp(x, fl)
+    assert err(y[..., 2:H, 0:W - 3], x[..., 0:H - 2, 3:W]) <= 2e-6
+    # space_to_depth is a permutation: sorted values identical, and depth->space inverts it
+    s2d = ops.space_to_depth(x, 4)
+    back = s2d.view(1, 4, 4, 3, H // 4, W // 4).permute(0, 3, 4, 1, 5, 2).reshape(1, 3, H, W)
+    assert torch.equal(back, x)
+    # conv linearity: conv(a x1 + b x2) = a conv(x1) + b conv(x2) (bias-free)
+    wt = dev(rs(8, (64, 64, 3, 3), -1, 1) / 24.0)
+    pk, _, _, ocb = ops.pack_conv3x3(wt)
+    x1, x2 = dev(rs(9, (1, 64, 134, 320), -1, 1)), dev(rs(10, (1, 64, 134, 320), -1, 1))
+    lhs = ops.conv3x3(2.0 * x1 - 0.5 * x2, pk, None, 64, 64, ocb)
+    rhs = 2.0 * ops.conv3x3(x1, pk, None, 64, 64, ocb) - 0.5 * ops.conv3x3(x2, pk, None, 64, 64, ocb)
+    assert err(lhs, rhs) <= 2e-5
+    # determinism: same launch twice is bit-identical
+    assert torch.equal(ops.conv3x3(x1, pk, None, 64, 64, ocb), ops.conv3x3(x1, pk, None, 64, 64, ocb))
+
+
+def test_step_is_deterministic_and_stateless():
+    net, _ = make_net('BD', 4)
+    a = [dev(rs(100 + i, sh)) for i, sh in enumerate([(1, 3, 134, 320), (1, 3, 134, 320),
+                                                      (1, 3, 536, 1280)])]
+    with torch.no_grad():
+        o1 = net.step(*a).clone()
+        net.step(a[1], a[0], a[2])          # disturb the workspace
+        o2 = net.step(*a)
+    assert torch.equal(o1, o2)
+
+
+def test_missing_library_is_loud(monkeypatch):
+    from tecogan_pytorch_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libtecogan_hip.so')
+    with pytest.raises(_lib.TecoganHipError):
+        _lib.lib()
