@@ -70,6 +70,10 @@ def lib():
                 f'{LIB_PATH} not found: build it with '
                 f'`bash {os.path.join(_HERE, "csrc", "build.sh")}` '
                 '(hipcc --offload-arch=gfx950).  There is no CPU/ATen fallback.')
+        # torch bundles its own HIP runtime; it must be the one already mapped
+        # when our library (linked against libamdhip64) is opened, otherwise two
+        # runtimes coexist and ours sees no device.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError if a symbol is missing

@@ -53,6 +53,12 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// Negative-side slope of the piecewise-linear activations: x >= 0 ? x : x*slope
+// (1 = identity, 0 = ReLU, 0.2 = LeakyReLU(0.2)); wave-uniform, branch free.
+__device__ __forceinline__ float act_slope(int act) {
+  return act == TG_ACT_RELU ? 0.f : (act == TG_ACT_LRELU02 ? 0.2f : 1.f);
+}
+
 // ---- shared sampling arithmetic (device) ---------------------------------
 // BicubicUpsampler weights (net_utils.py:113-127), a = -0.75, fp32, evaluated
 // exactly as cubic @ [1, s, s^2, s^3] with s = d/f.

@@ -9,14 +9,19 @@
 // contiguous segment per half-wave -- no transpose, no LDS round trip.
 //
 // Workgroup = WM x WN waves: WM consecutive image rows, WN groups of NT*32
-// output channels.  Input channels are streamed through LDS in chunks of 8
-// (double buffered, one barrier per chunk): the chunk's halo patch
-// [8][WM+2][34] stays planar (NCHW order), which is exactly the B-operand
-// order (lane&31 -> consecutive x, lane>>5 -> next channel), so every
-// ds_read_b32 is conflict free; weights sit as [tap][8][OCB] so the A operand
-// (lane&31 -> consecutive oc) is conflict free too.  fp32 MFMA consumes one A
-// and one B VGPR per 64 cycles, so plain 4-byte LDS reads are 4x below the
-// LDS roof; the kernel is MFMA-issue bound by construction.
+// output channels.  Input channels stream through LDS in chunks of 8 (double
+// buffered, one barrier per chunk).  Inside a chunk the K order is permuted so
+// that MFMA k-step kk of a tap consumes channel 4*(lane>>5) + kk: a lane's four
+// k-steps then need four CONSECUTIVE channels, and both operands of a whole tap
+// (4 MFMAs) come from one ds_read_b128 each:
+//     weights  LDS [tap][half][oc][4]     (A: lane -> oc,  16 B = 4 channels)
+//     input    LDS [row][half][col][4]    (B: lane -> col, 16 B = 4 channels)
+// Consecutive lanes read consecutive 16-byte slots: conflict free.  Operands
+// of tap t+1 are fetched into a second register set while tap t's MFMAs issue.
+//
+// Staging is branch free: bounds-checked raw buffer loads (out-of-image halo
+// pixels and channel tails get an out-of-range offset and read as 0), four
+// channel planes of one pixel per thread -> one ds_write_b128.
 //
 // Reference ops replaced: nn.Conv2d(.,.,3,1,1)+bias+act(+residual) at
 // codes/models/networks/tecogan_nets.py:23-65, 92-98, 111-113, 367-369 and the
@@ -27,7 +32,7 @@ namespace tg {
 
 constexpr int TW = 32;          // pixels per row segment (MFMA N)
 constexpr int PW = TW + 2;      // patch width incl. halo
-constexpr int RS = 36;          // LDS row stride (floats)
+constexpr int RS = 34;          // LDS patch row stride (16-byte slots)
 
 struct Conv3x3Args {
   const float* x;
@@ -41,20 +46,22 @@ struct Conv3x3Args {
   int tiles_x, tiles_y, nchunk, nocg;
 };
 
-// pack OIHW (or IOHW for transposed convs) -> [ocg][chunk][tap][CK][OCB]
+// pack OIHW (or IOHW for transposed convs) -> [ocg][chunk][tap][half][ocb][4]
+// (channel within chunk = 4*half + j), zero padded in cin and cout.
 __global__ void pack3x3_kernel(const float* __restrict__ w, float* __restrict__ out,
                                int cin, int cout, int ocb, int nchunk, int nocg,
                                int transposed) {
   int total = nocg * nchunk * 9 * CK * ocb;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += gridDim.x * blockDim.x) {
-    int o = i % ocb;
-    int t = i / ocb;
-    int c = t % CK; t /= CK;
+    int j = i & 3;
+    int t = i >> 2;
+    int o = t % ocb; t /= ocb;
+    int half = t & 1; t >>= 1;
     int tap = t % 9; t /= 9;
     int ch = t % nchunk;
     int g = t / nchunk;
-    int oc = g * ocb + o, ci = ch * CK + c;
+    int oc = g * ocb + o, ci = ch * CK + 4 * half + j;
     float v = 0.f;
     if (oc < cout && ci < cin) {
       v = transposed ? w[((size_t)ci * cout + oc) * 9 + tap]
@@ -64,19 +71,23 @@ __global__ void pack3x3_kernel(const float* __restrict__ w, float* __restrict__ 
   }
 }
 
-template <int WM, int WN, int NT>
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+}
+
+constexpr unsigned OOB = 0x80000000u;   // >= any num_records we build (tensors < 2 GiB per item)
+
+template <int WM, int WN, int NT, bool DUAL>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a) {
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int OCB = WN * NT * 32;
   constexpr int PH = WM + 2;
-  constexpr int SLOTS = PH * PW;                 // patch positions per channel
-  constexpr int IN_FLOATS = CK * PH * RS;
+  constexpr int IN_ITEMS = PH * 2 * PW;            // 16-byte items (pixel x 4 channels) per chunk
+  constexpr int IN_FLOATS = PH * 2 * RS * 4;
   constexpr int W_FLOATS = 9 * CK * OCB;
   constexpr int W_VEC4 = W_FLOATS / 4;
   constexpr int W_PER_T = (W_VEC4 + NTHREADS - 1) / NTHREADS;
-  constexpr int G = NTHREADS / SLOTS;            // channel groups staged in parallel
-  static_assert(G >= 1, "tile too large for the staging scheme");
-  constexpr int C_PER_T = (CK + G - 1) / G;
+  constexpr int I_PER_T = (IN_ITEMS + NTHREADS - 1) / NTHREADS;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;                        // [2][IN_FLOATS]
@@ -94,36 +105,47 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   const int ocg = b % a.nocg;
   const int n = b / a.nocg;
   const int x0 = tx * TW, y0 = ty * WM;
+  const int hw = a.h * a.w;
 
-  // ---- staging assignment: thread -> (patch slot, channel group) ----------
-  const int sg = tid / SLOTS;
-  const int ss = tid - sg * SLOTS;
-  const int sr = ss / PW, sc = ss - sr * PW;
-  const int gy = y0 - 1 + sr, gx = x0 - 1 + sc;
-  const bool s_active = (sg < G);
-  const bool s_inimg = s_active && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-  const long long hw = (long long)a.h * a.w;
-  const long long pix = (long long)gy * a.w + gx;
-  const float* xb1 = a.x + (long long)n * a.x_ns + pix;
-  const float* xb2 = a.x2 ? a.x2 + (long long)n * a.x2_ns + pix : nullptr;
-  const int lds_slot = sr * RS + sc;
+  // ---- staging assignment: item q = (row r, half hf, col) -------------------
+  unsigned voff[I_PER_T];     // byte offset of channel (4*hf) at this pixel, or OOB
+  int lds_item[I_PER_T];      // float index of the 16-byte LDS slot, -1 if none
+#pragma unroll
+  for (int i = 0; i < I_PER_T; ++i) {
+    int q = tid + i * NTHREADS;
+    int r = q / (2 * PW), rem = q - r * (2 * PW);
+    int hf = rem / PW, col = rem - hf * PW;
+    int gy = y0 - 1 + r, gx = x0 - 1 + col;
+    bool ok = q < IN_ITEMS && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+    voff[i] = ok ? (unsigned)((4 * hf * hw + gy * a.w + gx) * 4) : OOB;
+    lds_item[i] = q < IN_ITEMS ? ((r * 2 + hf) * RS + col) * 4 : -1;
+  }
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (long long)n * a.x_ns), 0, a.c1 * hw * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(DUAL ? a.x2 + (long long)n * a.x2_ns : a.x), 0,
+      DUAL ? (a.cin - a.c1) * hw * 4 : 0, 0x00020000);
+  const unsigned plane = (unsigned)hw * 4u;
 
-  const f32x4* wsrc = reinterpret_cast<const f32x4*>(
-      a.wpk + (size_t)ocg * a.nchunk * W_FLOATS);
+  const f32x4* wsrc =
+      reinterpret_cast<const f32x4*>(a.wpk + (size_t)ocg * a.nchunk * W_FLOATS);
 
-  float rin[C_PER_T];
+  f32x4 rin[I_PER_T];
   f32x4 rw[W_PER_T];
 
   auto load_chunk = [&](int ch) {
+    const unsigned cbase = (unsigned)(ch * CK) * plane;
 #pragma unroll
-    for (int i = 0; i < C_PER_T; ++i) {
-      int cl = sg + i * G;
-      int c = ch * CK + cl;
-      float v = 0.f;
-      if (s_inimg && cl < CK && c < a.cin) {
-        v = (c < a.c1) ? xb1[(long long)c * hw] : xb2[(long long)(c - a.c1) * hw];
+    for (int i = 0; i < I_PER_T; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // channel ch*8 + 4*hf + j.  Beyond c1 (or cin) the offset is past
+        // num_records and the load returns 0; the second source then supplies it.
+        unsigned o1 = voff[i] + cbase + (unsigned)j * plane;
+        float v = buf_load(rs1, o1);
+        if (DUAL) v += buf_load(rs2, o1 - (unsigned)a.c1 * plane);
+        rin[i][j] = v;
       }
-      rin[i] = v;
     }
     const f32x4* ws = wsrc + (size_t)ch * W_VEC4;
 #pragma unroll
@@ -134,13 +156,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   };
   auto store_chunk = [&](int buf) {
     float* si = s_in + buf * IN_FLOATS;
-    if (s_active) {
 #pragma unroll
-      for (int i = 0; i < C_PER_T; ++i) {
-        int cl = sg + i * G;
-        if (cl < CK) si[cl * (PH * RS) + lds_slot] = rin[i];
-      }
-    }
+    for (int i = 0; i < I_PER_T; ++i)
+      if (lds_item[i] >= 0) *reinterpret_cast<f32x4*>(si + lds_item[i]) = rin[i];
     f32x4* sw = reinterpret_cast<f32x4*>(s_w + buf * W_FLOATS);
 #pragma unroll
     for (int i = 0; i < W_PER_T; ++i) {
@@ -156,9 +174,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int lh = lane >> 5, ll = lane & 31;
-  // per-lane LDS offsets (floats)
-  const int b_off = lh * (PH * RS) + wm * RS + ll;
-  const int a_off = lh * OCB + wn * (NT * 32) + ll;
+  // per-lane LDS offsets (floats) of the 16-byte operand slots
+  const int b_off = ((wm * 2 + lh) * RS + ll) * 4;
+  const int a_off = (lh * OCB + wn * (NT * 32) + ll) * 4;
 
   load_chunk(0);
   store_chunk(0);
@@ -171,17 +189,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
 
     const float* si = s_in + buf * IN_FLOATS + b_off;
     const float* sw = s_w + buf * W_FLOATS + a_off;
+    f32x4 bq[2], aq[2][NT];
+    bq[0] = *reinterpret_cast<const f32x4*>(si);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) aq[0][t] = *reinterpret_cast<const f32x4*>(sw + t * 128);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap % 3;
+      const int cur = tap & 1, nxt = cur ^ 1;
+      if (tap + 1 < 9) {
+        const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
+        bq[nxt] = *reinterpret_cast<const f32x4*>(si + (ky * 2 * RS + kx) * 4);
 #pragma unroll
-      for (int kk = 0; kk < CK / 2; ++kk) {
-        float bv = si[(2 * kk) * (PH * RS) + ky * RS + kx];
+        for (int t = 0; t < NT; ++t)
+          aq[nxt][t] = *reinterpret_cast<const f32x4*>(sw + (tap + 1) * (2 * OCB * 4) + t * 128);
+      }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          float av = sw[(tap * CK + 2 * kk) * OCB + t * 32];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-        }
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][t][kk], bq[cur][kk], acc[t], 0, 0, 0);
       }
     }
     if (more) store_chunk(buf ^ 1);
@@ -189,24 +215,34 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   }
 
   // ---- epilogue: bias, activation, residual, NCHW store --------------------
+  // All loads are issued before any use (independent, one wait), and the
+  // activation is a select on a wave-uniform slope: no branches per element.
   const int px = x0 + ll, py = y0 + wm;
-  if (px < a.w && py < a.h) {
-    const long long opix = (long long)py * a.w + px;
-    float* yb = a.y + (long long)n * a.y_ns + opix;
-    const float* rb = a.res ? a.res + (long long)n * a.res_ns + opix : nullptr;
+  const bool inimg = px < a.w && py < a.h;
+  const long long opix = (long long)py * a.w + px;
+  const int ocb0 = ocg * OCB + wn * (NT * 32) + 4 * lh;
+  const float slope = act_slope(a.act);
+  float bv[NT][16], rv[NT][16];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int oc = ocb0 + t * 32 + (r & 3) + 8 * (r >> 2);
+      int occ = oc < a.cout ? oc : a.cout - 1;
+      bv[t][r] = a.bias ? a.bias[occ] : 0.f;
+      rv[t][r] = (a.res && inimg) ? a.res[(long long)n * a.res_ns + opix + (long long)occ * hw] : 0.f;
+    }
+  if (inimg) {
+    float* yb = a.y + (long long)n * a.y_ns + opix;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        int oc = ocg * OCB + wn * (NT * 32) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (oc < a.cout) {
-          float v = acc[t][r] + (a.bias ? a.bias[oc] : 0.f);
-          v = apply_act(v, a.act);
-          if (rb) v += rb[(long long)oc * hw];
-          yb[(long long)oc * hw] = v;
-        }
+        int oc = ocb0 + t * 32 + (r & 3) + 8 * (r >> 2);
+        float v = acc[t][r] + bv[t][r];
+        v = (v >= 0.f ? v : v * slope + 0.f) + rv[t][r];
+        if (oc < a.cout) yb[(long long)oc * hw] = v;
       }
-    }
   }
 }
 
@@ -218,11 +254,15 @@ static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   a.tiles_y = cdiv(a.h, WM);
   a.nocg = cdiv(a.cout, OCB);
   a.nchunk = cdiv(a.cin, CK);
-  size_t lds = 2 * (size_t)(CK * (WM + 2) * RS + 9 * CK * OCB) * sizeof(float);
+  size_t lds = 2 * (size_t)((WM + 2) * 2 * RS * 4 + 9 * CK * OCB) * sizeof(float);
   long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "conv3x3: grid %lld", blocks);
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT>), dim3((unsigned)blocks),
-                     dim3(WM * WN * 64), lds, stream, a);
+  if (a.x2)
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, true>), dim3((unsigned)blocks),
+                       dim3(WM * WN * 64), lds, stream, a);
+  else
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, false>), dim3((unsigned)blocks),
+                       dim3(WM * WN * 64), lds, stream, a);
   return check_launch("conv3x3_mfma");
 }
 
@@ -261,8 +301,11 @@ extern "C" int tg_conv3x3_fwd(const float* x, int64_t x_nstride, int c1, const f
              "conv3x3_fwd: n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, w);
   TG_REQUIRE(c1 > 0 && c1 <= cin && (c1 == cin || x2), TG_E_ARG,
              "conv3x3_fwd: c1=%d cin=%d needs a second source", c1, cin);
-  TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_TANH24, TG_E_ARG, "conv3x3_fwd: act=%d", act);
+  TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_LRELU02, TG_E_ARG,
+             "conv3x3_fwd: act=%d (none|relu|lrelu; tanh*24 only in tg_conv3x3_small_fwd)", act);
   TG_REQUIRE(ocb == 32 || ocb == 64, TG_E_ARG, "conv3x3_fwd: ocb=%d", ocb);
+  TG_REQUIRE((long long)(cin + CK) * h * w * 4 < (1ll << 31), TG_E_SHAPE,
+             "conv3x3_fwd: one batch item must be < 2 GiB (cin=%d h=%d w=%d)", cin, h, w);
   Conv3x3Args a{};
   a.x = x; a.x2 = (c1 < cin) ? x2 : nullptr; a.wpk = w_packed; a.bias = bias; a.res = res;
   a.y = y; a.x_ns = x_nstride; a.x2_ns = x2_nstride; a.res_ns = res_nstride; a.y_ns = y_nstride;

@@ -9,10 +9,12 @@
 //   multiplications by inserted zeros.
 //
 // One wave = one 32-pixel INPUT row segment x 32 output channels x 4 phases
-// (4 accumulator tiles of 32x32; a workgroup is WM rows x 2 oc halves).  The four distinct B operands (dy,dx in
-// {0,1}^2) are read once per K-step and shared by the taps that use them.
-// The epilogue pairs the px=0/px=1 accumulators into float2 stores, so each
-// half-wave writes 256 contiguous bytes of an output row.
+// (4 accumulator tiles of 32x32; a workgroup is WM rows x 2 oc halves).
+// Same operand layouts as tg_conv3x3_mfma.hip (K permuted so a tap's four
+// k-steps are one ds_read_b128 per operand); the four distinct B operands
+// (dy,dx in {0,1}^2) are read once per chunk-half and shared by the taps that
+// use them.  The epilogue pairs the px=0/px=1 accumulators into float2
+// stores, so each half-wave writes 256 contiguous bytes of an output row.
 //
 // Replaces SRNet.conv_up (codes/models/networks/tecogan_nets.py:119-126).
 #include "tg_common.h"
@@ -21,8 +23,9 @@ namespace tg {
 
 constexpr int TTW = 32;
 constexpr int TPW = TTW + 1;   // patch width: x .. x+32
-constexpr int TRS = 36;        // LDS row stride
+constexpr int TRS = 34;        // LDS row stride (16-byte slots)
 constexpr int TOCB = 64;
+constexpr unsigned TOOB = 0x80000000u;
 
 struct ConvTArgs {
   const float* x;
@@ -39,14 +42,12 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
   static_assert(WN * 32 == TOCB, "WN waves x 32 oc must cover the 64-oc block");
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int PH = WM + 1;
-  constexpr int SLOTS = PH * TPW;
-  constexpr int IN_FLOATS = CK * PH * TRS;
+  constexpr int IN_ITEMS = PH * 2 * TPW;
+  constexpr int IN_FLOATS = PH * 2 * TRS * 4;
   constexpr int W_FLOATS = 9 * CK * TOCB;
   constexpr int W_VEC4 = W_FLOATS / 4;
   constexpr int W_PER_T = (W_VEC4 + NTHREADS - 1) / NTHREADS;
-  constexpr int G = NTHREADS / SLOTS;
-  static_assert(G >= 1, "tile too large");
-  constexpr int C_PER_T = (CK + G - 1) / G;
+  constexpr int I_PER_T = (IN_ITEMS + NTHREADS - 1) / NTHREADS;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;
@@ -60,27 +61,37 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
   const int ocg = b % a.nocg;
   const int n = b / a.nocg;
   const int x0 = tx * TTW, y0 = ty * WM;
+  const int hw = a.h * a.w;
 
-  const int sg = tid / SLOTS;
-  const int ss = tid - sg * SLOTS;
-  const int sr = ss / TPW, sc = ss - sr * TPW;
-  const int gy = y0 + sr, gx = x0 + sc;
-  const bool s_active = sg < G;
-  const bool s_inimg = s_active && gy < a.h && gx < a.w;
-  const long long hw = (long long)a.h * a.w;
-  const float* xb = a.x + (long long)n * a.x_ns + (long long)gy * a.w + gx;
-  const int lds_slot = sr * TRS + sc;
+  unsigned voff[I_PER_T];
+  int lds_item[I_PER_T];
+#pragma unroll
+  for (int i = 0; i < I_PER_T; ++i) {
+    int q = tid + i * NTHREADS;
+    int r = q / (2 * TPW), rem = q - r * (2 * TPW);
+    int hf = rem / TPW, col = rem - hf * TPW;
+    int gy = y0 + r, gx = x0 + col;
+    bool ok = q < IN_ITEMS && gy < a.h && gx < a.w;
+    voff[i] = ok ? (unsigned)((4 * hf * hw + gy * a.w + gx) * 4) : TOOB;
+    lds_item[i] = q < IN_ITEMS ? ((r * 2 + hf) * TRS + col) * 4 : -1;
+  }
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (long long)n * a.x_ns), 0, a.cin * hw * 4, 0x00020000);
+  const unsigned plane = (unsigned)hw * 4u;
   const f32x4* wsrc =
       reinterpret_cast<const f32x4*>(a.wpk + (size_t)ocg * a.nchunk * W_FLOATS);
 
-  float rin[C_PER_T];
+  f32x4 rin[I_PER_T];
   f32x4 rw[W_PER_T];
   auto load_chunk = [&](int ch) {
+    const unsigned cbase = (unsigned)(ch * CK) * plane;
 #pragma unroll
-    for (int i = 0; i < C_PER_T; ++i) {
-      int cl = sg + i * G, c = ch * CK + cl;
-      rin[i] = (s_inimg && cl < CK && c < a.cin) ? xb[(long long)c * hw] : 0.f;
-    }
+    for (int i = 0; i < I_PER_T; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        rin[i][j] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(
+                       rs1, (int)(voff[i] + cbase + (unsigned)j * plane), 0, 0));
     const f32x4* ws = wsrc + (size_t)ch * W_VEC4;
 #pragma unroll
     for (int i = 0; i < W_PER_T; ++i) {
@@ -90,13 +101,9 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
   };
   auto store_chunk = [&](int buf) {
     float* si = s_in + buf * IN_FLOATS;
-    if (s_active) {
 #pragma unroll
-      for (int i = 0; i < C_PER_T; ++i) {
-        int cl = sg + i * G;
-        if (cl < CK) si[cl * (PH * TRS) + lds_slot] = rin[i];
-      }
-    }
+    for (int i = 0; i < I_PER_T; ++i)
+      if (lds_item[i] >= 0) *reinterpret_cast<f32x4*>(si + lds_item[i]) = rin[i];
     f32x4* sw = reinterpret_cast<f32x4*>(s_w + buf * W_FLOATS);
 #pragma unroll
     for (int i = 0; i < W_PER_T; ++i) {
@@ -113,17 +120,18 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
   const int lh = lane >> 5, ll = lane & 31;
-  const int b_off = lh * (PH * TRS) + wm * TRS + ll;
-  const int a_off = lh * TOCB + wn * 32 + ll;
+  const int b_off = ((wm * 2 + lh) * TRS + ll) * 4;
+  const int a_off = (lh * TOCB + wn * 32 + ll) * 4;
 
   load_chunk(0);
   store_chunk(0);
   __syncthreads();
 
-#define TG_CT_MFMA(P, TAP, BV)                                                   \
-  {                                                                              \
-    float av = sw[((TAP)*CK + 2 * kk) * TOCB];                                   \
-    acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, BV, acc[P], 0, 0, 0);      \
+#define TG_CT_TAP(P, TAP, BV)                                                           \
+  {                                                                                     \
+    f32x4 av = *reinterpret_cast<const f32x4*>(sw + (TAP) * (2 * TOCB * 4));            \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) acc[P] =                           \
+        __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], BV[kk], acc[P], 0, 0, 0);          \
   }
 
   for (int ch = 0; ch < a.nchunk; ++ch) {
@@ -132,42 +140,50 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
     if (more) load_chunk(ch + 1);
     const float* si = s_in + buf * IN_FLOATS + b_off;
     const float* sw = s_w + buf * W_FLOATS + a_off;
-#pragma unroll
-    for (int kk = 0; kk < CK / 2; ++kk) {
-      const float* sc_ = si + (2 * kk) * (PH * TRS);
-      float b00 = sc_[0], b01 = sc_[1], b10 = sc_[TRS], b11 = sc_[TRS + 1];
-      // tap index = ky*3 + kx
-      TG_CT_MFMA(0, 4, b00)   // (py0,px0): ky1,kx1 in[y][x]
-      TG_CT_MFMA(1, 3, b01)   // (py0,px1): ky1,kx0 in[y][x+1]
-      TG_CT_MFMA(1, 5, b00)   //            ky1,kx2 in[y][x]
-      TG_CT_MFMA(2, 1, b10)   // (py1,px0): ky0,kx1 in[y+1][x]
-      TG_CT_MFMA(2, 7, b00)   //            ky2,kx1 in[y][x]
-      TG_CT_MFMA(3, 0, b11)   // (py1,px1): ky0,kx0 in[y+1][x+1]
-      TG_CT_MFMA(3, 2, b10)   //            ky0,kx2 in[y+1][x]
-      TG_CT_MFMA(3, 6, b01)   //            ky2,kx0 in[y][x+1]
-      TG_CT_MFMA(3, 8, b00)   //            ky2,kx2 in[y][x]
-    }
+    const f32x4 b00 = *reinterpret_cast<const f32x4*>(si);
+    const f32x4 b01 = *reinterpret_cast<const f32x4*>(si + 4);
+    const f32x4 b10 = *reinterpret_cast<const f32x4*>(si + 2 * TRS * 4);
+    const f32x4 b11 = *reinterpret_cast<const f32x4*>(si + 2 * TRS * 4 + 4);
+    // tap index = ky*3 + kx
+    TG_CT_TAP(0, 4, b00)   // (py0,px0): ky1,kx1 in[y][x]
+    TG_CT_TAP(1, 3, b01)   // (py0,px1): ky1,kx0 in[y][x+1]
+    TG_CT_TAP(1, 5, b00)   //            ky1,kx2 in[y][x]
+    TG_CT_TAP(2, 1, b10)   // (py1,px0): ky0,kx1 in[y+1][x]
+    TG_CT_TAP(2, 7, b00)   //            ky2,kx1 in[y][x]
+    TG_CT_TAP(3, 0, b11)   // (py1,px1): ky0,kx0 in[y+1][x+1]
+    TG_CT_TAP(3, 2, b10)   //            ky0,kx2 in[y+1][x]
+    TG_CT_TAP(3, 6, b01)   //            ky2,kx0 in[y][x+1]
+    TG_CT_TAP(3, 8, b00)   //            ky2,kx2 in[y][x]
     if (more) store_chunk(buf ^ 1);
     __syncthreads();
   }
-#undef TG_CT_MFMA
+#undef TG_CT_TAP
 
   const int px = x0 + ll, py = y0 + wm;
+  const float slope = act_slope(a.act);
+  const int ocb0 = ocg * TOCB + wn * 32 + 4 * lh;
+  float bv[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int oc = ocb0 + (r & 3) + 8 * (r >> 2);
+    bv[r] = a.bias ? a.bias[oc < a.cout ? oc : a.cout - 1] : 0.f;
+  }
   if (px < a.w && py < a.h) {
     const int ow = 2 * a.w;
     const long long ohw = 4ll * hw;
     float* yb = a.y + (long long)n * a.y_ns + (long long)(2 * py) * ow + 2 * px;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int oc = ocg * TOCB + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      int oc = ocb0 + (r & 3) + 8 * (r >> 2);
+      float* yo = yb + (long long)oc * ohw;
+      float2 v0, v1;
+      float t0 = acc[0][r] + bv[r], t1 = acc[1][r] + bv[r];
+      float t2 = acc[2][r] + bv[r], t3 = acc[3][r] + bv[r];
+      v0.x = t0 >= 0.f ? t0 : t0 * slope + 0.f;
+      v0.y = t1 >= 0.f ? t1 : t1 * slope + 0.f;
+      v1.x = t2 >= 0.f ? t2 : t2 * slope + 0.f;
+      v1.y = t3 >= 0.f ? t3 : t3 * slope + 0.f;
       if (oc < a.cout) {
-        float bv = a.bias ? a.bias[oc] : 0.f;
-        float* yo = yb + (long long)oc * ohw;
-        float2 v0, v1;
-        v0.x = apply_act(acc[0][r] + bv, a.act);
-        v0.y = apply_act(acc[1][r] + bv, a.act);
-        v1.x = apply_act(acc[2][r] + bv, a.act);
-        v1.y = apply_act(acc[3][r] + bv, a.act);
         *reinterpret_cast<float2*>(yo) = v0;
         *reinterpret_cast<float2*>(yo + ow) = v1;
       }
@@ -186,9 +202,11 @@ extern "C" int tg_convt3x3s2_fwd(const float* x, int64_t x_nstride, const float*
   TG_REQUIRE(x && w_packed && y, TG_E_ARG, "convt3x3s2_fwd: null pointer");
   TG_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, TG_E_SHAPE,
              "convt3x3s2_fwd: n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, w);
-  TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_TANH24, TG_E_ARG, "convt: act=%d", act);
+  TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_LRELU02, TG_E_ARG, "convt: act=%d (none|relu|lrelu)", act);
   TG_REQUIRE((y_nstride % 2) == 0 && ((uintptr_t)y % 8) == 0, TG_E_ARG,
              "convt3x3s2_fwd: output must be 8-byte aligned");
+  TG_REQUIRE((long long)(cin + CK) * h * w * 4 < (1ll << 31), TG_E_SHAPE,
+             "convt3x3s2_fwd: one batch item must be < 2 GiB");
   ConvTArgs a{};
   a.x = x; a.wpk = w_packed; a.bias = bias; a.y = y; a.x_ns = x_nstride; a.y_ns = y_nstride;
   a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
@@ -197,10 +215,10 @@ extern "C" int tg_convt3x3s2_fwd(const float* x, int64_t x_nstride, const float*
   a.tiles_y = cdiv(h, WM);
   a.nocg = cdiv(cout, TOCB);
   a.nchunk = cdiv(cin, CK);
-  size_t lds = 2 * (size_t)(CK * (WM + 1) * TRS + 9 * CK * TOCB) * sizeof(float);
+  size_t lds = 2 * (size_t)((WM + 1) * 2 * TRS * 4 + 9 * CK * TOCB) * sizeof(float);
   long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "convt: grid %lld", blocks);
-  hipLaunchKernelGGL((convt3x3s2_mfma_kernel<WM, WN>), dim3((unsigned)blocks), dim3(WM * WN * 64), lds,
-                     (hipStream_t)stream, a);
+  hipLaunchKernelGGL((convt3x3s2_mfma_kernel<WM, WN>), dim3((unsigned)blocks),
+                     dim3(WM * WN * 64), lds, (hipStream_t)stream, a);
   return check_launch("convt3x3s2_mfma");
 }

@@ -58,8 +58,8 @@ def test_warp_vs_reference(golden, ops, case):
     flow = np.zeros((2, 2, 17, 23), np.float32) if case == '_zero' else g['warp_flow' + case]
     out = ops.backward_warp(dev(x), dev(flow))
     assert err(out, g['warp_out' + case]) <= 5e-6
-    if case == '_zero':
-        assert torch.equal(out.cpu(), T(x))          # identity, exactly
+    # (zero flow is NOT a bit-exact identity in the reference either: positions go
+    #  through the normalise / un-normalise round trip of grid_sample)
 
 
 def test_warp_small_width(golden, ops):
@@ -298,11 +298,13 @@ def test_fullsize_properties(ops):
     """Size-independent properties at HR 536x1280."""
     H, W = 536, 1280
     x = dev(rs(7, (1, 3, H, W)))
-    # zero flow is the identity; integer flow is a pure shift
-    assert torch.equal(ops.backward_warp(x, torch.zeros(1, 2, H, W, device='cuda')), x)
+    # zero flow is the identity and integer flow a pure shift, up to the fp32
+    # resolution of the normalised-coordinate round trip (ulp(1279) ~ 1.2e-4 px,
+    # times a white-noise gradient of <= 1 per px)
+    assert err(ops.backward_warp(x, torch.zeros(1, 2, H, W, device='cuda')), x) <= 5e-4
     fl = torch.zeros(1, 2, H, W, device='cuda'); fl[:, 0] = 3.0; fl[:, 1] = -2.0
     y = ops.backward_warp(x, fl)
-    assert err(y[..., 2:H, 0:W - 3], x[..., 0:H - 2, 3:W]) <= 2e-6
+    assert err(y[..., 2:H, 0:W - 3], x[..., 0:H - 2, 3:W]) <= 5e-4
     # space_to_depth is a permutation: sorted values identical, and depth->space inverts it
     s2d = ops.space_to_depth(x, 4)
     back = s2d.view(1, 4, 4, 3, H // 4, W // 4).permute(0, 3, 4, 1, 5, 2).reshape(1, 3, H, W)
