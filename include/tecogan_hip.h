@@ -84,6 +84,20 @@ int tg_conv3x3_fwd(
     float* y, int64_t y_nstride,
     int n, int cin, int cout, int h, int w, int act, tg_stream_t stream);
 
+/* Split-K variant for layers whose output tile count cannot fill the GPU (FNet's
+ * low-resolution many-channel middle, tecogan_nets.py:37-60): `ksplit` groups of
+ * input channels are reduced by different workgroups into `partials`
+ * (ksplit * n*cout*h*w floats, caller owned), then a finalize pass adds them in a
+ * fixed order (bit-reproducible) and applies bias + activation and, when
+ * pool != 0, the following nn.MaxPool2d(2,2) (y is then (n,cout,h/2,w/2)).
+ * tg_conv3x3_pick_ksplit returns the recommended factor (1 = use tg_conv3x3_fwd). */
+int tg_conv3x3_pick_ksplit(int n, int cin, int cout, int h, int w);
+int tg_conv3x3_splitk_fwd(const float* x, int64_t x_nstride, int c1, const float* x2,
+                          int64_t x2_nstride, const float* w_packed, int ocb,
+                          const float* bias, float* y, int n, int cin, int cout, int h,
+                          int w, int act, int ksplit, float* partials, int pool,
+                          tg_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) + bias
  * + activation, as 4 sub-pixel phase GEMMs (no zero MACs), fp32 MFMA.

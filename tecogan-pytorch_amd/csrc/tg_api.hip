@@ -25,7 +25,7 @@ extern "C" const char* tg_last_error_string(void) { return tg::g_err; }
 struct tg_frnet_plan {
   tg_frnet_cfg cfg;
   std::vector<tg_layer_weights> L;
-  float *A, *B, *FLOW, *S2D, *U1, *U2;
+  float *A, *B, *FLOW, *S2D, *U1, *U2, *PART;
   int fh, fw, launches;
   int st_launch[16];
   double st_flops[16], st_bytes[16];
@@ -37,7 +37,26 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
 
 static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
 
-static void carve(const tg_frnet_cfg* c, size_t off[7]) {
+// largest split-K partial buffer any layer of this shape asks for
+static size_t fnet_partial_floats(const tg_frnet_cfg* c) {
+  size_t best = 0;
+  int hh = c->h, ww = c->w, cin = 2 * c->in_nc;
+  auto consider = [&](int ci, int co) {
+    int ks = tg_conv3x3_pick_ksplit(c->n, ci, co, hh, ww);
+    if (ks > 1) { size_t v = (size_t)ks * c->n * co * hh * ww; if (v > best) best = v; }
+  };
+  const int enc[3] = {32, 64, 128}, dec[3] = {256, 128, 64};
+  for (int e = 0; e < 3; ++e) { consider(cin, enc[e]); consider(enc[e], enc[e]); cin = enc[e]; hh /= 2; ww /= 2; }
+  for (int d = 0; d < 3; ++d) { consider(cin, dec[d]); consider(dec[d], dec[d]); cin = dec[d]; hh *= 2; ww *= 2; }
+  consider(cin, 32);
+  // SRNet layers pick split-K too when the frame itself is tiny
+  hh = c->h; ww = c->w;
+  consider((c->scale * c->scale + 1) * c->in_nc, c->nf);
+  consider(c->nf, c->nf);
+  return best;
+}
+
+static void carve(const tg_frnet_cfg* c, size_t off[8]) {
   size_t hw = (size_t)c->h * c->w, n = c->n;
   size_t o = 0;
   off[0] = o; o += align64(n * 64 * hw);                       // A
@@ -46,7 +65,8 @@ static void carve(const tg_frnet_cfg* c, size_t off[7]) {
   off[3] = o; o += align64(n * c->scale * c->scale * c->in_nc * hw);  // S2D
   off[4] = o; o += align64(n * c->nf * 4 * hw);                // U1
   off[5] = o; o += (c->scale == 4) ? align64(n * c->nf * 16 * hw) : 0;  // U2
-  off[6] = o;
+  off[6] = o; o += align64(fnet_partial_floats(c));            // PART (split-K partial sums)
+  off[7] = o;
 }
 
 static int cfg_ok(const tg_frnet_cfg* c) {
@@ -58,9 +78,9 @@ static int cfg_ok(const tg_frnet_cfg* c) {
 
 extern "C" size_t tg_frnet_workspace_floats(const tg_frnet_cfg* cfg) {
   if (!cfg_ok(cfg)) return 0;
-  size_t off[7];
+  size_t off[8];
   carve(cfg, off);
-  return off[6];
+  return off[7];
 }
 
 extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weights* layers,
@@ -78,8 +98,9 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   TG_REQUIRE(p, TG_E_ARG, "frnet_plan_create: out of host memory");
   p->cfg = *cfg;
   p->L.assign(layers, layers + n_layers);
-  size_t off[7];
+  size_t off[8];
   carve(cfg, off);
+  p->PART = workspace + off[6];
   p->A = workspace + off[0]; p->B = workspace + off[1]; p->FLOW = workspace + off[2];
   p->S2D = workspace + off[3]; p->U1 = workspace + off[4];
   p->U2 = cfg->scale == 4 ? workspace + off[5] : nullptr;
@@ -110,7 +131,8 @@ enum {
   K_POOL = 6,
   K_UPSAMPLE = 7,
   K_QUANT = 8,
-  K_COUNT = 9
+  K_FINAL = 9,      // splitk_finalize_kernel
+  K_COUNT = 10
 };
 
 static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
@@ -131,9 +153,10 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     }
     if (mask & (1u << kind)) rc = fn();
   };
+  // conv3x3 (+bias+act) [+ MaxPool2d(2,2) when pool]; y receives the final tensor.
   auto conv = [&](const float* x, int64_t xns, int c1, const float* x2, int64_t x2ns, int cin,
                   int cout, int hh, int ww, int act, const float* res, int64_t rns, float* y,
-                  int64_t yns) {
+                  int64_t yns, bool pool = false, float* pool_tmp = nullptr) {
     const tg_layer_weights lw = p->L[li++];
     int ocb = tg_conv3x3_pick_ocb(cout);
     int kind = ocb == 32 ? K_CONV32
@@ -142,10 +165,26 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     double px = (double)n * hh * ww;
     double fl = 2.0 * cin * 9 * cout * px;
     double by = 4.0 * px * (cin + cout + (res ? cout : 0)) + 4.0 * 9 * cin * cout;
+    int ks = res ? 1 : tg_conv3x3_pick_ksplit(n, cin, cout, hh, ww);
+    if (ks > 1) {
+      go(kind, fl, by, [&] {
+        return tg::conv3x3_splitk_conv(x, xns, c1, x2, x2ns, lw.w, ocb, n, cin, cout, hh, ww, ks,
+                                       p->PART, st);
+      });
+      go(K_FINAL, 0, 4.0 * px * cout * (ks + 1), [&] {
+        return tg::conv3x3_splitk_finalize(p->PART, ks, lw.b, act, pool ? 1 : 0, y, n, cout, hh, ww,
+                                           st);
+      });
+      return;
+    }
+    float* yc = pool ? pool_tmp : y;
     go(kind, fl, by, [&] {
-      return tg_conv3x3_fwd(x, xns, c1, x2, x2ns, lw.w, ocb, lw.b, res, rns, y, yns, n, cin, cout,
-                            hh, ww, act, st);
+      return tg_conv3x3_fwd(x, xns, c1, x2, x2ns, lw.w, ocb, lw.b, res, rns, yc,
+                            pool ? (int64_t)cout * hh * ww : yns, n, cin, cout, hh, ww, act, st);
     });
+    if (pool)
+      go(K_POOL, 0, 4.0 * n * cout * (hh * ww + (hh / 2) * (ww / 2)),
+         [&] { return tg_maxpool2_fwd(yc, y, n * cout, hh, ww, st); });
   };
   // ---- FNet (tecogan_nets.py:67-82) ------------------------------------------
   int hh = h, ww = w;
@@ -160,13 +199,9 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     else
       conv(src, (int64_t)cin * hh * ww, cin, nullptr, 0, cin, co, hh, ww, TG_ACT_LRELU02, nullptr,
            0, A, (int64_t)co * hh * ww);
-    conv(A, (int64_t)co * hh * ww, co, nullptr, 0, co, co, hh, ww, TG_ACT_LRELU02, nullptr, 0, B,
-         (int64_t)co * hh * ww);
-    {
-      float *pi = B, *po = A; int ph = hh, pw = ww;
-      go(K_POOL, 0, 4.0 * n * co * (ph * pw + (ph / 2) * (pw / 2)),
-         [&] { return tg_maxpool2_fwd(pi, po, n * co, ph, pw, st); });
-    }
+    // second conv of the block + MaxPool2d: pooled result lands in A (B is scratch)
+    conv(A, (int64_t)co * hh * ww, co, nullptr, 0, co, co, hh, ww, TG_ACT_LRELU02, nullptr, 0, A,
+         (int64_t)co * (hh / 2) * (ww / 2), true, B);
     hh /= 2; ww /= 2; cin = co;
     float* t = A; A = B; B = t;   // pooled result now in B
     src = B;
@@ -267,7 +302,8 @@ extern "C" const char* tg_frnet_kind_name(int kind) {
   static const char* names[K_COUNT] = {
       "conv3x3_mfma_kernel<2,2,1>", "conv3x3_mfma_kernel<4,1,2>", "conv3x3_mfma_kernel<4,1,1>",
       "convt3x3s2_mfma_kernel<4,2>", "conv3x3_small_kernel",       "flowup_warp_s2d_kernel",
-      "maxpool2_kernel",             "upsample_kernel",            "quantize_u8_hwc_kernel"};
+      "maxpool2_kernel",             "upsample_kernel",            "quantize_u8_hwc_kernel",
+      "splitk_finalize_kernel"};
   return (kind >= 0 && kind < K_COUNT) ? names[kind] : "?";
 }
 

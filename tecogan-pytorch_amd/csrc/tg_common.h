@@ -28,6 +28,13 @@ inline int check_launch(const char* what) {
     }                               \
   } while (0)
 
+// split-K halves of tg_conv3x3_splitk_fwd (the plan accounts them as separate kernel classes)
+int conv3x3_splitk_conv(const float* x, int64_t x_nstride, int c1, const float* x2,
+                        int64_t x2_nstride, const float* w_packed, int ocb, int n, int cin,
+                        int cout, int h, int w, int ksplit, float* partials, tg_stream_t stream);
+int conv3x3_splitk_finalize(const float* partials, int ksplit, const float* bias, int act, int pool,
+                            float* y, int n, int cout, int h, int w, tg_stream_t stream);
+
 // rows of the image one conv3x3 workgroup covers (selects the kernel variant):
 // 64-oc blocks use the 4-row / 2-tile-per-wave variant on big images and the
 // 2-row variant (twice the workgroups) where tile quantisation dominates.
@@ -56,6 +63,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // Negative-side slope of the piecewise-linear activations: x >= 0 ? x : x*slope
 // (1 = identity, 0 = ReLU, 0.2 = LeakyReLU(0.2)); wave-uniform, branch free.
 __device__ __forceinline__ float act_slope(int act) {
+  return act == TG_ACT_RELU ? 0.f : (act == TG_ACT_LRELU02 ? 0.2f : 1.f);
+}
+
+inline float act_slope_host(int act) {
   return act == TG_ACT_RELU ? 0.f : (act == TG_ACT_LRELU02 ? 0.2f : 1.f);
 }
 

@@ -44,6 +44,12 @@ struct Conv3x3Args {
   long long x_ns, x2_ns, res_ns, y_ns;
   int c1, cin, cout, h, w, act;
   int tiles_x, tiles_y, nchunk, nocg;
+  // split-K: each workgroup reduces chunks [ks*nchunk/ksplit, (ks+1)*nchunk/ksplit) and
+  // writes RAW partial sums to part + ks*part_ss (n, cout, h, w); splitk_finalize_kernel
+  // adds them in a fixed order (deterministic) with bias / activation / pooling.
+  int ksplit;
+  float* part;
+  long long part_ss;
 };
 
 // pack OIHW (or IOHW for transposed convs) -> [ocg][chunk][tap][half][ocb][4]
@@ -77,7 +83,10 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned vof
 
 constexpr unsigned OOB = 0x80000000u;   // >= any num_records we build (tensors < 2 GiB per item)
 
-template <int WM, int WN, int NT, bool DUAL>
+// ABL: ablation bits for tools/conv_lab.hip only (0 in the product):
+//   1 = no re-staging inside the chunk loop, 2 = no barrier in the loop,
+//   4 = no epilogue stores, 8 = no LDS operand reads.
+template <int WM, int WN, int NT, bool DUAL, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a) {
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int OCB = WN * NT * 32;
@@ -102,10 +111,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   int b = blockIdx.x;
   const int tx = b % a.tiles_x; b /= a.tiles_x;
   const int ty = b % a.tiles_y; b /= a.tiles_y;
-  const int ocg = b % a.nocg;
-  const int n = b / a.nocg;
+  const int ocg = b % a.nocg; b /= a.nocg;
+  const int ks = b % a.ksplit;
+  const int n = b / a.ksplit;
   const int x0 = tx * TW, y0 = ty * WM;
   const int hw = a.h * a.w;
+  const int ch_begin = (int)((long long)ks * a.nchunk / a.ksplit);
+  const int ch_end = (int)((long long)(ks + 1) * a.nchunk / a.ksplit);
 
   // ---- staging assignment: item q = (row r, half hf, col) -------------------
   unsigned voff[I_PER_T];     // byte offset of channel (4*hf) at this pixel, or OOB
@@ -178,13 +190,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   const int b_off = ((wm * 2 + lh) * RS + ll) * 4;
   const int a_off = (lh * OCB + wn * (NT * 32) + ll) * 4;
 
-  load_chunk(0);
-  store_chunk(0);
+  load_chunk(ch_begin);
+  store_chunk(ch_begin & 1);
   __syncthreads();
 
-  for (int ch = 0; ch < a.nchunk; ++ch) {
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
     const int buf = ch & 1;
-    const bool more = (ch + 1 < a.nchunk);
+    const bool more = (ch + 1 < ch_end) && !(ABL & 1);
     if (more) load_chunk(ch + 1);
 
     const float* si = s_in + buf * IN_FLOATS + b_off;
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int cur = tap & 1, nxt = cur ^ 1;
-      if (tap + 1 < 9) {
+      if (tap + 1 < 9 && !(ABL & 8)) {
         const int ky = (tap + 1) / 3, kx = (tap + 1) % 3;
         bq[nxt] = *reinterpret_cast<const f32x4*>(si + (ky * 2 * RS + kx) * 4);
 #pragma unroll
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
       }
     }
     if (more) store_chunk(buf ^ 1);
-    __syncthreads();
+    if (!(ABL & 2)) __syncthreads();
   }
 
   // ---- epilogue: bias, activation, residual, NCHW store --------------------
@@ -221,6 +233,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   const bool inimg = px < a.w && py < a.h;
   const long long opix = (long long)py * a.w + px;
   const int ocb0 = ocg * OCB + wn * (NT * 32) + 4 * lh;
+  if (a.ksplit > 1) {   // raw partial sums, wave-uniform branch
+    if (inimg) {
+      float* pb = a.part + (long long)ks * a.part_ss + (long long)n * a.cout * hw + opix;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int oc = ocb0 + t * 32 + (r & 3) + 8 * (r >> 2);
+          if (oc < a.cout) pb[(long long)oc * hw] = acc[t][r];
+        }
+    }
+    return;
+  }
   const float slope = act_slope(a.act);
   float bv[NT][16], rv[NT][16];
 #pragma unroll
@@ -241,7 +266,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
         int oc = ocb0 + t * 32 + (r & 3) + 8 * (r >> 2);
         float v = acc[t][r] + bv[t][r];
         v = (v >= 0.f ? v : v * slope + 0.f) + rv[t][r];
-        if (oc < a.cout) yb[(long long)oc * hw] = v;
+        if (oc < a.cout && (!(ABL & 4) || v == 12345.678f)) yb[(long long)oc * hw] = v;
       }
   }
 }
@@ -255,7 +280,8 @@ static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   a.nocg = cdiv(a.cout, OCB);
   a.nchunk = cdiv(a.cin, CK);
   size_t lds = 2 * (size_t)((WM + 2) * 2 * RS * 4 + 9 * CK * OCB) * sizeof(float);
-  long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n;
+  if (a.ksplit < 1) a.ksplit = 1;
+  long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n * a.ksplit;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "conv3x3: grid %lld", blocks);
   if (a.x2)
     hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, true>), dim3((unsigned)blocks),
@@ -266,9 +292,54 @@ static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   return check_launch("conv3x3_mfma");
 }
 
+// out = act(sum_s part[s] + bias), optionally followed by MaxPool2d(2,2) (floor).
+// The sum runs s = 0..S-1 in order: bit-reproducible.
+__global__ void splitk_finalize_kernel(const float* __restrict__ part, int S, long long part_ss,
+                                       const float* __restrict__ bias, float slope, int pool,
+                                       float* __restrict__ y, int n, int c, int h, int w) {
+  const int oh = pool ? h / 2 : h, ow = pool ? w / 2 : w;
+  const long long total = (long long)n * c * oh * ow;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int ox = (int)(i % ow); long long t = i / ow;
+    int oy = (int)(t % oh); t /= oh;
+    int ch = (int)(t % c);
+    long long plane = t * h * (long long)w;   // (n*c + ch) plane offset
+    float b = bias ? bias[ch] : 0.f;
+    auto at = [&](int yy, int xx) {
+      const float* p = part + plane + (long long)yy * w + xx;
+      float v = 0.f;
+      for (int s = 0; s < S; ++s) v += p[(long long)s * part_ss];
+      v += b;
+      return v >= 0.f ? v : v * slope + 0.f;
+    };
+    float v;
+    if (pool) {
+      v = fmaxf(fmaxf(at(2 * oy, 2 * ox), at(2 * oy, 2 * ox + 1)),
+                fmaxf(at(2 * oy + 1, 2 * ox), at(2 * oy + 1, 2 * ox + 1)));
+    } else {
+      v = at(oy, ox);
+    }
+    y[i] = v;
+  }
+}
+
 }  // namespace tg
 
 using namespace tg;
+
+// Split factor for layers whose tile count cannot fill 256 CUs (FNet's
+// low-resolution, many-channel middle).  1 = no split.
+extern "C" int tg_conv3x3_pick_ksplit(int n, int cin, int cout, int h, int w) {
+  int ocb = tg_conv3x3_pick_ocb(cout);
+  int rows = conv3x3_rows_per_wg(ocb, (long long)n * h * w);
+  long long wgs = (long long)cdiv(w, TW) * cdiv(h, rows) * cdiv(cout, ocb) * n;
+  int nchunk = cdiv(cin, CK);
+  if (wgs >= 400 || nchunk < 4) return 1;
+  int ks = 1;
+  while (ks < 8 && wgs * ks < 640 && nchunk / (ks * 2) >= 2) ks *= 2;
+  return ks;
+}
 
 extern "C" int tg_conv3x3_pick_ocb(int cout) { return cout <= 32 ? 32 : 64; }
 
@@ -291,11 +362,11 @@ extern "C" int tg_conv3x3_pack(const float* w, float* w_packed, int cin, int cou
   return check_launch("pack3x3");
 }
 
-extern "C" int tg_conv3x3_fwd(const float* x, int64_t x_nstride, int c1, const float* x2,
-                              int64_t x2_nstride, const float* w_packed, int ocb,
-                              const float* bias, const float* res, int64_t res_nstride,
-                              float* y, int64_t y_nstride, int n, int cin, int cout, int h,
-                              int w, int act, tg_stream_t stream) {
+static int conv3x3_impl(const float* x, int64_t x_nstride, int c1, const float* x2,
+                        int64_t x2_nstride, const float* w_packed, int ocb, const float* bias,
+                        const float* res, int64_t res_nstride, float* y, int64_t y_nstride, int n,
+                        int cin, int cout, int h, int w, int act, int ksplit, float* partials,
+                        tg_stream_t stream) {
   TG_REQUIRE(x && w_packed && y, TG_E_ARG, "conv3x3_fwd: null pointer");
   TG_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, TG_E_SHAPE,
              "conv3x3_fwd: n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, w);
@@ -310,10 +381,56 @@ extern "C" int tg_conv3x3_fwd(const float* x, int64_t x_nstride, int c1, const f
   a.x = x; a.x2 = (c1 < cin) ? x2 : nullptr; a.wpk = w_packed; a.bias = bias; a.res = res;
   a.y = y; a.x_ns = x_nstride; a.x2_ns = x2_nstride; a.res_ns = res_nstride; a.y_ns = y_nstride;
   a.c1 = c1; a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
+  a.ksplit = ksplit; a.part = partials; a.part_ss = (long long)n * cout * h * w;
   hipStream_t s = (hipStream_t)stream;
   if (ocb == 32) return launch_conv<4, 1, 1>(a, n, s);
   // 64 output channels per workgroup.  Small images get the 2-row tile so that
   // more workgroups exist (tile quantisation dominates there).
   if (conv3x3_rows_per_wg(ocb, (long long)n * h * w) == 4) return launch_conv<4, 1, 2>(a, n, s);
   return launch_conv<2, 2, 1>(a, n, s);
+}
+
+extern "C" int tg_conv3x3_fwd(const float* x, int64_t x_nstride, int c1, const float* x2,
+                              int64_t x2_nstride, const float* w_packed, int ocb,
+                              const float* bias, const float* res, int64_t res_nstride,
+                              float* y, int64_t y_nstride, int n, int cin, int cout, int h,
+                              int w, int act, tg_stream_t stream) {
+  return conv3x3_impl(x, x_nstride, c1, x2, x2_nstride, w_packed, ocb, bias, res, res_nstride, y,
+                      y_nstride, n, cin, cout, h, w, act, 1, nullptr, stream);
+}
+
+namespace tg {
+int conv3x3_splitk_conv(const float* x, int64_t x_nstride, int c1, const float* x2,
+                        int64_t x2_nstride, const float* w_packed, int ocb, int n, int cin,
+                        int cout, int h, int w, int ksplit, float* partials, tg_stream_t stream) {
+  return conv3x3_impl(x, x_nstride, c1, x2, x2_nstride, w_packed, ocb, nullptr, nullptr, 0,
+                      partials, (int64_t)cout * h * w, n, cin, cout, h, w, TG_ACT_NONE, ksplit,
+                      partials, stream);
+}
+int conv3x3_splitk_finalize(const float* partials, int ksplit, const float* bias, int act, int pool,
+                            float* y, int n, int cout, int h, int w, tg_stream_t stream) {
+  long long total = (long long)n * cout * (pool ? (h / 2) * (w / 2) : h * w);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(splitk_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     partials, ksplit, (long long)n * cout * h * w, bias, act_slope_host(act), pool,
+                     y, n, cout, h, w);
+  return check_launch("splitk_finalize");
+}
+}  // namespace tg
+
+extern "C" int tg_conv3x3_splitk_fwd(const float* x, int64_t x_nstride, int c1, const float* x2,
+                                     int64_t x2_nstride, const float* w_packed, int ocb,
+                                     const float* bias, float* y, int n, int cin, int cout, int h,
+                                     int w, int act, int ksplit, float* partials, int pool,
+                                     tg_stream_t stream) {
+  TG_REQUIRE(y && partials, TG_E_ARG, "conv3x3_splitk_fwd: null pointer");
+  TG_REQUIRE(ksplit >= 2 && ksplit <= 16 && ksplit <= cdiv(cin, CK), TG_E_ARG,
+             "conv3x3_splitk_fwd: ksplit=%d for cin=%d", ksplit, cin);
+  TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_LRELU02, TG_E_ARG, "conv3x3_splitk_fwd: act=%d", act);
+  TG_REQUIRE(!pool || (h >= 2 && w >= 2), TG_E_SHAPE, "conv3x3_splitk_fwd: pool needs h,w >= 2");
+  int rc = conv3x3_splitk_conv(x, x_nstride, c1, x2, x2_nstride, w_packed, ocb, n, cin, cout, h, w,
+                               ksplit, partials, stream);
+  if (rc != TG_OK) return rc;
+  return conv3x3_splitk_finalize(partials, ksplit, bias, act, pool, y, n, cout, h, w, stream);
 }

@@ -46,12 +46,12 @@ class _Conv(nn.Module):
             self._cache = (key, pk, ocb)
         return self._cache[1], self._cache[2]
 
-    def forward(self, x, act=ops.ACT_NONE, x2=None, res=None, out=None):
+    def forward(self, x, act=ops.ACT_NONE, x2=None, res=None, out=None, pool=False):
         pk, ocb = self.packed()
         if self.transposed:
             return ops.convt3x3s2(x, pk, self.bias, self.cout, act, out=out)
         return ops.conv3x3(x, pk, self.bias, self.cin, self.cout, ocb, act, x2=x2, res=res,
-                           out=out)
+                           out=out, pool=pool)
 
 
 def _block(pairs):
@@ -86,8 +86,7 @@ class FNet(nn.Module):
         for i, name in enumerate(('encoder1', 'encoder2', 'encoder3')):
             blk = getattr(self, name)
             out = blk['0'](x1, ops.ACT_LRELU02, x2=x2) if i == 0 else blk['0'](out, ops.ACT_LRELU02)
-            out = blk['2'](out, ops.ACT_LRELU02)
-            out = ops.maxpool2(out)
+            out = blk['2'](out, ops.ACT_LRELU02, pool=True)
         for name in ('decoder1', 'decoder2', 'decoder3'):
             blk = getattr(self, name)
             out = blk['2'](blk['0'](out, ops.ACT_LRELU02), ops.ACT_LRELU02)

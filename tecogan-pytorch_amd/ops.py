@@ -51,10 +51,31 @@ def pack_conv3x3(weight, transposed=False, ocb=None):
     return out, cin, cout, ocb
 
 
-def conv3x3(x, wpk, bias, cin, cout, ocb, act=ACT_NONE, x2=None, res=None, out=None):
-    """y = act(conv3x3(cat[x, x2]) + bias) (+ res).  x: (n,c1,h,w), x2: (n,cin-c1,h,w)."""
+def conv3x3(x, wpk, bias, cin, cout, ocb, act=ACT_NONE, x2=None, res=None, out=None,
+            pool=False, ksplit=None):
+    """y = act(conv3x3(cat[x, x2]) + bias) (+ res) [-> maxpool2 when pool].
+    x: (n,c1,h,w), x2: (n,cin-c1,h,w).  Small, deep layers go through the
+    deterministic split-K path (ksplit=None: library heuristic)."""
     _chk(x, 'x')
     n, c1, h, w = x.shape
+    if ksplit is None:
+        ksplit = 1 if res is not None else L.lib().tg_conv3x3_pick_ksplit(n, cin, cout, h, w)
+    if ksplit > 1:
+        if res is not None:
+            raise L.TecoganHipError('conv3x3: split-K path has no residual epilogue')
+        if x2 is not None:
+            _chk(x2, 'x2')
+        part = torch.empty(ksplit * n * cout * h * w, dtype=torch.float32, device=x.device)
+        oh, ow = (h // 2, w // 2) if pool else (h, w)
+        if out is None:
+            out = torch.empty(n, cout, oh, ow, dtype=torch.float32, device=x.device)
+        L.check(L.lib().tg_conv3x3_splitk_fwd(
+            x.data_ptr(), c1 * h * w, c1, _ptr(x2), 0 if x2 is None else x2.shape[1] * h * w,
+            wpk.data_ptr(), ocb, _ptr(bias), out.data_ptr(), n, cin, cout, h, w, act, ksplit,
+            part.data_ptr(), 1 if pool else 0, _stream()), 'tg_conv3x3_splitk_fwd')
+        return out
+    if pool:
+        return maxpool2(conv3x3(x, wpk, bias, cin, cout, ocb, act, x2=x2, res=res, ksplit=1))
     if x2 is not None:
         _chk(x2, 'x2')
         if x2.shape[0] != n or x2.shape[2:] != x.shape[2:] or c1 + x2.shape[1] != cin:

@@ -140,6 +140,26 @@ def test_conv3x3_mfma(ops, n, cin, cout, h, w, act, c1, use_res):
     assert err(out, ref) <= 1e-5, err(out, ref)
 
 
+@pytest.mark.parametrize('n,cin,cout,h,w,ks,pool', [
+    (1, 256, 256, 16, 40, 8, False), (1, 128, 128, 33, 80, 4, True), (2, 64, 64, 9, 21, 2, True),
+    (1, 128, 256, 16, 40, None, False), (1, 64, 128, 33, 80, None, True)])
+def test_conv3x3_splitk(ops, n, cin, cout, h, w, ks, pool):
+    """Deterministic split-K path (FNet middle layers) incl. the fused MaxPool2d."""
+    import torch.nn.functional as F
+    x = rs(1, (n, cin, h, w), -1, 1)
+    wt = rs(2, (cout, cin, 3, 3), -1, 1) / (3.0 * cin ** 0.5)
+    b = rs(3, (cout,), -0.5, 0.5)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    ref = torch.where(ref >= 0, ref, ref * 0.2)
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    pk, _, _, ocb = ops.pack_conv3x3(dev(wt))
+    out = ops.conv3x3(dev(x), pk, dev(b), cin, cout, ocb, 2, pool=pool, ksplit=ks)
+    assert out.shape == ref.shape and err(out, ref) <= 1e-5, err(out, ref)
+    out2 = ops.conv3x3(dev(x), pk, dev(b), cin, cout, ocb, 2, pool=pool, ksplit=ks)
+    assert torch.equal(out, out2)          # fixed summation order: bit-reproducible
+
+
 def test_conv3x3_inplace_residual(ops):
     """The resblock tail writes `conv(t) + x` over x (plan does this)."""
     import torch.nn.functional as F
