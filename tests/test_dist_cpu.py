@@ -1,0 +1,61 @@
+"""world_size-2 gloo test of the N > 1 path: round-robin clip sharding with no
+data-path collective, max-over-ranks timing and metric reduce to rank 0."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, num_seq, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from tecogan_pytorch_amd.utils import dist_utils as D
+    opt = {}
+    D.init_dist(opt, rank, backend='gloo')
+    assert opt['rank'] == rank and opt['world_size'] == world and opt['dist']
+    mine = D.shard_indices(num_seq)
+    # each rank "processes" its own sequences: metric = 10 + idx, others stay 0
+    vals = [0.0] * num_seq
+    for i in mine:
+        vals[i] = 10.0 + i
+    red = D.reduce_sum_to_master(vals)
+    tmax = D.max_over_ranks(1.0 + rank)
+    calls = []
+    D.master_only(lambda: calls.append(rank))()
+    out[rank] = (mine, red.tolist(), tmax, calls)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_sharding_and_reductions():
+    world, num_seq = 2, 7
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, num_seq, out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert sorted(a[0] + b[0]) == list(range(num_seq))          # every clip exactly once
+    assert set(a[0]).isdisjoint(b[0])
+    assert a[0] == [0, 2, 4, 6] and b[0] == [1, 3, 5]           # main.py:169 order
+    assert a[1] == [10.0 + i for i in range(num_seq)]           # rank 0 holds the full table
+    assert a[2] == 2.0 and b[2] == 2.0                          # MAX over ranks everywhere
+    assert a[3] == [0] and b[3] == []                           # master_only
+
+
+def test_single_process_defaults():
+    from tecogan_pytorch_amd.utils import dist_utils as D
+    assert D.get_dist_info() == (0, 1)
+    assert D.shard_indices(5) == [0, 1, 2, 3, 4]
+    assert D.max_over_ranks(3.5) == 3.5
