@@ -439,3 +439,223 @@ def psnr_float(a, b, peak=1.0):
     if mse == 0:
         return np.inf
     return 10 * math.log10(peak * peak / mse)
+
+
+# ==========================================================================
+# Training rows (D1, T1-T4).  All ops above are built
+# from differentiable torch primitives, so torch autograd over THIS file is
+# the gradient oracle for the HIP backward kernels.
+# ==========================================================================
+
+# --------------------------------------------------------------------------
+# T4  losses   (codes/models/optim/losses.py:6-50)
+# --------------------------------------------------------------------------
+def charbonnier(x, y, reduction='mean', eps=1e-6):
+    """sqrt(d^2 + eps), losses.py:31-50."""
+    d = x - y
+    v = torch.sqrt(d * d + eps)
+    return v.mean() if reduction == 'mean' else v.sum()
+
+
+def bce_with_logits(x, status, reduction='mean'):
+    """VanillaGANLoss, losses.py:6-14: BCEWithLogits against a constant target
+    t in {0,1}:  max(x,0) - x*t + log(1 + exp(-|x|))."""
+    t = float(int(status))
+    v = torch.clamp(x, min=0) - x * t + torch.log1p(torch.exp(-x.abs()))
+    return v.mean() if reduction == 'mean' else v.sum()
+
+
+# --------------------------------------------------------------------------
+# D1  SpatioTemporalDiscriminator   (tecogan_nets.py:318-477)
+# --------------------------------------------------------------------------
+def batch_norm_train(x, weight, bias, running_mean, running_var, momentum=0.1, eps=1e-5):
+    """nn.BatchNorm2d in train mode (tecogan_nets.py:324-339): batch statistics
+    (biased variance) for normalisation; running stats updated in place with the
+    UNBIASED variance."""
+    n = x.numel() / x.shape[1]
+    mean = x.mean(dim=(0, 2, 3))
+    var = x.var(dim=(0, 2, 3), unbiased=False)
+    with torch.no_grad():
+        running_mean.mul_(1 - momentum).add_(momentum * mean)
+        running_var.mul_(1 - momentum).add_(momentum * var * n / (n - 1))
+    xh = (x - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + eps)
+    return xh * weight.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+
+
+def discriminator_forward(sd, data, lr_data, bi_data, hr_flow, spatial_size,
+                          crop_border_ratio, use_pp_crit=True, hr_flow_merge=None):
+    """forward_sequence, tecogan_nets.py:384-477, use_pp_crit branch (:408-411).
+    `sd` tensors for BN running stats are updated in place.  Returns
+    (logits (n_clip,1), [4 feature maps], hr_flow_merge)."""
+    n, t, c, lr_h, lr_w = lr_data.shape
+    hr_h, hr_w = data.shape[3:]
+    t = t // 3 * 3
+    n_clip = n * t // 3
+    c_size = int(spatial_size * crop_border_ratio)
+    n_pad = (spatial_size - c_size) // 2
+    if hr_flow_merge is None:
+        if not use_pp_crit:
+            raise NotImplementedError('oracle covers the shipped use_pp_crit=True path')
+        bw = hr_flow[:, 0:t:3]
+        idle = torch.zeros_like(bw)
+        fw = hr_flow.flip(1)[:, 1:t:3]
+        hr_flow_merge = torch.stack([bw, idle, fw], dim=2).reshape(
+            n_clip * 3, 2, hr_h, hr_w).detach()
+
+    def triplets(x):   # (n,t,c,h,w) -> (n_clip, c*3, h, w) in rrrgggbbb order (:440-449)
+        x = x[:, :t].reshape(n_clip, 3, c, hr_h, hr_w)
+        return x.permute(0, 2, 1, 3, 4).reshape(n_clip, c * 3, hr_h, hr_w)
+
+    cond = triplets(bi_data)
+    orig = triplets(data)
+    warp = backward_warp(data[:, :t].reshape(n * t, c, hr_h, hr_w), hr_flow_merge)
+    warp = warp.view(n_clip, 3, c, hr_h, hr_w).permute(0, 2, 1, 3, 4).reshape(
+        n_clip, c * 3, hr_h, hr_w)
+    warp = F.pad(warp[..., n_pad:n_pad + c_size, n_pad:n_pad + c_size], (n_pad,) * 4)
+    x = torch.cat([orig, warp, cond], 1)                                  # :463
+    out = _lrelu(_conv(x, sd, 'conv_in.0'))
+    feats = []
+    for i in range(1, 5):
+        p = f'discriminator_block.block{i}'
+        out = F.conv2d(out, sd[p + '.0.weight'], None, stride=2, padding=1)
+        out = batch_norm_train(out, sd[p + '.1.weight'], sd[p + '.1.bias'],
+                               sd[p + '.1.running_mean'], sd[p + '.1.running_var'])
+        sd[p + '.1.num_batches_tracked'] += 1
+        out = _lrelu(out)
+        feats.append(out)
+    logits = F.linear(out.reshape(out.shape[0], -1), sd['dense.weight'], sd['dense.bias'])
+    return logits, feats, hr_flow_merge
+
+
+# --------------------------------------------------------------------------
+# T4  Adam   (torch.optim.Adam as used at vsr_model.py:47-52, vsrgan_model.py:76-87)
+# --------------------------------------------------------------------------
+def adam_step(params, grads, state, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """In-place Adam (no amsgrad): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+    p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)."""
+    b1, b2 = betas
+    state['step'] = state.get('step', 0) + 1
+    t = state['step']
+    for k, p in params.items():
+        g = grads.get(k)
+        if g is None:
+            continue
+        if weight_decay:
+            g = g + weight_decay * p
+        m = state.setdefault('m', {}).setdefault(k, torch.zeros_like(p))
+        v = state.setdefault('v', {}).setdefault(k, torch.zeros_like(p))
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(1 - b2 ** t)).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / (1 - b1 ** t))
+
+
+def _leafs(sd):
+    """float tensors of a state dict as autograd leaves (buffers stay plain)."""
+    out = {}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and not k.endswith(('running_mean', 'running_var', 'kernels')):
+            out[k] = v.detach().clone().requires_grad_(True)
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def prepare_training_data(gt, scale, degradation, sigma=1.5):
+    """BaseModel.prepare_training_data, base_model.py:42-85 (BD): valid-conv
+    blur+decimate of the bordered GT, then crop the GT border."""
+    assert degradation == 'BD'
+    n, t, c, gh, gw = gt.shape
+    border = int(sigma * 3.0)
+    lr_h, lr_w = (gh - 2 * border) // scale, (gw - 2 * border) // scale
+    flat = gt.reshape(n * t, c, gh, gw)
+    lr = downsample_bd(flat, sigma, scale, False).view(n, t, c, lr_h, lr_w)
+    gtc = flat[..., border:border + scale * lr_h, border:border + scale * lr_w]
+    return lr, gtc.reshape(n, t, c, scale * lr_h, scale * lr_w)
+
+
+# --------------------------------------------------------------------------
+# T2  VSRModel.train   (codes/models/vsr_model.py:61-95)
+# --------------------------------------------------------------------------
+def vsr_train_step(sd_G, adam_G, lr_data, gt_data, scale, degradation, lr=1e-4,
+                   pix_w=1.0, warp_w=1.0, reduction='mean'):
+    """One FRVSR iteration.  sd_G / adam_G are updated in place.
+    Returns (log_dict, grads)."""
+    P = _leafs(sd_G)
+    out = forward_sequence(P, lr_data, scale, degradation)
+    l_pix = pix_w * charbonnier(out['hr_data'], gt_data, reduction)
+    lr_warp = backward_warp(out['lr_prev'], out['lr_flow'])
+    l_warp = warp_w * charbonnier(lr_warp, out['lr_curr'], reduction)
+    (l_pix + l_warp).backward()
+    grads = {k: v.grad for k, v in P.items() if torch.is_tensor(v) and v.requires_grad
+             and v.grad is not None}
+    with torch.no_grad():
+        adam_step({k: sd_G[k] for k in grads}, grads, adam_G, lr)
+    return {'l_pix_G': l_pix.item(), 'l_warp_G': l_warp.item()}, grads
+
+
+# --------------------------------------------------------------------------
+# T1  VSRGANModel.train   (codes/models/vsrgan_model.py:98-286), feature_crit and
+#     feature_matching_crit disabled (BASELINE config 3: "G+D+warp losses")
+# --------------------------------------------------------------------------
+def vsrgan_train_step(sd_G, sd_D, adam_G, adam_D, state, lr_data, gt_data, scale, degradation,
+                      spatial_size, tempo_extent, lr_G=5e-5, lr_D=5e-5, pix_w=1.0, warp_w=1.0,
+                      pp_w=0.5, gan_w=0.01, crop_border_ratio=0.75, update_threshold=0.4,
+                      reduction='mean'):
+    n, t, c, lr_h, lr_w = lr_data.shape
+    gt_h, gt_w = gt_data.shape[3:]
+    bi = upsample(lr_data.reshape(n * t, c, lr_h, lr_w), scale, degradation).view(
+        n, t, c, gt_h, gt_w)                                                  # :106-108
+    lr_data = torch.cat([lr_data, lr_data.flip(1)[:, 1:]], 1)                 # :112-119
+    gt_data = torch.cat([gt_data, gt_data.flip(1)[:, 1:]], 1)
+    bi = torch.cat([bi, bi.flip(1)[:, 1:]], 1)
+    PG, PD = _leafs(sd_G), _leafs(sd_D)
+    log = {}
+    out = forward_sequence(PG, lr_data, scale, degradation)                   # :129
+    hr = out['hr_data']
+    kw = dict(lr_data=lr_data, bi_data=bi, hr_flow=out['hr_flow'], spatial_size=spatial_size,
+              crop_border_ratio=crop_border_ratio)
+    real, _, merge = discriminator_forward(PD, gt_data, **kw)                 # :148
+    fake, _, _ = discriminator_forward(PD, hr.detach(), hr_flow_merge=merge, **kw)   # :154
+    lreal = torch.log(torch.sigmoid(real) + 1e-8).mean()                      # :163-164
+    lfake = torch.log(torch.sigmoid(fake) + 1e-8).mean()
+    distance = (lreal - lfake).item()
+    upd_D = distance < update_threshold                                       # :176
+    gD = {}
+    if upd_D:
+        state['cnt_upd_D'] = state.get('cnt_upd_D', 0) + 1.0
+        loss_D = bce_with_logits(real, True, reduction) + bce_with_logits(fake, False, reduction)
+        loss_D.backward()
+        gD = {k: v.grad for k, v in PD.items() if torch.is_tensor(v) and v.requires_grad
+              and v.grad is not None}
+        with torch.no_grad():
+            # BN running stats were advanced on PD's copies; publish everything
+            adam_step({k: PD[k] for k in gD}, gD, adam_D, lr_D)
+        log['l_gan_D'] = loss_D.item()
+    else:
+        log['l_gan_D'] = 0.0
+    log['p_real_D'] = real.mean().item()
+    log['p_fake_D'] = fake.mean().item()
+    log['distance'] = distance
+    log['n_upd_D'] = state.get('cnt_upd_D', 0)
+    # D frozen (its parameters now hold the UPDATED values, :201-202 after :188)
+    PDf = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in PD.items()}
+    l_pix = pix_w * charbonnier(hr, gt_data, reduction)                       # :208-212
+    lr_warp = backward_warp(out['lr_prev'], out['lr_flow'])                   # :219
+    l_warp = warp_w * charbonnier(lr_warp, out['lr_curr'], reduction)
+    hr_fw = hr[:, :tempo_extent - 1]                                          # :246-247
+    hr_bw = hr[:, tempo_extent:].flip(1)
+    l_pp = pp_w * charbonnier(hr_fw, hr_bw, reduction)
+    fake_g, _, _ = discriminator_forward(PDf, hr, hr_flow_merge=merge, **kw)  # :275
+    l_gan = gan_w * bce_with_logits(fake_g, True, reduction)
+    (l_pix + l_warp + l_pp + l_gan).backward()
+    gG = {k: v.grad for k, v in PG.items() if torch.is_tensor(v) and v.requires_grad
+          and v.grad is not None}
+    with torch.no_grad():
+        adam_step({k: sd_G[k] for k in gG}, gG, adam_G, lr_G)
+        for k, v in PD.items():          # publish D params / BN buffers back
+            sd_D[k].copy_(v.detach()) if torch.is_tensor(sd_D[k]) and sd_D[k].shape == v.shape \
+                else None
+    log.update({'l_pix_G': l_pix.item(), 'l_warp_G': l_warp.item(), 'l_pp_G': l_pp.item(),
+                'l_gan_G': l_gan.item(), 'p_fake_G': fake_g.mean().item()})
+    return log, gG, gD
