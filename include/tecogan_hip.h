@@ -72,7 +72,10 @@ const char* tg_last_error_string(void);
 int tg_conv3x3_pick_ocb(int cout);
 size_t tg_conv3x3_packed_floats(int cin, int cout, int ocb);
 /* w_oihw: (cout, cin, 3, 3) as nn.Conv2d.weight.  transposed=1: w is
- * (cin, cout, 3, 3) as nn.ConvTranspose2d.weight (used by tg_convt3x3s2_fwd). */
+ * (cin, cout, 3, 3) as nn.ConvTranspose2d.weight (used by tg_convt3x3s2_fwd).
+ * transposed=2: data-gradient packing of a Conv2d weight: the op maps the conv's
+ * cout -> cin, i.e. call with cin := conv.cout, cout := conv.cin and w the
+ * ORIGINAL (conv.cout, conv.cin, 3, 3) tensor; taps are rotated by 180 degrees. */
 int tg_conv3x3_pack(const float* w, float* w_packed, int cin, int cout, int ocb,
                     int transposed, tg_stream_t stream);
 
@@ -163,6 +166,74 @@ int tg_maxpool2_fwd(const float* x, float* y, int nc, int h, int w,
  * y = uint8(clip(rint(x*255), 0, 255)), rint = round-half-even. */
 int tg_quantize_u8_hwc(const float* x, uint8_t* y, int c, int h, int w,
                        tg_stream_t stream);
+
+/* ========================================================================
+ * Training side: backward kernels.
+ * Conv data gradients reuse tg_conv3x3_fwd with weights packed by
+ * tg_conv3x3_pack(..., transposed = 2) (rot180 + in/out swap).
+ * ====================================================================== */
+
+/* dW of Conv2d(cin,cout,3,1,1):  G[a][b][tap] (+)= sum_{n,y,x} p[n][a][y][x] * q[n][b][y+ky-1][x+kx-1]
+ * with p = dZ (a = cout), q = X (b = cin); fp32 MFMA, deterministic split reduction.
+ * `grad` is the (ca, cb_total, 3, 3) gradient tensor; columns [cb_off, cb_off+cb) are
+ * written (two-source convs call it once per source).  workspace:
+ * tg_wgrad3x3_workspace_floats(...) floats, caller owned. */
+size_t tg_wgrad3x3_workspace_floats(int n, int ca, int cb_total, int h, int w);
+int tg_wgrad3x3(const float* p, int64_t p_nstride, const float* q, int64_t q_nstride,
+                float* grad, float* workspace, int n, int ca, int cb, int cb_total,
+                int cb_off, int h, int w, int accumulate, tg_stream_t stream);
+
+/* dx = dy * act'(.), expressed through the activation OUTPUT y (ReLU, LeakyReLU(0.2),
+ * tanh*24).  dx may alias dy. */
+int tg_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act,
+               tg_stream_t stream);
+/* db[c] (+)= sum_{n,h,w} dy */
+int tg_bias_grad(const float* dy, float* db, int n, int c, int hw, int accumulate,
+                 tg_stream_t stream);
+/* MaxPool2d(2,2) backward; x is the pool INPUT (nc,h,w), dy (nc,h/2,w/2) */
+int tg_maxpool2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w,
+                    tg_stream_t stream);
+/* transpose of tg_upsample_fwd: dx (nc,h,w) = up^T(mul * dy) */
+int tg_upsample_bwd(const float* dy, float* dx, int nc, int h, int w, int scale,
+                    int up_mode, float mul, tg_stream_t stream);
+/* backward_warp backward (grid_sample bilinear/border/align_corners=True autograd):
+ * dimg (n,c,h,w) and/or dflow (n,2,h,w); either may be NULL. */
+int tg_backward_warp_bwd(const float* x, const float* flow, const float* dy, float* dimg,
+                         float* dflow, int n, int c, int h, int w, tg_stream_t stream);
+/* inverse of tg_space_to_depth: x (n, s*s*c, h, w) -> y (n, c, s*h, s*w) */
+int tg_depth_to_space(const float* x, float* y, int n, int c, int h, int w, int scale,
+                      tg_stream_t stream);
+/* CharbonnierLoss (optim/losses.py:31-50): *loss_accum += loss_scale * sum sqrt(d^2+eps),
+ * dx = grad_scale * d / sqrt(d^2+eps)  (d = x - y); loss_accum or dx may be NULL. */
+int tg_charbonnier(const float* x, const float* y, int64_t n, float eps, float loss_scale,
+                   float* loss_accum, float grad_scale, float* dx, tg_stream_t stream);
+/* VanillaGANLoss (optim/losses.py:6-14) against a constant target, plus the statistics
+ * VSRGANModel.train logs (vsrgan_model.py:163-164,194-195):
+ * stats3[0] += scale*sum(bce), [1] += scale*sum(x), [2] += scale*sum(log(sigmoid(x)+1e-8));
+ * dx = grad_scale * (sigmoid(x) - target). */
+int tg_bce_logits(const float* x, int64_t n, float target, float scale, float* stats3,
+                  float grad_scale, float* dx, tg_stream_t stream);
+/* torch.optim.Adam step (vsrgan_model.py:76-87), in place, `step` = 1-based count */
+int tg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int step,
+                 tg_stream_t stream);
+int tg_axpy(float* y, const float* x, float a, int64_t n, tg_stream_t stream);
+/* BatchNorm2d (train mode, batch statistics, running stats updated with the unbiased
+ * variance) + LeakyReLU(slope), tecogan_nets.py:322-340; and its backward. */
+int tg_bn_lrelu_train_fwd(const float* x, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum,
+                          float eps, float slope, float* y, float* save_mean,
+                          float* save_invstd, int n, int c, int hw, tg_stream_t stream);
+int tg_bn_lrelu_train_bwd(const float* x, const float* y, const float* dy,
+                          const float* gamma, const float* save_mean,
+                          const float* save_invstd, float slope, float* dx,
+                          float* dgamma, float* dbeta, int accumulate, float* scratch2c,
+                          int n, int c, int hw, tg_stream_t stream);
+/* nn.Linear(k, 1) (tecogan_nets.py:375): y[r] = x[r,:].w + b, and backward */
+int tg_linear1_fwd(const float* x, const float* w, const float* b, float* y, int rows,
+                   int k, tg_stream_t stream);
+int tg_linear1_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                   float* db, int rows, int k, int accumulate, tg_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Whole-frame plan: one call = FRNet.step (tecogan_nets.py:227-252).  The plan

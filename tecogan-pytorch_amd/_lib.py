@@ -43,6 +43,22 @@ SIGNATURES = {
     'tg_upsample_fwd': (I, [P, P, I, I, I, I, I, F, P]),
     'tg_maxpool2_fwd': (I, [P, P, I, I, I, P]),
     'tg_quantize_u8_hwc': (I, [P, P, I, I, I, P]),
+    'tg_wgrad3x3_workspace_floats': (SZ, [I, I, I, I, I]),
+    'tg_wgrad3x3': (I, [P, I64, P, I64, P, P, I, I, I, I, I, I, I, I, P]),
+    'tg_act_bwd': (I, [P, P, P, I64, I, P]),
+    'tg_bias_grad': (I, [P, P, I, I, I, I, P]),
+    'tg_maxpool2_bwd': (I, [P, P, P, I, I, I, P]),
+    'tg_upsample_bwd': (I, [P, P, I, I, I, I, I, F, P]),
+    'tg_backward_warp_bwd': (I, [P, P, P, P, P, I, I, I, I, P]),
+    'tg_depth_to_space': (I, [P, P, I, I, I, I, I, P]),
+    'tg_charbonnier': (I, [P, P, I64, F, F, P, F, P, P]),
+    'tg_bce_logits': (I, [P, I64, F, F, P, F, P, P]),
+    'tg_adam_step': (I, [P, P, P, P, I64, F, F, F, F, F, I, P]),
+    'tg_axpy': (I, [P, P, F, I64, P]),
+    'tg_bn_lrelu_train_fwd': (I, [P, P, P, P, P, F, F, F, P, P, P, I, I, I, P]),
+    'tg_bn_lrelu_train_bwd': (I, [P, P, P, P, P, P, F, P, P, P, I, P, I, I, I, P]),
+    'tg_linear1_fwd': (I, [P, P, P, P, I, I, P]),
+    'tg_linear1_bwd': (I, [P, P, P, P, P, P, I, I, I, P]),
     'tg_frnet_workspace_floats': (SZ, [C.POINTER(FrnetCfg)]),
     'tg_frnet_plan_create': (I, [C.POINTER(FrnetCfg), C.POINTER(LayerWeights), I, P,
                                  C.POINTER(C.c_void_p)]),

@@ -70,8 +70,9 @@ __global__ void pack3x3_kernel(const float* __restrict__ w, float* __restrict__ 
     int oc = g * ocb + o, ci = ch * CK + 4 * half + j;
     float v = 0.f;
     if (oc < cout && ci < cin) {
-      v = transposed ? w[((size_t)ci * cout + oc) * 9 + tap]
-                     : w[((size_t)oc * cin + ci) * 9 + tap];
+      if (transposed == 2) v = w[((size_t)ci * cout + oc) * 9 + (8 - tap)];   // dgrad: swap + rot180
+      else if (transposed == 1) v = w[((size_t)ci * cout + oc) * 9 + tap];
+      else v = w[((size_t)oc * cin + ci) * 9 + tap];
     }
     out[i] = v;
   }

@@ -1,0 +1,529 @@
+// Training-side element-wise / gather / reduction kernels (gfx950, HBM-bound):
+// activation backward, bias gradient, maxpool / upsample / warp / space-to-depth
+// transposes, BatchNorm (train) forward+backward, Linear(->1), the two loss
+// functions with their gradients, fused Adam, axpy.  The matrix-shaped backward
+// work (conv dgrad / wgrad) lives in tg_conv3x3_mfma.hip / tg_wgrad_mfma.hip.
+//
+// Reference ops replaced (autograd of): LeakyReLU/ReLU/tanh*24
+// (tecogan_nets.py:24-80), MaxPool2d (:28-42), F.interpolate / BicubicUpsampler
+// (net_utils.py:85-156), backward_warp (net_utils.py:50-82), space_to_depth
+// (:36-47), BatchNorm2d (tecogan_nets.py:324-339), Linear (:375), CharbonnierLoss
+// / VanillaGANLoss (optim/losses.py:6-50), optim.Adam (vsrgan_model.py:76-87).
+#include "tg_common.h"
+
+namespace tg {
+
+static inline int grid_for(long long total, int cap = 4096) {
+  long long b = (total + 255) / 256;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+#define TG_GRID_STRIDE(i, total)                                                   \
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total); \
+       i += (long long)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// block-wide sum (256 threads); result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) sm[wv] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sm[i];
+  __syncthreads();
+  return r;
+}
+
+// dx = dy * act'(.) expressed through the OUTPUT y of the activation
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                               float* __restrict__ dx, long long n, int act) {
+  TG_GRID_STRIDE(i, n) {
+    float g = dy[i], o = y[i], r;
+    if (act == TG_ACT_RELU) r = o > 0.f ? g : 0.f;
+    else if (act == TG_ACT_LRELU02) r = o > 0.f ? g : g * 0.2f;
+    else if (act == TG_ACT_TANH24) r = g * (24.f - o * o * (1.f / 24.f));  // 24*(1 - tanh^2)
+    else r = g;
+    dx[i] = r;
+  }
+}
+
+// db[c] (+)= sum over n, h, w of dy[n][c][h][w]; one block per channel
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy,
+                                                        float* __restrict__ db, int n, int c,
+                                                        int hw, int accumulate) {
+  __shared__ float sm[4];
+  int ch = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < n; ++b) {
+    const float* p = dy + ((long long)b * c + ch) * hw;
+    for (int i = threadIdx.x; i < hw; i += 256) s += p[i];
+  }
+  float r = block_sum(s, sm);
+  if (threadIdx.x == 0) db[ch] = accumulate ? db[ch] + r : r;
+}
+
+// gradient of MaxPool2d(2,2) floor mode: goes to the FIRST maximal element of the window
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    float* __restrict__ dx, int nc, int h, int w) {
+  const int oh = h / 2, ow = w / 2;
+  const long long total = (long long)nc * h * w;
+  TG_GRID_STRIDE(i, total) {
+    int xx = (int)(i % w); long long t = i / w;
+    int yy = (int)(t % h); int p = (int)(t / h);
+    int oy = yy / 2, ox = xx / 2;
+    float g = 0.f;
+    if (oy < oh && ox < ow) {
+      const float* s = x + ((long long)p * h + 2 * oy) * w + 2 * ox;
+      float v0 = s[0], v1 = s[1], v2 = s[w], v3 = s[w + 1];
+      int arg = 0; float m = v0;
+      if (v1 > m) { m = v1; arg = 1; }
+      if (v2 > m) { m = v2; arg = 2; }
+      if (v3 > m) { m = v3; arg = 3; }
+      if (arg == (yy - 2 * oy) * 2 + (xx - 2 * ox)) g = dy[((long long)p * oh + oy) * ow + ox];
+    }
+    dx[i] = g;
+  }
+}
+
+// transpose of tg_upsample_fwd: dx (nc,h,w) += scatter of mul * dy (nc, s*h, s*w).  dx pre-zeroed.
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int nc,
+                                    int h, int w, int s, int mode, float mul) {
+  const int oh = h * s, ow = w * s;
+  const long long total = (long long)nc * oh * ow;
+  TG_GRID_STRIDE(i, total) {
+    int ox = (int)(i % ow); long long t = i / ow;
+    int oy = (int)(t % oh); int p = (int)(t / oh);
+    float g = mul * dy[i];
+    float* dst = dx + (long long)p * h * w;
+    if (mode == TG_UP_BICUBIC) {
+      int ii = oy / s, dyy = oy - ii * s, jj = ox / s, dxx = ox - jj * s;
+      float ky[4], kx[4];
+      bicubic_w(dyy, s, ky);
+      bicubic_w(dxx, s, kx);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int cq = jj - 1 + q; cq = cq < 0 ? 0 : (cq > w - 1 ? w - 1 : cq);
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          int rp = ii - 1 + pp; rp = rp < 0 ? 0 : (rp > h - 1 ? h - 1 : rp);
+          float wgt = kx[q] * ky[pp];
+          if (wgt != 0.f) atomicAdd(dst + rp * w + cq, g * wgt);
+        }
+      }
+    } else {
+      int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+      bilinear_src(oy, s, h, y0, y1, ly0, ly1);
+      bilinear_src(ox, s, w, x0, x1, lx0, lx1);
+      atomicAdd(dst + y0 * w + x0, g * ly0 * lx0);
+      atomicAdd(dst + y0 * w + x1, g * ly0 * lx1);
+      atomicAdd(dst + y1 * w + x0, g * ly1 * lx0);
+      atomicAdd(dst + y1 * w + x1, g * ly1 * lx1);
+    }
+  }
+}
+
+// backward of backward_warp: dflow (n,2,h,w) and (optionally) dimg scatter.  dimg pre-zeroed.
+__global__ __launch_bounds__(256) void backward_warp_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ flow, const float* __restrict__ dy,
+    float* __restrict__ dimg, float* __restrict__ dflow, int n, int c, int h, int w) {
+  const int px_ = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int py_ = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (px_ >= w || py_ >= h) return;
+  const long long hw = (long long)h * w;
+  const long long pix = (long long)py_ * w + px_;
+  const float fx = flow[(long long)b * 2 * hw + pix], fy = flow[((long long)b * 2 + 1) * hw + pix];
+  // recompute the forward sampling position, tracking whether the clip was active
+  float halfx = (float)(w - 1) / 2.0f, halfy = (float)(h - 1) / 2.0f;
+  float gx = linspace_m1p1(px_, w, 2.0f / (float)(w - 1)) + fx / halfx;
+  float gy = linspace_m1p1(py_, h, 2.0f / (float)(h - 1)) + fy / halfy;
+  float ux = (gx + 1.0f) * halfx, uy = (gy + 1.0f) * halfy;
+  // clip_coordinates_set_grad: gradient passes only strictly inside (0, size-1)
+  float mx = (ux <= 0.f || ux >= (float)(w - 1)) ? 0.f : 1.f;
+  float my = (uy <= 0.f || uy >= (float)(h - 1)) ? 0.f : 1.f;
+  float sx = ux < 0.f ? 0.f : (ux > (float)(w - 1) ? (float)(w - 1) : ux);
+  float sy = uy < 0.f ? 0.f : (uy > (float)(h - 1) ? (float)(h - 1) : uy);
+  float fx0 = floorf(sx), fy0 = floorf(sy);
+  float wx1 = sx - fx0, wx0 = 1.f - wx1, wy1 = sy - fy0, wy0 = 1.f - wy1;
+  int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+  bool okx1 = x1 <= w - 1, oky1 = y1 <= h - 1;
+  float gsx = 0.f, gsy = 0.f;
+  for (int ch = 0; ch < c; ++ch) {
+    const long long plane = ((long long)b * c + ch) * hw;
+    const float g = dy[plane + pix];
+    const float* img = x + plane;
+    float v00 = img[y0 * w + x0];
+    float v01 = okx1 ? img[y0 * w + x1] : 0.f;
+    float v10 = oky1 ? img[y1 * w + x0] : 0.f;
+    float v11 = (okx1 && oky1) ? img[y1 * w + x1] : 0.f;
+    // d out / d sx, d out / d sy
+    gsx += g * ((v01 - v00) * wy0 + (v11 - v10) * wy1);
+    gsy += g * ((v10 - v00) * wx0 + (v11 - v01) * wx1);
+    if (dimg) {
+      float* d = dimg + plane;
+      atomicAdd(d + y0 * w + x0, g * wy0 * wx0);
+      if (okx1) atomicAdd(d + y0 * w + x1, g * wy0 * wx1);
+      if (oky1) atomicAdd(d + y1 * w + x0, g * wy1 * wx0);
+      if (okx1 && oky1) atomicAdd(d + y1 * w + x1, g * wy1 * wx1);
+    }
+  }
+  if (dflow) {
+    // s = (g + 1) * half, g = lin + f / half  =>  ds/df = 1 (where not clipped)
+    dflow[(long long)b * 2 * hw + pix] = gsx * mx;
+    dflow[((long long)b * 2 + 1) * hw + pix] = gsy * my;
+  }
+}
+
+// inverse of space_to_depth: x (n, s*s*c, h, w) -> y (n, c, s*h, s*w)
+__global__ void depth_to_space_kernel(const float* __restrict__ x, float* __restrict__ y, int n,
+                                      int c, int h, int w, int s) {
+  const int oh = h * s, ow = w * s;
+  const long long total = (long long)n * c * oh * ow;
+  TG_GRID_STRIDE(i, total) {
+    int ox = (int)(i % ow); long long t = i / ow;
+    int oy = (int)(t % oh); t /= oh;
+    int ch = (int)(t % c); int b = (int)(t / c);
+    int sy = oy % s, sx = ox % s;
+    int k = (sy * s + sx) * c + ch;
+    y[i] = x[(((long long)b * s * s * c + k) * h + oy / s) * w + ox / s];
+  }
+}
+
+// Charbonnier: loss += scale * sum sqrt(d^2+eps); dx = gscale * d / sqrt(d^2+eps)
+__global__ __launch_bounds__(256) void charbonnier_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ y,
+                                                          long long n, float eps, float scale,
+                                                          float* __restrict__ loss,
+                                                          float gscale, float* __restrict__ dx) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  TG_GRID_STRIDE(i, n) {
+    float d = x[i] - y[i];
+    float r = sqrtf(d * d + eps);
+    s += r;
+    if (dx) dx[i] = gscale * d / r;
+  }
+  float r = block_sum(s, sm);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, r * scale);
+}
+
+// BCE-with-logits against a constant target t; also mean(x) and mean(log(sigmoid(x)+1e-8))
+// stats[0] += scale*sum(loss), stats[1] += scale*sum(x), stats[2] += scale*sum(log(sig+1e-8))
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, long long n,
+                                                         float target, float scale,
+                                                         float* __restrict__ stats, float gscale,
+                                                         float* __restrict__ dx) {
+  __shared__ float sm[4];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  TG_GRID_STRIDE(i, n) {
+    float v = x[i];
+    float sig = 1.f / (1.f + expf(-v));
+    s0 += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+    s1 += v;
+    s2 += logf(sig + 1e-8f);
+    if (dx) dx[i] = gscale * (sig - target);
+  }
+  float r0 = block_sum(s0, sm), r1 = block_sum(s1, sm), r2 = block_sum(s2, sm);
+  if (threadIdx.x == 0 && stats) {
+    atomicAdd(stats + 0, r0 * scale);
+    atomicAdd(stats + 1, r1 * scale);
+    atomicAdd(stats + 2, r2 * scale);
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                            float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2) {
+  TG_GRID_STRIDE(i, n) {
+    float gi = g[i];
+    if (wd != 0.f) gi += wd * p[i];
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+  }
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a,
+                            long long n) {
+  TG_GRID_STRIDE(i, n) y[i] += a * x[i];
+}
+
+// ---- BatchNorm2d (train) + LeakyReLU(0.2) fused ---------------------------------
+// stats: one block per channel -> mean, invstd (biased var), running stats update
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int n, int c,
+                                                       int hw, float eps, float momentum,
+                                                       float* __restrict__ save_mean,
+                                                       float* __restrict__ save_invstd,
+                                                       float* __restrict__ run_mean,
+                                                       float* __restrict__ run_var) {
+  __shared__ float sm[4];
+  __shared__ float s_mean;
+  int ch = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < n; ++b) {
+    const float* p = x + ((long long)b * c + ch) * hw;
+    for (int i = threadIdx.x; i < hw; i += 256) s += p[i];
+  }
+  float tot = block_sum(s, sm);
+  const float cnt = (float)n * (float)hw;
+  if (threadIdx.x == 0) s_mean = tot / cnt;
+  __syncthreads();
+  const float mean = s_mean;
+  float q = 0.f;
+  for (int b = 0; b < n; ++b) {
+    const float* p = x + ((long long)b * c + ch) * hw;
+    for (int i = threadIdx.x; i < hw; i += 256) { float d = p[i] - mean; q += d * d; }
+  }
+  float sq = block_sum(q, sm);
+  if (threadIdx.x == 0) {
+    float var = sq / cnt;
+    save_mean[ch] = mean;
+    save_invstd[ch] = 1.0f / sqrtf(var + eps);
+    if (run_mean) {
+      run_mean[ch] = (1.f - momentum) * run_mean[ch] + momentum * mean;
+      run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * (var * cnt / (cnt - 1.f));
+    }
+  }
+}
+
+// y = lrelu((x - mean) * invstd * gamma + beta)
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ y,
+                                long long total, int c, int hw, float slope) {
+  TG_GRID_STRIDE(i, total) {
+    int ch = (int)((i / hw) % c);
+    float v = (x[i] - mean[ch]) * invstd[ch] * gamma[ch] + beta[ch];
+    y[i] = v >= 0.f ? v : v * slope;
+  }
+}
+
+// backward of (BN train + lrelu): per-channel reductions then the input gradient.
+//   dz = dy * lrelu'(y);  dbeta = sum dz;  dgamma = sum dz * xhat
+//   dx = gamma*invstd * (dz - dbeta/N - xhat * dgamma/N)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+    const float* __restrict__ mean, const float* __restrict__ invstd, int n, int c, int hw,
+    float slope, float* __restrict__ sum_dz, float* __restrict__ sum_dz_xhat) {
+  __shared__ float sm[4];
+  int ch = blockIdx.x;
+  float a = 0.f, bq = 0.f;
+  const float mu = mean[ch], is = invstd[ch];
+  for (int b = 0; b < n; ++b) {
+    const long long off = ((long long)b * c + ch) * hw;
+    for (int i = threadIdx.x; i < hw; i += 256) {
+      float g = dy[off + i];
+      float dz = y[off + i] > 0.f ? g : g * slope;
+      a += dz;
+      bq += dz * (x[off + i] - mu) * is;
+    }
+  }
+  float r0 = block_sum(a, sm), r1 = block_sum(bq, sm);
+  if (threadIdx.x == 0) { sum_dz[ch] = r0; sum_dz_xhat[ch] = r1; }
+}
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                    const float* __restrict__ dy, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma,
+                                    const float* __restrict__ sum_dz,
+                                    const float* __restrict__ sum_dz_xhat, float* __restrict__ dx,
+                                    long long total, int c, int hw, float slope, float inv_cnt) {
+  TG_GRID_STRIDE(i, total) {
+    int ch = (int)((i / hw) % c);
+    float g = dy[i];
+    float dz = y[i] > 0.f ? g : g * slope;
+    float xhat = (x[i] - mean[ch]) * invstd[ch];
+    dx[i] = gamma[ch] * invstd[ch] * (dz - sum_dz[ch] * inv_cnt - xhat * sum_dz_xhat[ch] * inv_cnt);
+  }
+}
+
+// Linear(K -> 1): y[r] = dot(x[r,:], w) + b ; one block per row
+__global__ __launch_bounds__(256) void linear1_fwd_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ b,
+                                                          float* __restrict__ y, int k) {
+  __shared__ float sm[4];
+  const float* xr = x + (long long)blockIdx.x * k;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < k; i += 256) s += xr[i] * w[i];
+  float r = block_sum(s, sm);
+  if (threadIdx.x == 0) y[blockIdx.x] = r + (b ? b[0] : 0.f);
+}
+// dx[r,:] = dy[r] * w ; dw (+)= sum_r dy[r] * x[r,:] ; db (+)= sum_r dy[r]
+__global__ void linear1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                   const float* __restrict__ dy, float* __restrict__ dx,
+                                   float* __restrict__ dw, float* __restrict__ db, int rows, int k,
+                                   int accumulate) {
+  TG_GRID_STRIDE(i, k) {
+    float acc = 0.f;
+    float wi = w[i];
+    for (int r = 0; r < rows; ++r) {
+      float g = dy[r];
+      if (dx) dx[(long long)r * k + i] = g * wi;
+      acc += g * x[(long long)r * k + i];
+    }
+    if (dw) dw[i] = accumulate ? dw[i] + acc : acc;
+    if (i == 0 && db) {
+      float s = 0.f;
+      for (int r = 0; r < rows; ++r) s += dy[r];
+      db[0] = accumulate ? db[0] + s : s;
+    }
+  }
+}
+
+}  // namespace tg
+
+using namespace tg;
+#define ST ((hipStream_t)stream)
+
+extern "C" int tg_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act,
+                          tg_stream_t stream) {
+  TG_REQUIRE(dy && y && dx && n > 0, TG_E_ARG, "act_bwd: bad argument");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST, dy, y, dx, (long long)n, act);
+  return check_launch("act_bwd");
+}
+
+extern "C" int tg_bias_grad(const float* dy, float* db, int n, int c, int hw, int accumulate,
+                            tg_stream_t stream) {
+  TG_REQUIRE(dy && db && n > 0 && c > 0 && hw > 0, TG_E_ARG, "bias_grad: bad argument");
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(c), dim3(256), 0, ST, dy, db, n, c, hw, accumulate);
+  return check_launch("bias_grad");
+}
+
+extern "C" int tg_maxpool2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w,
+                               tg_stream_t stream) {
+  TG_REQUIRE(x && dy && dx && nc > 0 && h >= 2 && w >= 2, TG_E_ARG, "maxpool2_bwd: bad argument");
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for((long long)nc * h * w)), dim3(256), 0, ST, x,
+                     dy, dx, nc, h, w);
+  return check_launch("maxpool2_bwd");
+}
+
+extern "C" int tg_upsample_bwd(const float* dy, float* dx, int nc, int h, int w, int scale,
+                               int up_mode, float mul, tg_stream_t stream) {
+  TG_REQUIRE(dy && dx && nc > 0 && h > 0 && w > 0 && scale >= 1, TG_E_ARG, "upsample_bwd: bad argument");
+  TG_REQUIRE(up_mode == TG_UP_BICUBIC || up_mode == TG_UP_BILINEAR, TG_E_ARG, "upsample_bwd: mode");
+  hipError_t e = hipMemsetAsync(dx, 0, (size_t)nc * h * w * sizeof(float), ST);
+  TG_REQUIRE(e == hipSuccess, TG_E_HIP, "upsample_bwd: memset: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((long long)nc * h * scale * w * scale, 8192)),
+                     dim3(256), 0, ST, dy, dx, nc, h, w, scale, up_mode, mul);
+  return check_launch("upsample_bwd");
+}
+
+extern "C" int tg_backward_warp_bwd(const float* x, const float* flow, const float* dy, float* dimg,
+                                    float* dflow, int n, int c, int h, int w, tg_stream_t stream) {
+  TG_REQUIRE(x && flow && dy && (dimg || dflow), TG_E_ARG, "backward_warp_bwd: null pointer");
+  TG_REQUIRE(n > 0 && c > 0 && h >= 2 && w >= 2, TG_E_SHAPE, "backward_warp_bwd: shape");
+  if (dimg) {
+    hipError_t e = hipMemsetAsync(dimg, 0, (size_t)n * c * h * w * sizeof(float), ST);
+    TG_REQUIRE(e == hipSuccess, TG_E_HIP, "backward_warp_bwd: memset: %s", hipGetErrorString(e));
+  }
+  dim3 g(cdiv(w, 64), cdiv(h, 4), n), t(256);
+  hipLaunchKernelGGL(backward_warp_bwd_kernel, g, t, 0, ST, x, flow, dy, dimg, dflow, n, c, h, w);
+  return check_launch("backward_warp_bwd");
+}
+
+extern "C" int tg_depth_to_space(const float* x, float* y, int n, int c, int h, int w, int scale,
+                                 tg_stream_t stream) {
+  TG_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0 && scale >= 1, TG_E_ARG, "depth_to_space");
+  long long total = (long long)n * c * h * scale * w * scale;
+  hipLaunchKernelGGL(depth_to_space_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, ST, x, y, n, c,
+                     h, w, scale);
+  return check_launch("depth_to_space");
+}
+
+extern "C" int tg_charbonnier(const float* x, const float* y, int64_t n, float eps, float loss_scale,
+                              float* loss_accum, float grad_scale, float* dx, tg_stream_t stream) {
+  TG_REQUIRE(x && y && n > 0 && (loss_accum || dx), TG_E_ARG, "charbonnier: bad argument");
+  hipLaunchKernelGGL(charbonnier_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, x, y,
+                     (long long)n, eps, loss_scale, loss_accum, grad_scale, dx);
+  return check_launch("charbonnier");
+}
+
+extern "C" int tg_bce_logits(const float* x, int64_t n, float target, float scale, float* stats3,
+                             float grad_scale, float* dx, tg_stream_t stream) {
+  TG_REQUIRE(x && n > 0 && (stats3 || dx), TG_E_ARG, "bce_logits: bad argument");
+  hipLaunchKernelGGL(bce_logits_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST, x, (long long)n,
+                     target, scale, stats3, grad_scale, dx);
+  return check_launch("bce_logits");
+}
+
+extern "C" int tg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int step,
+                            tg_stream_t stream) {
+  TG_REQUIRE(p && g && m && v && n > 0 && step >= 1, TG_E_ARG, "adam_step: bad argument");
+  float bc1 = 1.f - powf(beta1, (float)step);
+  float sbc2 = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, g, m, v, (long long)n, lr,
+                     beta1, beta2, eps, weight_decay, bc1, sbc2);
+  return check_launch("adam_step");
+}
+
+extern "C" int tg_axpy(float* y, const float* x, float a, int64_t n, tg_stream_t stream) {
+  TG_REQUIRE(y && x && n > 0, TG_E_ARG, "axpy: bad argument");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, ST, y, x, a, (long long)n);
+  return check_launch("axpy");
+}
+
+extern "C" int tg_bn_lrelu_train_fwd(const float* x, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float momentum,
+                                     float eps, float slope, float* y, float* save_mean,
+                                     float* save_invstd, int n, int c, int hw, tg_stream_t stream) {
+  TG_REQUIRE(x && gamma && beta && y && save_mean && save_invstd, TG_E_ARG, "bn_fwd: null pointer");
+  TG_REQUIRE(n > 0 && c > 0 && hw > 0 && (long long)n * hw > 1, TG_E_SHAPE, "bn_fwd: shape");
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(c), dim3(256), 0, ST, x, n, c, hw, eps, momentum, save_mean,
+                     save_invstd, running_mean, running_var);
+  long long total = (long long)n * c * hw;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, ST, x, save_mean,
+                     save_invstd, gamma, beta, y, total, c, hw, slope);
+  return check_launch("bn_lrelu_train_fwd");
+}
+
+extern "C" int tg_bn_lrelu_train_bwd(const float* x, const float* y, const float* dy,
+                                     const float* gamma, const float* save_mean,
+                                     const float* save_invstd, float slope, float* dx,
+                                     float* dgamma, float* dbeta, int accumulate, float* scratch2c,
+                                     int n, int c, int hw, tg_stream_t stream) {
+  TG_REQUIRE(x && y && dy && gamma && save_mean && save_invstd && scratch2c, TG_E_ARG,
+             "bn_bwd: null pointer");
+  float* s0 = scratch2c;
+  float* s1 = scratch2c + c;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(c), dim3(256), 0, ST, x, y, dy, save_mean, save_invstd,
+                     n, c, hw, slope, s0, s1);
+  long long total = (long long)n * c * hw;
+  if (dx)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, ST, x, y, dy, save_mean,
+                       save_invstd, gamma, s0, s1, dx, total, c, hw, slope,
+                       1.0f / ((float)n * (float)hw));
+  if (dgamma) {
+    if (accumulate) {
+      hipLaunchKernelGGL(axpy_kernel, dim3(1), dim3(256), 0, ST, dgamma, (const float*)s1, 1.0f, (long long)c);
+      hipLaunchKernelGGL(axpy_kernel, dim3(1), dim3(256), 0, ST, dbeta, (const float*)s0, 1.0f, (long long)c);
+    } else {
+      hipMemcpyAsync(dgamma, s1, c * sizeof(float), hipMemcpyDeviceToDevice, ST);
+      hipMemcpyAsync(dbeta, s0, c * sizeof(float), hipMemcpyDeviceToDevice, ST);
+    }
+  }
+  return check_launch("bn_lrelu_train_bwd");
+}
+
+extern "C" int tg_linear1_fwd(const float* x, const float* w, const float* b, float* y, int rows,
+                              int k, tg_stream_t stream) {
+  TG_REQUIRE(x && w && y && rows > 0 && k > 0, TG_E_ARG, "linear1_fwd: bad argument");
+  hipLaunchKernelGGL(linear1_fwd_kernel, dim3(rows), dim3(256), 0, ST, x, w, b, y, k);
+  return check_launch("linear1_fwd");
+}
+
+extern "C" int tg_linear1_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                              float* db, int rows, int k, int accumulate, tg_stream_t stream) {
+  TG_REQUIRE(x && w && dy && rows > 0 && k > 0, TG_E_ARG, "linear1_bwd: bad argument");
+  hipLaunchKernelGGL(linear1_bwd_kernel, dim3(grid_for(k)), dim3(256), 0, ST, x, w, dy, dx, dw, db, rows,
+                     k, accumulate);
+  return check_launch("linear1_bwd");
+}

@@ -1,0 +1,246 @@
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution on fp32 MFMA (gfx950):
+//
+//   G[a][b][tap] = sum_{n,y,x}  P[n][a][y][x] * Q[n][b][y+ky-1][x+kx-1]      (zero padded)
+//
+// With P = dZ (gradient w.r.t. the conv's pre-activation, `a` = cout) and Q = X
+// (the conv's input, `b` = cin) this is dW of nn.Conv2d(cin,cout,3,1,1)
+// (tecogan_nets.py:23-65,92-98,111-113).  The transposed convs and the
+// discriminator's 4x4/s2 convs reach the same kernel through their
+// space-to-depth embedding (see models/train_ops.py).
+//
+// GEMM view: M = a (32 per wave), N = b (32 per wave), K = pixels.  A lane
+// holds channel (lane&31); the K order is permuted as in the forward kernel so
+// a lane's four k-steps are four CONSECUTIVE pixels of a row: the A operand is
+// one ds_read_b128 from a planar [channel][pixel] LDS tile -- NCHW rows are
+// staged as they are.  The 9 taps of a pixel group share 18 shifted B values
+// (3 rows x 6 columns), so per 36 MFMAs a wave issues 1 b128 + 18 b32 LDS reads.
+// Each wave keeps 9 tap accumulators (32x32 each); a workgroup = 2x2 waves
+// covers a 64x64 channel block.  Workgroups stride over the pixel tiles
+// (K split) and write raw partial sums; wgrad_reduce_kernel adds the splits in
+// a fixed order (deterministic) and accumulates into the gradient tensor.
+#include "tg_common.h"
+
+namespace tg {
+
+constexpr int WG_R = 2;                 // rows per pixel tile
+constexpr int WG_TW = 32;               // cols per pixel tile
+constexpr int WG_CSA = WG_R * WG_TW + 4;         // 68: A channel stride (floats), 17 slots (odd)
+constexpr int WG_RSB = WG_TW + 3;                // 35: B row stride
+constexpr int WG_CSB = (WG_R + 2) * WG_RSB + 1;  // 141: B channel stride (odd -> conflict free)
+constexpr int WG_A_FLOATS = 64 * WG_CSA;
+constexpr int WG_B_FLOATS = 64 * WG_CSB;
+constexpr unsigned WG_OOB = 0x80000000u;
+
+struct WgradArgs {
+  const float* p;   // (n, ca, h, w)  unshifted operand (dZ)
+  const float* q;   // (n, cb, h, w)  shifted operand (X)
+  float* part;      // [nsplit][ca][cb_total][9] raw partial sums
+  long long p_ns, q_ns;
+  int ca, cb, cb_total, cb_off;   // G is written at columns [cb_off, cb_off+cb) of a cb_total-wide matrix
+  int n, h, w;
+  int tiles_x, tiles_y, ntiles, nsplit, nab, nbb;
+};
+
+__global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                          // [2][WG_A_FLOATS]
+  float* sB = smem + 2 * WG_A_FLOATS;        // [2][WG_B_FLOATS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cot = wave & 1, cit = wave >> 1;
+  int b = blockIdx.x;
+  const int split = b % a.nsplit; b /= a.nsplit;
+  const int bb = b % a.nbb;
+  const int ab = b / a.nbb;
+  const int a0 = ab * 64, b0 = bb * 64;
+  const int hw = a.h * a.w;
+  const unsigned plane = (unsigned)hw * 4u;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int lh = lane >> 5, ll = lane & 31;
+  const int a_rd = (cot * 32 + ll) * WG_CSA + 4 * lh;
+  const int b_rd = (cit * 32 + ll) * WG_CSB + 4 * lh;
+
+  constexpr int A_PER_T = (64 * WG_R * WG_TW) / 256;                 // 16
+  constexpr int B_ELEMS = 64 * (WG_R + 2) * (WG_TW + 2);            // 8704
+  constexpr int B_PER_T = B_ELEMS / 256;                             // 34
+  float ra[A_PER_T], rb[B_PER_T];
+
+  auto load_tile = [&](int tile) {
+    int n = tile / (a.tiles_x * a.tiles_y);
+    int rem = tile - n * (a.tiles_x * a.tiles_y);
+    int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    int x0 = tx * WG_TW, y0 = ty * WG_R;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.p + (long long)n * a.p_ns), 0, a.ca * hw * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.q + (long long)n * a.q_ns), 0, a.cb * hw * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      int idx = tid + i * 256;
+      int c = idx >> 6, r = (idx >> 5) & 1, col = idx & 31;
+      int gy = y0 + r, gx = x0 + col;
+      bool ok = gy < a.h && gx < a.w;      // channel tail handled by num_records
+      unsigned off = ok ? ((unsigned)(a0 + c) * plane + (unsigned)(gy * a.w + gx) * 4u) : WG_OOB;
+      ra[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)off, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      int idx = tid + i * 256;
+      int c = idx / ((WG_R + 2) * (WG_TW + 2));
+      int rem2 = idx - c * ((WG_R + 2) * (WG_TW + 2));
+      int r = rem2 / (WG_TW + 2), col = rem2 - r * (WG_TW + 2);
+      int gy = y0 - 1 + r, gx = x0 - 1 + col;
+      bool ok = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      unsigned off = ok ? ((unsigned)(b0 + c) * plane + (unsigned)(gy * a.w + gx) * 4u) : WG_OOB;
+      rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, (int)off, 0, 0));
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* pa = sA + buf * WG_A_FLOATS;
+    float* pb = sB + buf * WG_B_FLOATS;
+#pragma unroll
+    for (int i = 0; i < A_PER_T; ++i) {
+      int idx = tid + i * 256;
+      int c = idx >> 6, rc = idx & 63;
+      pa[c * WG_CSA + rc] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER_T; ++i) {
+      int idx = tid + i * 256;
+      int c = idx / ((WG_R + 2) * (WG_TW + 2));
+      int rem2 = idx - c * ((WG_R + 2) * (WG_TW + 2));
+      int r = rem2 / (WG_TW + 2), col = rem2 - r * (WG_TW + 2);
+      pb[c * WG_CSB + r * WG_RSB + col] = rb[i];
+    }
+  };
+
+  int tile = split;
+  int it = 0;
+  if (tile < a.ntiles) {
+    load_tile(tile);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (; tile < a.ntiles; tile += a.nsplit, ++it) {
+    const int buf = it & 1;
+    const bool more = tile + a.nsplit < a.ntiles;
+    if (more) load_tile(tile + a.nsplit);
+    const float* pa = sA + buf * WG_A_FLOATS + a_rd;
+    const float* pb = sB + buf * WG_B_FLOATS + b_rd;
+#pragma unroll
+    for (int r = 0; r < WG_R; ++r) {
+#pragma unroll
+      for (int g = 0; g < WG_TW / 8; ++g) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(pa + r * WG_TW + 8 * g);
+        float bv[3][6];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int c6 = 0; c6 < 6; ++c6) bv[ky][c6] = pb[(r + ky) * WG_RSB + 8 * g + c6];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+              acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[ky][kk + kx],
+                                                                      acc[ky * 3 + kx], 0, 0, 0);
+      }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // D[i = a-channel][j = b-channel]: lane holds j = ll, registers walk i
+  float* out = a.part + (long long)split * a.ca * a.cb_total * 9;
+  const int bj = b0 + cit * 32 + ll;
+  if (bj < a.cb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int ai = a0 + cot * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ai < a.ca) {
+        float* o = out + ((long long)ai * a.cb_total + a.cb_off + bj) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o[t] = acc[t][r];
+      }
+    }
+  }
+}
+
+// g[e] = (accumulate ? g[e] : 0) + sum_s part[s][e]  over the written column range
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ g,
+                                    int nsplit, int ca, int cb, int cb_total, int cb_off,
+                                    int accumulate) {
+  const long long stride = (long long)ca * cb_total * 9;
+  const long long total = (long long)ca * cb * 9;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int t = (int)(i % 9); long long r = i / 9;
+    int bj = (int)(r % cb); int ai = (int)(r / cb);
+    long long e = ((long long)ai * cb_total + cb_off + bj) * 9 + t;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[k * stride + e];
+    g[e] = accumulate ? g[e] + s : s;
+  }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+static int wgrad_nsplit(int n, int h, int w, int ca, int cb) {
+  int ntiles = n * cdiv(h, WG_R) * cdiv(w, WG_TW);
+  int blocks_ch = cdiv(ca, 64) * cdiv(cb, 64);
+  int s = 512 / blocks_ch;
+  if (s < 1) s = 1;
+  if (s > ntiles) s = ntiles;
+  if (s > 256) s = 256;
+  return s;
+}
+
+extern "C" size_t tg_wgrad3x3_workspace_floats(int n, int ca, int cb_total, int h, int w) {
+  if (n <= 0 || ca <= 0 || cb_total <= 0 || h <= 0 || w <= 0) return 0;
+  return (size_t)wgrad_nsplit(n, h, w, ca, cb_total) * ca * cb_total * 9;
+}
+
+extern "C" int tg_wgrad3x3(const float* p, int64_t p_nstride, const float* q, int64_t q_nstride,
+                           float* grad, float* workspace, int n, int ca, int cb, int cb_total,
+                           int cb_off, int h, int w, int accumulate, tg_stream_t stream) {
+  TG_REQUIRE(p && q && grad && workspace, TG_E_ARG, "wgrad3x3: null pointer");
+  TG_REQUIRE(n > 0 && ca > 0 && cb > 0 && h > 0 && w > 0 && cb_off >= 0 && cb_off + cb <= cb_total,
+             TG_E_SHAPE, "wgrad3x3: n=%d ca=%d cb=%d (+%d of %d) h=%d w=%d", n, ca, cb, cb_off,
+             cb_total, h, w);
+  TG_REQUIRE((long long)(ca > cb ? ca : cb) * h * w * 4 < (1ll << 31), TG_E_SHAPE,
+             "wgrad3x3: one batch item must be < 2 GiB");
+  WgradArgs a{};
+  a.p = p; a.q = q; a.part = workspace; a.p_ns = p_nstride; a.q_ns = q_nstride;
+  a.ca = ca; a.cb = cb; a.cb_total = cb_total; a.cb_off = cb_off; a.n = n; a.h = h; a.w = w;
+  a.tiles_x = cdiv(w, WG_TW); a.tiles_y = cdiv(h, WG_R);
+  a.ntiles = n * a.tiles_x * a.tiles_y;
+  a.nab = cdiv(ca, 64); a.nbb = cdiv(cb, 64);
+  a.nsplit = wgrad_nsplit(n, h, w, ca, cb_total);   // same value the workspace was sized with
+  size_t lds = 2 * (size_t)(WG_A_FLOATS + WG_B_FLOATS) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_mfma_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  unsigned blocks = (unsigned)(a.nab * a.nbb * a.nsplit);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad3x3_mfma_kernel, dim3(blocks), dim3(256), lds, s, a);
+  int rc = check_launch("wgrad3x3_mfma");
+  if (rc != TG_OK) return rc;
+  long long total = (long long)ca * cb * 9;
+  int rb = (int)((total + 255) / 256);
+  if (rb > 2048) rb = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, workspace, grad, a.nsplit, ca, cb,
+                     cb_total, cb_off, accumulate);
+  return check_launch("wgrad_reduce");
+}

@@ -187,3 +187,178 @@ def quantize_u8_hwc(x):
     L.check(L.lib().tg_quantize_u8_hwc(x.data_ptr(), out.data_ptr(), c, h, w, _stream()),
             'tg_quantize_u8_hwc')
     return out
+
+
+# ---------------------------------------------------------------------------
+# training-side wrappers (backward kernels, losses, optimiser)
+# ---------------------------------------------------------------------------
+def pack_conv3x3_dgrad(weight, ocb=None):
+    """Pack a Conv2d weight (cout,cin,3,3) for its DATA gradient: a conv3x3 op
+    mapping cout -> cin with 180-degree rotated taps.  Returns (packed, op_cin, op_cout, ocb)."""
+    w = _chk(weight.detach().contiguous(), 'weight')
+    cout, cin = w.shape[0], w.shape[1]
+    ocb = ocb or pick_ocb(cin)
+    nfl = L.lib().tg_conv3x3_packed_floats(cout, cin, ocb)
+    out = torch.empty(nfl, dtype=torch.float32, device=w.device)
+    L.check(L.lib().tg_conv3x3_pack(w.data_ptr(), out.data_ptr(), cout, cin, ocb, 2, _stream()),
+            'tg_conv3x3_pack(dgrad)')
+    return out, cout, cin, ocb
+
+
+_WGRAD_WS = {}
+
+
+def _wgrad_workspace(device, nfloats):
+    key = str(device)
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < nfloats:
+        ws = torch.empty(int(nfloats), dtype=torch.float32, device=device)
+        _WGRAD_WS[key] = ws
+    return ws
+
+
+def wgrad3x3(p, q, grad, cb_off=0, accumulate=True):
+    """grad[a, cb_off:cb_off+cb, ky, kx] (+)= sum p[n,a,y,x] * q[n,b,y+ky-1,x+kx-1]."""
+    _chk(p, 'p'); _chk(q, 'q'); _chk(grad, 'grad')
+    n, ca, h, w = p.shape
+    cb = q.shape[1]
+    cb_total = grad.shape[1]
+    if q.shape[0] != n or q.shape[2:] != p.shape[2:] or grad.shape[0] != ca or grad.shape[2:] != (3, 3):
+        raise L.TecoganHipError(f'wgrad3x3: p {tuple(p.shape)} q {tuple(q.shape)} grad {tuple(grad.shape)}')
+    nfl = L.lib().tg_wgrad3x3_workspace_floats(n, ca, cb_total, h, w)
+    ws = _wgrad_workspace(p.device, nfl)
+    L.check(L.lib().tg_wgrad3x3(p.data_ptr(), ca * h * w, q.data_ptr(), cb * h * w, grad.data_ptr(),
+                                ws.data_ptr(), n, ca, cb, cb_total, cb_off, h, w,
+                                1 if accumulate else 0, _stream()), 'tg_wgrad3x3')
+    return grad
+
+
+def act_bwd(dy, y, act, out=None):
+    _chk(dy, 'dy'); _chk(y, 'y')
+    if out is None:
+        out = torch.empty_like(dy)
+    L.check(L.lib().tg_act_bwd(dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), act,
+                               _stream()), 'tg_act_bwd')
+    return out
+
+
+def bias_grad(dy, db, accumulate=True):
+    _chk(dy, 'dy'); _chk(db, 'db')
+    n, c = dy.shape[:2]
+    hw = dy.numel() // (n * c)
+    L.check(L.lib().tg_bias_grad(dy.data_ptr(), db.data_ptr(), n, c, hw, 1 if accumulate else 0,
+                                 _stream()), 'tg_bias_grad')
+    return db
+
+
+def maxpool2_bwd(x, dy):
+    _chk(x, 'x'); _chk(dy, 'dy')
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    L.check(L.lib().tg_maxpool2_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), n * c, h, w,
+                                    _stream()), 'tg_maxpool2_bwd')
+    return dx
+
+
+def upsample_bwd(dy, scale, up_mode, mul=1.0):
+    _chk(dy, 'dy')
+    n, c, oh, ow = dy.shape
+    h, w = oh // scale, ow // scale
+    dx = torch.empty(n, c, h, w, dtype=torch.float32, device=dy.device)
+    L.check(L.lib().tg_upsample_bwd(dy.data_ptr(), dx.data_ptr(), n * c, h, w, scale, up_mode,
+                                    float(mul), _stream()), 'tg_upsample_bwd')
+    return dx
+
+
+def backward_warp_bwd(x, flow, dy, need_img=True, need_flow=True):
+    _chk(x, 'x'); _chk(flow, 'flow'); _chk(dy, 'dy')
+    n, c, h, w = x.shape
+    dimg = torch.empty_like(x) if need_img else None
+    dflow = torch.empty_like(flow) if need_flow else None
+    L.check(L.lib().tg_backward_warp_bwd(x.data_ptr(), flow.data_ptr(), dy.data_ptr(), _ptr(dimg),
+                                         _ptr(dflow), n, c, h, w, _stream()), 'tg_backward_warp_bwd')
+    return dimg, dflow
+
+
+def depth_to_space(x, scale):
+    _chk(x, 'x')
+    n, cs, h, w = x.shape
+    c = cs // (scale * scale)
+    y = torch.empty(n, c, h * scale, w * scale, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_depth_to_space(x.data_ptr(), y.data_ptr(), n, c, h, w, scale, _stream()),
+            'tg_depth_to_space')
+    return y
+
+
+def charbonnier(x, y, loss_accum, loss_scale, grad_scale=None, eps=1e-6):
+    """loss_accum[0] += loss_scale * sum sqrt((x-y)^2+eps); returns d loss / dx (scaled) or None."""
+    _chk(x, 'x'); _chk(y, 'y')
+    dx = torch.empty_like(x) if grad_scale is not None else None
+    L.check(L.lib().tg_charbonnier(x.data_ptr(), y.data_ptr(), x.numel(), float(eps),
+                                   float(loss_scale), _ptr(loss_accum),
+                                   float(grad_scale or 0.0), _ptr(dx), _stream()), 'tg_charbonnier')
+    return dx
+
+
+def bce_logits(x, target, stats3, scale, grad_scale=None):
+    _chk(x, 'x')
+    dx = torch.empty_like(x) if grad_scale is not None else None
+    L.check(L.lib().tg_bce_logits(x.data_ptr(), x.numel(), float(target), float(scale),
+                                  _ptr(stats3), float(grad_scale or 0.0), _ptr(dx), _stream()),
+            'tg_bce_logits')
+    return dx
+
+
+def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step):
+    L.check(L.lib().tg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                 float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                 float(weight_decay), int(step), _stream()), 'tg_adam_step')
+
+
+def axpy_(y, x, a=1.0):
+    _chk(y, 'y'); _chk(x, 'x')
+    L.check(L.lib().tg_axpy(y.data_ptr(), x.data_ptr(), float(a), y.numel(), _stream()), 'tg_axpy')
+    return y
+
+
+def bn_lrelu_train_fwd(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, slope=0.2):
+    _chk(x, 'x')
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_bn_lrelu_train_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                          _ptr(running_mean), _ptr(running_var), float(momentum),
+                                          float(eps), float(slope), y.data_ptr(), mean.data_ptr(),
+                                          invstd.data_ptr(), n, c, h * w, _stream()),
+            'tg_bn_lrelu_train_fwd')
+    return y, mean, invstd
+
+
+def bn_lrelu_train_bwd(x, y, dy, gamma, mean, invstd, dgamma=None, dbeta=None, need_dx=True,
+                       slope=0.2):
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    scratch = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_bn_lrelu_train_bwd(x.data_ptr(), y.data_ptr(), dy.data_ptr(), gamma.data_ptr(),
+                                          mean.data_ptr(), invstd.data_ptr(), float(slope), _ptr(dx),
+                                          _ptr(dgamma), _ptr(dbeta), 1, scratch.data_ptr(), n, c,
+                                          h * w, _stream()), 'tg_bn_lrelu_train_bwd')
+    return dx
+
+
+def linear1_fwd(x, w, b):
+    _chk(x, 'x')
+    rows, k = x.shape
+    y = torch.empty(rows, 1, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_linear1_fwd(x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), rows, k,
+                                   _stream()), 'tg_linear1_fwd')
+    return y
+
+
+def linear1_bwd(x, w, dy, dw=None, db=None, need_dx=True):
+    rows, k = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    L.check(L.lib().tg_linear1_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _ptr(dx), _ptr(dw),
+                                   _ptr(db), rows, k, 1, _stream()), 'tg_linear1_bwd')
+    return dx

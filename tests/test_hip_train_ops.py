@@ -1,0 +1,194 @@
+"""GPU parity of the training-side kernels against autograd of the CPU oracle /
+torch fp32 reference ops (the gradient oracle).  Tolerances: 1e-5 relative to
+the gradient's own scale unless stated (different summation order only)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import tecogan_oracle as O
+
+T = torch.from_numpy
+
+
+def rs(seed, shape, lo=-1.0, hi=1.0):
+    return T(np.random.RandomState(seed).uniform(lo, hi, shape).astype(np.float32))
+
+
+def dev(x):
+    return x.cuda().contiguous()
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import tecogan_pytorch_amd.ops as ops_
+    return ops_
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w', [(2, 64, 64, 16, 40), (1, 51, 64, 9, 33), (1, 6, 32, 12, 20),
+                                            (2, 3, 64, 10, 34), (1, 128, 256, 5, 9), (1, 64, 3, 20, 36)])
+def test_conv3x3_dgrad_and_wgrad(ops, n, cin, cout, h, w):
+    x = rs(1, (n, cin, h, w)).requires_grad_(True)
+    wt = (rs(2, (cout, cin, 3, 3)) / (3.0 * cin ** 0.5)).requires_grad_(True)
+    dz = rs(3, (n, cout, h, w))
+    F.conv2d(x, wt, None, padding=1).backward(dz)
+    # data gradient = forward kernel on rot180/transposed weights
+    pk, op_cin, op_cout, ocb = ops.pack_conv3x3_dgrad(dev(wt.detach()))
+    assert (op_cin, op_cout) == (cout, cin)
+    dx = ops.conv3x3(dev(dz), pk, None, cout, cin, ocb, ksplit=1)
+    assert relerr(dx, x.grad) <= 1e-5
+    # weight gradient
+    g = torch.zeros(cout, cin, 3, 3, device='cuda')
+    ops.wgrad3x3(dev(dz), dev(x.detach()), g, accumulate=False)
+    assert relerr(g, wt.grad) <= 2e-5, relerr(g, wt.grad)
+    ops.wgrad3x3(dev(dz), dev(x.detach()), g, accumulate=True)          # accumulate doubles
+    assert relerr(g, 2 * wt.grad) <= 2e-5
+
+
+def test_wgrad_two_sources(ops):
+    """cat[x1(3ch), x2(48ch)] input: two calls into column ranges of one gradient."""
+    x = rs(1, (2, 51, 16, 24)).requires_grad_(True)
+    wt = (rs(2, (64, 51, 3, 3)) / 20).requires_grad_(True)
+    dz = rs(3, (2, 64, 16, 24))
+    F.conv2d(x, wt, None, padding=1).backward(dz)
+    g = torch.zeros(64, 51, 3, 3, device='cuda')
+    xd = x.detach()
+    ops.wgrad3x3(dev(dz), dev(xd[:, :3]), g, cb_off=0, accumulate=False)
+    ops.wgrad3x3(dev(dz), dev(xd[:, 3:]), g, cb_off=3, accumulate=False)
+    assert relerr(g, wt.grad) <= 2e-5
+
+
+@pytest.mark.parametrize('act', [1, 2, 3])
+def test_act_bwd(ops, act):
+    z = rs(1, (3, 5, 7, 9), -2, 2).requires_grad_(True)
+    y = {1: torch.relu(z), 2: F.leaky_relu(z, 0.2), 3: torch.tanh(z) * 24}[act]
+    dy = rs(2, (3, 5, 7, 9))
+    y.backward(dy)
+    out = ops.act_bwd(dev(dy), dev(y.detach()), act)
+    assert relerr(out, z.grad) <= (2e-5 if act == 3 else 1e-7)
+
+
+def test_bias_grad_maxpool_bwd(ops):
+    dy = rs(1, (3, 7, 10, 11))
+    db = torch.zeros(7, device='cuda')
+    ops.bias_grad(dev(dy), db, accumulate=False)
+    assert relerr(db, dy.sum((0, 2, 3))) <= 1e-6
+    x = rs(2, (2, 5, 9, 13)).requires_grad_(True)
+    g = rs(3, (2, 5, 4, 6))
+    F.max_pool2d(x, 2, 2).backward(g)
+    assert torch.equal(ops.maxpool2_bwd(dev(x.detach()), dev(g)).cpu(), x.grad)
+
+
+@pytest.mark.parametrize('deg,s', [('BD', 4), ('BI', 2), ('BD', 2), ('BI', 4)])
+def test_upsample_bwd(ops, deg, s):
+    x = rs(1, (2, 3, 9, 13)).requires_grad_(True)
+    g = rs(2, (2, 3, 9 * s, 13 * s))
+    (float(s) * O.upsample(x, s, deg)).backward(g)
+    out = ops.upsample_bwd(dev(g), s, ops.UP_MODE[deg], mul=float(s))
+    assert relerr(out, x.grad) <= 1e-5
+
+
+@pytest.mark.parametrize('scale_flow', [3.0, 40.0])
+def test_backward_warp_bwd(ops, scale_flow):
+    """autograd of the oracle's backward_warp == grid_sample's backward."""
+    x = rs(1, (2, 3, 17, 23), 0, 1).requires_grad_(True)
+    fl = (rs(2, (2, 2, 17, 23)) * scale_flow).requires_grad_(True)
+    g = rs(3, (2, 3, 17, 23))
+    O.backward_warp(x, fl).backward(g)
+    dimg, dflow = ops.backward_warp_bwd(dev(x.detach()), dev(fl.detach()), dev(g))
+    assert relerr(dimg, x.grad) <= 2e-5
+    # flow gradient: positions that sit within 1e-4 px of an integer differ (kink of the
+    # bilinear kernel); compare away from kinks
+    ref = fl.grad.detach().clone()
+    d = (dflow.cpu() - ref).abs()
+    assert (d > 1e-3 * ref.abs().max()).float().mean() < 2e-3
+
+
+def test_warp_bwd_matches_torch_grid_sample(ops):
+    """and the oracle's autograd itself equals F.grid_sample's (reference op)."""
+    x = rs(1, (1, 3, 12, 15), 0, 1).requires_grad_(True)
+    fl = (rs(2, (1, 2, 12, 15)) * 4).requires_grad_(True)
+    g = rs(3, (1, 3, 12, 15))
+    n, c, h, w = x.shape
+    iu = torch.linspace(-1, 1, w).view(1, 1, 1, w).expand(n, -1, h, -1)
+    iv = torch.linspace(-1, 1, h).view(1, 1, h, 1).expand(n, -1, -1, w)
+    grid = torch.cat([iu, iv], 1) + torch.cat([fl[:, 0:1] / ((w - 1) / 2), fl[:, 1:2] / ((h - 1) / 2)], 1)
+    F.grid_sample(x, grid.permute(0, 2, 3, 1), mode='bilinear', padding_mode='border',
+                  align_corners=True).backward(g)
+    dimg, dflow = ops.backward_warp_bwd(dev(x.detach()), dev(fl.detach()), dev(g))
+    assert relerr(dimg, x.grad) <= 2e-5
+    assert ((dflow.cpu() - fl.grad).abs() > 1e-3 * fl.grad.abs().max()).float().mean() < 2e-3
+
+
+def test_depth_to_space_inverts_s2d(ops):
+    x = dev(rs(1, (2, 3, 16, 24)))
+    for s in (2, 4):
+        assert torch.equal(ops.depth_to_space(ops.space_to_depth(x, s), s), x)
+
+
+def test_losses(ops):
+    x = rs(1, (2, 3, 20, 30), 0, 1).requires_grad_(True)
+    y = rs(2, (2, 3, 20, 30), 0, 1)
+    loss = 0.5 * O.charbonnier(x, y, 'mean')
+    loss.backward()
+    acc = torch.zeros(1, device='cuda')
+    dx = ops.charbonnier(dev(x.detach()), dev(y), acc, 0.5 / x.numel(), grad_scale=0.5 / x.numel())
+    assert abs(acc.item() - loss.item()) <= 1e-6 and relerr(dx, x.grad) <= 1e-5
+    for target in (1.0, 0.0):
+        z = (rs(3, (12, 1)) * 3).requires_grad_(True)
+        l = 0.01 * O.bce_with_logits(z, target)
+        l.backward()
+        st = torch.zeros(3, device='cuda')
+        dz = ops.bce_logits(dev(z.detach()), target, st, 1.0 / z.numel(), grad_scale=0.01 / z.numel())
+        assert abs(st[0].item() * 0.01 - l.item()) <= 1e-7
+        assert abs(st[1].item() - z.mean().item()) <= 1e-6
+        assert abs(st[2].item() - torch.log(torch.sigmoid(z) + 1e-8).mean().item()) <= 1e-6
+        assert relerr(dz, z.grad) <= 1e-5
+
+
+def test_adam_matches_oracle(ops):
+    p0, g1, g2 = rs(1, (1000,)), rs(2, (1000,)) * 1e-2, rs(3, (1000,)) * 1e-2
+    sd, st = {'p': p0.clone()}, {}
+    O.adam_step(sd, {'p': g1}, st, 5e-5)
+    O.adam_step(sd, {'p': g2}, st, 5e-5)
+    p, m, v = dev(p0), torch.zeros(1000, device='cuda'), torch.zeros(1000, device='cuda')
+    ops.adam_step(p, dev(g1), m, v, 5e-5, (0.9, 0.999), 1e-8, 0.0, 1)
+    ops.adam_step(p, dev(g2), m, v, 5e-5, (0.9, 0.999), 1e-8, 0.0, 2)
+    assert (p.cpu() - sd['p']).abs().max() <= 1.5e-7      # 1 ulp at |p| ~ 1; a step is 5e-5
+
+
+def test_bn_lrelu_and_linear(ops):
+    x = rs(1, (4, 8, 6, 5), -2, 2).requires_grad_(True)
+    gamma = (1 + 0.2 * rs(2, (8,))).requires_grad_(True)
+    beta = (0.1 * rs(3, (8,))).requires_grad_(True)
+    rm, rv = torch.zeros(8), torch.ones(8)
+    y = O._lrelu(O.batch_norm_train(x, gamma, beta, rm, rv))
+    g = rs(4, (4, 8, 6, 5))
+    y.backward(g)
+    rmd, rvd = torch.zeros(8, device='cuda'), torch.ones(8, device='cuda')
+    yd, mean, invstd = ops.bn_lrelu_train_fwd(dev(x.detach()), dev(gamma.detach()), dev(beta.detach()), rmd, rvd)
+    assert relerr(yd, y) <= 1e-5 and relerr(rmd, rm) <= 1e-5 and relerr(rvd, rv) <= 1e-5
+    dg, db = torch.zeros(8, device='cuda'), torch.zeros(8, device='cuda')
+    dx = ops.bn_lrelu_train_bwd(dev(x.detach()), yd, dev(g), dev(gamma.detach()), mean, invstd, dg, db)
+    assert relerr(dx, x.grad) <= 2e-5 and relerr(dg, gamma.grad) <= 1e-5 and relerr(db, beta.grad) <= 1e-5
+    # Linear(k -> 1)
+    xf = rs(5, (6, 1024)).requires_grad_(True)
+    w = (rs(6, (1, 1024)) / 32).requires_grad_(True)
+    b = rs(7, (1,)).requires_grad_(True)
+    out = F.linear(xf, w, b)
+    gy = rs(8, (6, 1))
+    out.backward(gy)
+    od = ops.linear1_fwd(dev(xf.detach()), dev(w.detach()), dev(b.detach()))
+    assert relerr(od, out) <= 1e-5
+    dw, dbb = torch.zeros(1, 1024, device='cuda'), torch.zeros(1, device='cuda')
+    dxf = ops.linear1_bwd(dev(xf.detach()), dev(w.detach()), dev(gy), dw, dbb)
+    assert relerr(dxf, xf.grad) <= 1e-6 and relerr(dw, w.grad) <= 1e-5 and relerr(dbb, b.grad) <= 1e-6
