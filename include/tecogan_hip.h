@@ -235,6 +235,13 @@ int tg_linear1_fwd(const float* x, const float* w, const float* b, float* y, int
 int tg_linear1_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
                    float* db, int rows, int k, int accumulate, tg_stream_t stream);
 
+/* downsample_bd (codes/utils/data_utils.py:30-53): per-plane 2-D Gaussian (kernel2d:
+ * ksize*ksize floats on the device, create_kernel :11-27) + stride-`scale` decimation.
+ * pad = 0: valid conv (training);  pad = 1: reflect padding (testing).
+ * y is (nc, oh, ow) with oh = pad ? (h-1)/scale+1 : (h-ksize)/scale+1. */
+int tg_downsample_bd(const float* x, const float* kernel2d, float* y, int nc, int h,
+                     int w, int ksize, int scale, int pad, tg_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Whole-frame plan: one call = FRNet.step (tecogan_nets.py:227-252).  The plan
  * holds only launch geometry and pointers into a caller-owned workspace and

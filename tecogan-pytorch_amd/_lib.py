@@ -59,6 +59,7 @@ SIGNATURES = {
     'tg_bn_lrelu_train_bwd': (I, [P, P, P, P, P, P, F, P, P, P, I, P, I, I, I, P]),
     'tg_linear1_fwd': (I, [P, P, P, P, I, I, P]),
     'tg_linear1_bwd': (I, [P, P, P, P, P, P, I, I, I, P]),
+    'tg_downsample_bd': (I, [P, P, P, I, I, I, I, I, I, P]),
     'tg_frnet_workspace_floats': (SZ, [C.POINTER(FrnetCfg)]),
     'tg_frnet_plan_create': (I, [C.POINTER(FrnetCfg), C.POINTER(LayerWeights), I, P,
                                  C.POINTER(C.c_void_p)]),

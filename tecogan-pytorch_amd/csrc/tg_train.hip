@@ -527,3 +527,45 @@ extern "C" int tg_linear1_bwd(const float* x, const float* w, const float* dy, f
                      k, accumulate);
   return check_launch("linear1_bwd");
 }
+
+// ---- BD degradation: per-channel Gaussian blur + stride-s decimation -------------
+// Replaces downsample_bd (codes/utils/data_utils.py:30-53; create_kernel :11-27):
+// y[p][oy][ox] = sum_{i,j} k[i][j] * x[p][oy*s + i - pad_t][ox*s + j - pad_l]
+// pad = 0: valid conv (training, base_model.py:75); pad = 1: 'reflect' padding of
+// (k-1)//2 before / k-1-(k-1)//2 after (testing, data_utils.py:40-48).
+namespace tg {
+__global__ void downsample_bd_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                     float* __restrict__ y, int nc, int h, int w, int ks, int s,
+                                     int pad, int oh, int ow) {
+  const long long total = (long long)nc * oh * ow;
+  const int pb = pad ? (ks - 1) / 2 : 0;
+  TG_GRID_STRIDE(i, total) {
+    int ox = (int)(i % ow); long long t = i / ow;
+    int oy = (int)(t % oh); int p = (int)(t / oh);
+    const float* src = x + (long long)p * h * w;
+    float acc = 0.f;
+    for (int a = 0; a < ks; ++a) {
+      int yy = oy * s + a - pb;
+      yy = yy < 0 ? -yy : (yy > h - 1 ? 2 * (h - 1) - yy : yy);
+      for (int b = 0; b < ks; ++b) {
+        int xx = ox * s + b - pb;
+        xx = xx < 0 ? -xx : (xx > w - 1 ? 2 * (w - 1) - xx : xx);
+        acc += k[a * ks + b] * src[(long long)yy * w + xx];
+      }
+    }
+    y[i] = acc;
+  }
+}
+}  // namespace tg
+
+extern "C" int tg_downsample_bd(const float* x, const float* kernel2d, float* y, int nc, int h,
+                                int w, int ksize, int scale, int pad, tg_stream_t stream) {
+  TG_REQUIRE(x && kernel2d && y, TG_E_ARG, "downsample_bd: null pointer");
+  TG_REQUIRE(nc > 0 && ksize >= 1 && scale >= 1 && h >= ksize && w >= ksize, TG_E_SHAPE,
+             "downsample_bd: nc=%d h=%d w=%d k=%d s=%d", nc, h, w, ksize, scale);
+  int oh = pad ? (h - 1) / scale + 1 : (h - ksize) / scale + 1;
+  int ow = pad ? (w - 1) / scale + 1 : (w - ksize) / scale + 1;
+  hipLaunchKernelGGL(tg::downsample_bd_kernel, dim3(tg::grid_for((long long)nc * oh * ow)), dim3(256),
+                     0, ST, x, kernel2d, y, nc, h, w, ksize, scale, pad, oh, ow);
+  return tg::check_launch("downsample_bd");
+}

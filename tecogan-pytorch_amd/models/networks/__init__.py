@@ -1,4 +1,4 @@
-from .tecogan_nets import FRNet, FNet, SRNet
+from .tecogan_nets import FRNet, FNet, SRNet, SpatioTemporalDiscriminator
 
 
 def define_generator(opt):
@@ -10,3 +10,18 @@ def define_generator(opt):
                      degradation=opt['dataset']['degradation']['type'],
                      scale=opt['scale'])
     raise ValueError(f'Unrecognized generator: {net_G_opt["name"]}')
+
+
+def define_discriminator(opt):
+    """codes/models/networks/__init__.py:22-47 (STNet; the never-selected SNet is not built)."""
+    net_D_opt = opt['model']['discriminator']
+    if opt['dataset']['degradation']['type'] == 'BD':
+        spatial_size = opt['dataset']['train']['crop_size']
+    else:
+        spatial_size = opt['dataset']['train']['gt_crop_size']
+    if net_D_opt['name'].lower() == 'stnet':
+        return SpatioTemporalDiscriminator(
+            in_nc=net_D_opt['in_nc'], spatial_size=spatial_size,
+            tempo_range=net_D_opt['tempo_range'],
+            degradation=opt['dataset']['degradation']['type'], scale=opt['scale'])
+    raise ValueError(f'Unrecognized discriminator: {net_D_opt["name"]}')

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from ... import _lib as L
 from ... import ops
+from .. import train_graph as TG
 from ...utils.net_utils import get_upsampling_func
 
 
@@ -40,7 +41,7 @@ class _Conv(nn.Module):
         """(packed weights, ocb) on the parameter's device; re-packed only when
         the parameter changed (optimizer step / load_state_dict)."""
         w = self.weight
-        key = (w.data_ptr(), w._version, w.device)
+        key = (ops.param_version(w), w.device)
         if self._cache is None or self._cache[0] != key:
             pk, _, _, ocb = ops.pack_conv3x3(w, transposed=self.transposed)
             self._cache = (key, pk, ocb)
@@ -80,8 +81,10 @@ class FNet(nn.Module):
             out += [blk['0'], blk['2']]
         return out
 
-    def forward(self, x1, x2):
+    def forward(self, x1, x2, tape=None):
         x1, x2 = x1.contiguous(), x2.contiguous()
+        if tape is not None:
+            return self._forward_train(x1, x2, tape)
         out = None
         for i, name in enumerate(('encoder1', 'encoder2', 'encoder3')):
             blk = getattr(self, name)
@@ -94,6 +97,26 @@ class FNet(nn.Module):
         out = self.flow['0'](out, ops.ACT_LRELU02)
         head = self.flow['2']
         return ops.conv3x3_small(out, head.weight, head.bias, ops.ACT_TANH24)
+
+
+    def _forward_train(self, x1, x2, tape):
+        """Same network on the tape (activations kept, backward closures recorded)."""
+        out = None
+        for i, name in enumerate(('encoder1', 'encoder2', 'encoder3')):
+            blk = getattr(self, name)
+            if i == 0:
+                out = TG.conv3x3(tape, blk['0'], x1, TG.LRELU, x2=x2, need_dx=False, need_dx2=False)
+            else:
+                out = TG.conv3x3(tape, blk['0'], out, TG.LRELU)
+            out = TG.conv3x3(tape, blk['2'], out, TG.LRELU)
+            out = TG.maxpool2(tape, out)
+        for name in ('decoder1', 'decoder2', 'decoder3'):
+            blk = getattr(self, name)
+            out = TG.conv3x3(tape, blk['0'], out, TG.LRELU)
+            out = TG.conv3x3(tape, blk['2'], out, TG.LRELU)
+            out = TG.upsample(tape, out, 2, ops.UP_BILINEAR)
+        out = TG.conv3x3(tape, self.flow['0'], out, TG.LRELU)
+        return TG.conv3x3_small(tape, self.flow['2'], out, TG.TANH24)
 
 
 class _ResBlock(nn.Module):
@@ -128,8 +151,18 @@ class SRNet(nn.Module):
     def up_mode(self):
         return ops.UP_BICUBIC if isinstance(self.upsample_func, nn.Module) else ops.UP_BILINEAR
 
-    def forward(self, lr_curr, hr_prev_tran):
+    def forward(self, lr_curr, hr_prev_tran, tape=None):
         lr_curr, hr_prev_tran = lr_curr.contiguous(), hr_prev_tran.contiguous()
+        if tape is not None:
+            out = TG.conv3x3(tape, self.conv_in['0'], lr_curr, TG.RELU, x2=hr_prev_tran,
+                             need_dx=False, need_dx2=True)
+            for rb in self.resblocks:
+                t = TG.conv3x3(tape, rb.conv['0'], out, TG.RELU)
+                out = TG.conv3x3(tape, rb.conv['2'], t, TG.NONE, res=out)
+            for k in self.conv_up:
+                out = TG.convt3x3s2(tape, self.conv_up[k], out, TG.RELU)
+            return TG.conv3x3_small(tape, self.conv_out, out, TG.NONE, up_src=lr_curr,
+                                    up_mode=self.up_mode(), up_scale=self.scale)
         out = self.conv_in['0'](lr_curr, ops.ACT_RELU, x2=hr_prev_tran)
         for rb in self.resblocks:
             t = rb.conv['0'](out, ops.ACT_RELU)
@@ -194,7 +227,7 @@ class FRNet(nn.Module):
 
     # -- plan cache ---------------------------------------------------------
     def _weights_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple(ops.param_version(p) for p in self.parameters())
 
     def _get_plan(self, n, h, w, device):
         key = (n, h, w, str(device), self._weights_key())
@@ -258,9 +291,56 @@ class FRNet(nn.Module):
         return u8.cpu().numpy()
 
     def forward_sequence(self, lr_data):
-        raise L.TecoganHipError(
-            'forward_sequence (training unroll with autograd) is not built yet on the HIP path; '
-            'there is deliberately no ATen fallback')
+        """Training unroll (tecogan_nets.py:174-225): lr_data (n,t,c,h,w) -> dict with
+        hr_data (n,t,c,sh,sw), hr_flow (n,t-1,2,sh,sw), lr_prev, lr_curr, lr_flow.
+        The recorded tape is kept in `self.tape`; the wrapper seeds it with
+        d loss / d hr_data and d loss / d lr_flow and calls `self.tape.backward()`."""
+        lr_data = ops._chk(lr_data.contiguous(), 'lr_data')
+        n, t, c, h, w = lr_data.shape
+        s = self.scale
+        tape = TG.Tape()
+        lr_prev = lr_data[:, :-1].reshape(n * (t - 1), c, h, w).contiguous()
+        lr_curr = lr_data[:, 1:].reshape(n * (t - 1), c, h, w).contiguous()
+        lr_flow = self.fnet(lr_curr, lr_prev, tape=tape)
+        hr_flow_all = TG.upsample(tape, lr_flow, s, self.srnet.up_mode(), mul=float(s))
+        hr_flow = hr_flow_all.view(n, t - 1, 2, s * h, s * w)
+        g_flow = {}
+
+        def flow_grad_finalize():          # runs after every per-frame slice has deposited
+            if 'g' in g_flow:
+                tape.add_grad(hr_flow_all, g_flow['g'])
+        tape.record(flow_grad_finalize)
+
+        frames = []
+        zeros = torch.zeros(n, s * s * c, h, w, dtype=torch.float32, device=lr_data.device)
+        hr_prev = self.srnet(lr_data[:, 0].contiguous(), zeros, tape=tape)
+        frames.append(hr_prev)
+        for i in range(1, t):
+            flow_i = hr_flow[:, i - 1].contiguous()
+
+            def slice_bwd(flow_i=flow_i, i=i):
+                g = tape.pop_grad(flow_i)
+                if g is None:
+                    return
+                if 'g' not in g_flow:
+                    g_flow['g'] = torch.zeros_like(hr_flow_all)
+                g_flow['g'].view(n, t - 1, 2, s * h, s * w)[:, i - 1].copy_(g)
+            tape.record(slice_bwd)
+            warped = TG.backward_warp(tape, hr_prev, flow_i)
+            tran = TG.space_to_depth(tape, warped, s)
+            hr_prev = self.srnet(lr_data[:, i].contiguous(), tran, tape=tape)
+            frames.append(hr_prev)
+        hr_data = torch.stack(frames, dim=1)
+
+        def stack_bwd():
+            g = tape.pop_grad(hr_data)
+            if g is not None:
+                for i, f in enumerate(frames):
+                    tape.add_grad(f, g[:, i].contiguous())
+        tape.record(stack_bwd)
+        self.tape = tape
+        return {'hr_data': hr_data, 'hr_flow': hr_flow, 'lr_prev': lr_prev, 'lr_curr': lr_curr,
+                'lr_flow': lr_flow}
 
     def generate_dummy_data(self, lr_size, device):
         c, lr_h, lr_w = lr_size
@@ -301,3 +381,148 @@ class FRNet(nn.Module):
         sz.append((hh, ww))
         gflops['SRNet'], params['SRNet'] = walk(self.srnet.layers(), sz)
         return gflops, params
+
+
+# ====================== discriminator ====================== #
+class _Conv4(nn.Module):
+    """nn.Conv2d(ci, co, 4, 2, 1, bias=False) parameter holder (default init)."""
+
+    def __init__(self, ci, co):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(co, ci, 4, 4))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+
+class _BN(nn.Module):
+    """nn.BatchNorm2d(c) parameter / buffer holder (same state-dict entries)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+
+class _Linear1(nn.Module):
+    def __init__(self, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(1, k))
+        self.bias = nn.Parameter(torch.empty(1))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(k)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class DiscriminatorBlocks(nn.Module):
+    """tecogan_nets.py:318-349: 4 x (conv4x4 s2 no-bias, BatchNorm, LeakyReLU)."""
+
+    def __init__(self):
+        super().__init__()
+        for i, (ci, co) in enumerate([(64, 64), (64, 64), (64, 128), (128, 256)], 1):
+            setattr(self, f'block{i}', _block([(0, _Conv4(ci, co)), (1, _BN(co))]))
+
+    def forward(self, x, tape, need_dx):
+        feats = []
+        for i in range(1, 5):
+            blk = getattr(self, f'block{i}')
+            x = TG.conv4x4s2(tape, blk['0'], x, need_dx=True)   # conv_in below it has parameters
+            x = TG.bn_lrelu(tape, blk['1'], x, need_dx=True)
+            feats.append(x)
+        return x, feats
+
+
+class SpatioTemporalDiscriminator(nn.Module):
+    """tecogan_nets.py:352-477.  Always runs in train mode (batch statistics), as
+    the reference does for all three passes of an iteration.
+
+    args_dict carries what the reference's does (net_G, lr_data, bi_data,
+    use_pp_crit, crop_border_ratio, hr_flow [, hr_flow_merge]) plus
+    `tape` (Tape or None) and `need_input_grad` (third pass: gradient to `data`)."""
+
+    def __init__(self, in_nc, spatial_size, tempo_range, degradation, scale):
+        super().__init__()
+        assert tempo_range == 3, 'currently only support 3 as tempo_range'
+        self.spatial_size, self.tempo_range, self.scale = spatial_size, tempo_range, scale
+        self.conv_in = _block([(0, _Conv(in_nc * tempo_range * 3, 64))])
+        self.discriminator_block = DiscriminatorBlocks()
+        self.dense = _Linear1(256 * spatial_size // 16 * spatial_size // 16)
+        self.upsample_func = get_upsampling_func(scale, degradation)
+
+    def forward(self, data, args_dict):
+        return self.forward_sequence(data, args_dict)
+
+    def forward_sequence(self, data, args_dict):
+        tape = args_dict.get('tape')
+        need_in = bool(args_dict.get('need_input_grad', False))
+        lr_data, bi_data, hr_flow = args_dict['lr_data'], args_dict['bi_data'], args_dict['hr_flow']
+        n, t, c, lr_h, lr_w = lr_data.size()
+        hr_h, hr_w = data.shape[3:]
+        s_size = self.spatial_size
+        t = t // 3 * 3
+        n_clip = n * t // 3
+        c_size = int(s_size * args_dict['crop_border_ratio'])
+        n_pad = (s_size - c_size) // 2
+
+        if 'hr_flow_merge' not in args_dict:
+            if not args_dict['use_pp_crit']:
+                raise L.TecoganHipError('only the use_pp_crit=True flow construction '
+                                        '(tecogan_nets.py:408-411) is built')
+            bw = hr_flow[:, 0:t:3]
+            fw = hr_flow.flip(1)[:, 1:t:3]
+            merge = torch.stack([bw, torch.zeros_like(bw), fw], dim=2)
+            hr_flow_merge = merge.reshape(n_clip * 3, 2, hr_h, hr_w).contiguous()
+        else:
+            hr_flow_merge = args_dict['hr_flow_merge']
+
+        def triplets(x):       # (n*t, c, H, W) frames -> (n_clip, 3c, H, W), rrrgggbbb
+            return x.view(n_clip, 3, c, hr_h, hr_w).permute(0, 2, 1, 3, 4).reshape(
+                n_clip, c * 3, hr_h, hr_w)
+
+        frames = data[:, :t].reshape(n * t, c, hr_h, hr_w).contiguous()
+        track = tape is not None and need_in
+        if track:
+            # recorded first => runs last: hands the gradient of the frame copies back to `data`
+            def frames_bwd():
+                g = tape.pop_grad(frames)
+                if g is not None:
+                    full = torch.zeros_like(data)
+                    full[:, :t] = g.view(n, t, c, hr_h, hr_w)
+                    tape.add_grad(data, full)
+            tape.record(frames_bwd)
+        warped = TG.backward_warp(tape if track else None, frames, hr_flow_merge,
+                                  need_dimg=True, need_dflow=False)
+        x = torch.zeros(n_clip, 9 * c, hr_h, hr_w, dtype=torch.float32, device=data.device)
+        x[:, 0:3 * c] = triplets(frames)
+        x[:, 3 * c:6 * c, n_pad:n_pad + c_size, n_pad:n_pad + c_size] = \
+            triplets(warped)[:, :, n_pad:n_pad + c_size, n_pad:n_pad + c_size]
+        x[:, 6 * c:9 * c] = triplets(bi_data[:, :t].reshape(n * t, c, hr_h, hr_w))
+
+        if track:
+            def assemble_bwd():
+                g = tape.pop_grad(x)
+                if g is None:
+                    return
+
+                def untrip(z):     # inverse of triplets
+                    return z.reshape(n_clip, c, 3, hr_h, hr_w).permute(0, 2, 1, 3, 4).reshape(
+                        n * t, c, hr_h, hr_w).contiguous()
+                gw = torch.zeros(n_clip, 3 * c, hr_h, hr_w, dtype=torch.float32, device=g.device)
+                gw[:, :, n_pad:n_pad + c_size, n_pad:n_pad + c_size] = \
+                    g[:, 3 * c:6 * c, n_pad:n_pad + c_size, n_pad:n_pad + c_size]
+                tape.add_grad(warped, untrip(gw))
+                tape.add_grad(frames, untrip(g[:, 0:3 * c]))
+            tape.record(assemble_bwd)
+
+        out = TG.conv3x3(tape, self.conv_in['0'], x, TG.LRELU, need_dx=need_in)
+        out, feats = self.discriminator_block(out, tape, need_in)
+        flat = out.reshape(out.size(0), -1)
+        if tape is not None:
+            def flat_bwd():        # recorded before the linear node => runs right after it
+                g = tape.pop_grad(flat)
+                if g is not None:
+                    tape.add_grad(out, g.view_as(out))
+            tape.record(flat_bwd)
+        logits = TG.linear1(tape, self.dense, flat, need_dx=True)
+        return (logits, feats), {'hr_flow_merge': hr_flow_merge}

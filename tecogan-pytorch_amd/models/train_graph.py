@@ -1,0 +1,324 @@
+"""A minimal reverse-mode tape whose every arithmetic node is a HIP kernel.
+
+The reference trains through torch.autograd over ATen ops; here the training
+graph of this one model family is recorded explicitly: each differentiable op
+below runs its forward kernel, and registers a closure that runs the matching
+backward kernels (conv data gradients reuse the forward MFMA kernel on
+rot180-packed weights, weight gradients use the MFMA wgrad kernel, transposed
+and strided convs go through their space-to-depth embedding).  torch is used
+for storage and for pure data movement (slicing / stacking / zero fill) only.
+
+Gradients of intermediate tensors are keyed by tensor identity; parameter
+gradients accumulate into `param.grad` (allocated and zeroed by the caller).
+"""
+import torch
+
+from .. import ops
+
+NONE, RELU, LRELU, TANH24 = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU02, ops.ACT_TANH24
+
+
+class Tape:
+    def __init__(self):
+        self.nodes = []
+        self.grads = {}
+        self.keep = []          # tensors that must outlive backward (id() stability)
+
+    # -- gradient bookkeeping -------------------------------------------------
+    def add_grad(self, t, g):
+        """Accumulate g into the gradient of t.  Takes ownership of g."""
+        k = id(t)
+        cur = self.grads.get(k)
+        if cur is None:
+            self.grads[k] = g
+            self.keep.append(t)
+        else:
+            ops.axpy_(cur, g, 1.0)
+
+    def grad(self, t):
+        return self.grads.get(id(t))
+
+    def pop_grad(self, t):
+        return self.grads.pop(id(t), None)
+
+    def record(self, fn):
+        self.nodes.append(fn)
+
+    def backward(self):
+        for fn in reversed(self.nodes):
+            fn()
+        self.nodes = []
+
+
+def _grad_buf(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class ConvCache:
+    """Per-layer packed weights for the training step (forward, data-gradient and
+    the space-to-depth embeddings), rebuilt when the parameter version changes."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, key, version, build):
+        ent = self.store.get(key)
+        if ent is None or ent[0] != version:
+            ent = (version, build())
+            self.store[key] = ent
+        return ent[1]
+
+
+_CACHE = ConvCache()
+
+
+def _ver(w):
+    return ops.param_version(w)
+
+
+# ---------------------------------------------------------------------------
+# conv3x3 (+bias, +activation, two-source input, residual)
+# ---------------------------------------------------------------------------
+def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=True):
+    w, b = layer.weight, layer.bias
+    cout, cin = w.shape[0], w.shape[1]
+    pk, ocb = layer.packed()
+    y = ops.conv3x3(x, pk, b, cin, cout, ocb, act, x2=x2, res=res, ksplit=None if res is None else 1)
+    if tape is None:
+        return y
+    c1 = x.shape[1]
+
+    def bwd():
+        g = tape.pop_grad(y)
+        if g is None:
+            return
+        if res is not None:
+            tape.add_grad(res, g.clone())
+        dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
+        if w.requires_grad:
+            gw = _grad_buf(w)
+            ops.wgrad3x3(dz, x, gw, cb_off=0, accumulate=True)
+            if x2 is not None:
+                ops.wgrad3x3(dz, x2, gw, cb_off=c1, accumulate=True)
+            ops.bias_grad(dz, _grad_buf(b), accumulate=True)
+        wd = w.detach()
+        if need_dx:
+            pkd = _CACHE.get(('dg', id(layer), 0), _ver(w), lambda: ops.pack_conv3x3_dgrad(
+                wd[:, :c1].contiguous()))
+            tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, c1, pkd[3], ksplit=1))
+        if x2 is not None and need_dx2:
+            pkd = _CACHE.get(('dg', id(layer), 1), _ver(w), lambda: ops.pack_conv3x3_dgrad(
+                wd[:, c1:].contiguous()))
+            tape.add_grad(x2, ops.conv3x3(dz, pkd[0], None, cout, cin - c1, pkd[3], ksplit=1))
+    tape.record(bwd)
+    return y
+
+
+def conv3x3_small(tape, layer, x, act=NONE, up_src=None, up_mode=ops.UP_NONE, up_scale=1):
+    """cout <= 4 head (flow[2] / conv_out).  `up_src` is data (no gradient)."""
+    w, b = layer.weight, layer.bias
+    cout, cin = w.shape[0], w.shape[1]
+    y = ops.conv3x3_small(x, w, b, act, up_src=up_src, up_mode=up_mode, up_scale=up_scale)
+    if tape is None:
+        return y
+
+    def bwd():
+        g = tape.pop_grad(y)
+        if g is None:
+            return
+        dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
+        if w.requires_grad:
+            ops.wgrad3x3(dz, x, _grad_buf(w), accumulate=True)
+            ops.bias_grad(dz, _grad_buf(b), accumulate=True)
+        pkd = _CACHE.get(('dg', id(layer), 0), _ver(w),
+                         lambda: ops.pack_conv3x3_dgrad(w.detach().contiguous()))
+        tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, cin, pkd[3], ksplit=1))
+    tape.record(bwd)
+    return y
+
+
+# ---------------------------------------------------------------------------
+# ConvTranspose2d(k3,s2,p1,op1): forward = sub-pixel phase kernel; backward via
+# the space-to-depth embedding (oy = 2*iy - 1 + ky  <=>  ky -> (phase, tap)).
+# ---------------------------------------------------------------------------
+_KT = {0: (1, 0), 1: (0, 1), 2: (1, 1)}          # convT: ky -> (py, ty)
+
+
+def _convt_embed(wt):
+    """(ci, co, 3, 3) -> conv weight (cout_op = ci, cin_op = 4*co, 3, 3) acting on s2d(dY)."""
+    ci, co = wt.shape[:2]
+    we = torch.zeros(ci, 4 * co, 3, 3, dtype=wt.dtype, device=wt.device)
+    for ky, (py, ty) in _KT.items():
+        for kx, (px, tx) in _KT.items():
+            ph = py * 2 + px
+            we[:, ph * co:(ph + 1) * co, ty, tx] = wt[:, :, ky, kx]
+    return we
+
+
+def convt3x3s2(tape, layer, x, act=RELU):
+    w, b = layer.weight, layer.bias            # (ci, co, 3, 3)
+    ci, co = w.shape[:2]
+    pk, _ = layer.packed()
+    y = ops.convt3x3s2(x, pk, b, co, act)
+    if tape is None:
+        return y
+
+    def bwd():
+        g = tape.pop_grad(y)
+        if g is None:
+            return
+        dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
+        s = ops.space_to_depth(dz, 2)                              # (n, 4co, h, w)
+        we = _CACHE.get(('cte', id(layer)), _ver(w), lambda: ops.pack_conv3x3(_convt_embed(w.detach())))
+        tape.add_grad(x, ops.conv3x3(s, we[0], None, 4 * co, ci, we[3], ksplit=1))
+        if w.requires_grad:
+            ge = torch.zeros(ci, 4 * co, 3, 3, dtype=torch.float32, device=x.device)
+            ops.wgrad3x3(x, s, ge, accumulate=False)               # G[ci][(ph,co)][ty][tx]
+            sel = torch.empty(ci, co, 3, 3, dtype=torch.float32, device=x.device)
+            for ky, (py, ty) in _KT.items():
+                for kx, (px, tx) in _KT.items():
+                    ph = py * 2 + px
+                    sel[:, :, ky, kx] = ge[:, ph * co:(ph + 1) * co, ty, tx]     # gather (copy)
+            ops.axpy_(_grad_buf(w), sel, 1.0)
+            ops.bias_grad(dz, _grad_buf(b), accumulate=True)
+    tape.record(bwd)
+    return y
+
+
+# ---------------------------------------------------------------------------
+# Conv2d(k4, s2, p1, no bias) of the discriminator blocks through s2d:
+#   2*oy - 1 + ky = 2*(oy + ty - 1) + py
+# ---------------------------------------------------------------------------
+_K4 = {0: (1, 0), 1: (0, 1), 2: (1, 1), 3: (0, 2)}   # ky -> (py, ty)
+
+
+def _conv4_embed(w4):
+    """(co, ci, 4, 4) -> (co, 4*ci, 3, 3) acting on s2d(x, 2)."""
+    co, ci = w4.shape[:2]
+    we = torch.zeros(co, 4 * ci, 3, 3, dtype=w4.dtype, device=w4.device)
+    for ky, (py, ty) in _K4.items():
+        for kx, (px, tx) in _K4.items():
+            ph = py * 2 + px
+            we[:, ph * ci:(ph + 1) * ci, ty, tx] = w4[:, :, ky, kx]
+    return we
+
+
+def conv4x4s2(tape, holder, x, need_dx=True):
+    """holder.weight: (co, ci, 4, 4).  Returns (n, co, h/2, w/2)."""
+    w = holder.weight
+    co, ci = w.shape[:2]
+    s = ops.space_to_depth(x, 2)
+    pk = _CACHE.get(('c4f', id(holder)), _ver(w), lambda: ops.pack_conv3x3(_conv4_embed(w.detach())))
+    y = ops.conv3x3(s, pk[0], None, 4 * ci, co, pk[3])
+    if tape is None:
+        return y
+
+    def bwd():
+        g = tape.pop_grad(y)
+        if g is None:
+            return
+        if w.requires_grad:
+            ge = torch.zeros(co, 4 * ci, 3, 3, dtype=torch.float32, device=x.device)
+            ops.wgrad3x3(g, s, ge, accumulate=False)
+            sel = torch.empty(co, ci, 4, 4, dtype=torch.float32, device=x.device)
+            for ky, (py, ty) in _K4.items():
+                for kx, (px, tx) in _K4.items():
+                    ph = py * 2 + px
+                    sel[:, :, ky, kx] = ge[:, ph * ci:(ph + 1) * ci, ty, tx]     # gather (copy)
+            ops.axpy_(_grad_buf(w), sel, 1.0)
+        if need_dx:
+            pkd = _CACHE.get(('c4d', id(holder)), _ver(w),
+                             lambda: ops.pack_conv3x3_dgrad(_conv4_embed(w.detach())))
+            ds = ops.conv3x3(g, pkd[0], None, co, 4 * ci, pkd[3], ksplit=1)
+            tape.add_grad(x, ops.depth_to_space(ds, 2))
+    tape.record(bwd)
+    return y
+
+
+# ---------------------------------------------------------------------------
+# pointwise / gather ops
+# ---------------------------------------------------------------------------
+def maxpool2(tape, x):
+    y = ops.maxpool2(x)
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is not None:
+                tape.add_grad(x, ops.maxpool2_bwd(x, g))
+        tape.record(bwd)
+    return y
+
+
+def upsample(tape, x, scale, up_mode, mul=1.0):
+    y = ops.upsample(x, scale, up_mode, mul)
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is not None:
+                tape.add_grad(x, ops.upsample_bwd(g, scale, up_mode, mul))
+        tape.record(bwd)
+    return y
+
+
+def backward_warp(tape, x, flow, need_dimg=True, need_dflow=True):
+    y = ops.backward_warp(x, flow)
+    if tape is not None and (need_dimg or need_dflow):
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is None:
+                return
+            dimg, dflow = ops.backward_warp_bwd(x, flow, g, need_dimg, need_dflow)
+            if need_dimg:
+                tape.add_grad(x, dimg)
+            if need_dflow:
+                tape.add_grad(flow, dflow)
+        tape.record(bwd)
+    return y
+
+
+def space_to_depth(tape, x, scale):
+    y = ops.space_to_depth(x, scale)
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is not None:
+                tape.add_grad(x, ops.depth_to_space(g, scale))
+        tape.record(bwd)
+    return y
+
+
+def bn_lrelu(tape, bn, x, need_dx=True):
+    """BatchNorm2d (train mode) + LeakyReLU(0.2); bn holds weight/bias/running stats."""
+    y, mean, invstd = ops.bn_lrelu_train_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    bn.num_batches_tracked += 1
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is None:
+                return
+            train = bn.weight.requires_grad
+            dx = ops.bn_lrelu_train_bwd(x, y, g, bn.weight, mean, invstd,
+                                        _grad_buf(bn.weight) if train else None,
+                                        _grad_buf(bn.bias) if train else None, need_dx)
+            if need_dx:
+                tape.add_grad(x, dx)
+        tape.record(bwd)
+    return y
+
+
+def linear1(tape, lin, x, need_dx=True):
+    y = ops.linear1_fwd(x, lin.weight, lin.bias)
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is None:
+                return
+            train = lin.weight.requires_grad
+            dx = ops.linear1_bwd(x, lin.weight, g, _grad_buf(lin.weight) if train else None,
+                                 _grad_buf(lin.bias) if train else None, need_dx)
+            if need_dx:
+                tape.add_grad(x, dx)
+        tape.record(bwd)
+    return y

@@ -1,0 +1,75 @@
+"""VSRModel (FRVSR): generator only, Charbonnier pixel + warping loss
+(codes/models/vsr_model.py)."""
+from collections import OrderedDict
+
+import torch
+
+from .. import ops
+from . import train_graph as TG
+from .base_model import BaseModel
+from .networks import define_generator
+from .optim import Adam, define_criterion
+
+
+class VSRModel(BaseModel):
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.set_networks()
+        if self.is_train:
+            self.set_criterions()
+            self.set_optimizers()
+
+    def set_networks(self):
+        self.net_G = self.model_to_device(define_generator(self.opt))
+        load_path_G = self.opt['model']['generator'].get('load_path')
+        if load_path_G:
+            self.load_network(self.net_G, load_path_G)
+
+    def set_criterions(self):
+        self.pix_crit = define_criterion(self.opt['train'].get('pixel_crit'))
+        self.warp_crit = define_criterion(self.opt['train'].get('warping_crit'))
+
+    def set_optimizers(self):
+        g = self.opt['train']['generator']
+        self.optim_G = Adam(self.net_G.parameters(), lr=g['lr'],
+                            weight_decay=g.get('weight_decay', 0), betas=g.get('betas', (0.9, 0.999)))
+
+    # -- loss helpers (value accumulates on the device; gradient returned) -----
+    @staticmethod
+    def _cb(x, y, weight, reduction, acc):
+        scale = weight / x.numel() if reduction == 'mean' else weight
+        return ops.charbonnier(x, y, acc, scale, grad_scale=scale)
+
+    def train(self):
+        """vsr_model.py:61-95."""
+        self.net_G.train()
+        self.optim_G.zero_grad()
+        out = self.net_G(self.lr_data)
+        tape = self.net_G.tape
+        self.hr_data = out['hr_data']
+        losses = torch.zeros(2, dtype=torch.float32, device=self.device)
+        pix_w = self.opt['train']['pixel_crit'].get('weight', 1.0)
+        tape.add_grad(out['hr_data'], self._cb(out['hr_data'], self.gt_data.contiguous(), pix_w,
+                                               self.pix_crit[1], losses[0:1]))
+        if self.warp_crit is not None:
+            lr_warp = TG.backward_warp(tape, out['lr_prev'], out['lr_flow'], need_dimg=False)
+            warp_w = self.opt['train']['warping_crit'].get('weight', 1.0)
+            tape.add_grad(lr_warp, self._cb(lr_warp, out['lr_curr'], warp_w, self.warp_crit[1],
+                                            losses[1:2]))
+        tape.backward()
+        self.allreduce_grads(self.net_G)
+        self.optim_G.step()
+        vals = losses.tolist()                       # the iteration's only host sync
+        self.log_dict = OrderedDict(l_pix_G=vals[0])
+        if self.warp_crit is not None:
+            self.log_dict['l_warp_G'] = vals[1]
+
+    def infer(self):
+        """vsr_model.py:97-113: temporal padding, inference, crop the padding back."""
+        lr_data, n_pad_front = self.pad_sequence(self.lr_data)
+        self.net_G.eval()
+        hr_seq = self.net_G(lr_data, self.device)
+        return hr_seq[n_pad_front:]
+
+    def save(self, current_iter):
+        self.save_network(self.net_G, 'G', current_iter)

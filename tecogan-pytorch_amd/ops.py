@@ -28,6 +28,16 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def param_version(w):
+    """Cache key for anything derived from a parameter (packed weights, plans)."""
+    return (w.data_ptr(), w._version, getattr(w, '_tg_version', 0))
+
+
+def bump_version(w):
+    """Call after modifying a parameter through its raw pointer (fused Adam)."""
+    w._tg_version = getattr(w, '_tg_version', 0) + 1
+
+
 def pick_ocb(cout):
     return L.lib().tg_conv3x3_pick_ocb(int(cout))
 
@@ -362,3 +372,23 @@ def linear1_bwd(x, w, dy, dw=None, db=None, need_dx=True):
     L.check(L.lib().tg_linear1_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _ptr(dx), _ptr(dw),
                                    _ptr(db), rows, k, 1, _stream()), 'tg_linear1_bwd')
     return dx
+
+
+_BD_KERNELS = {}
+
+
+def downsample_bd(x, kernel2d, scale, pad):
+    """x (n,c,h,w) -> blurred + decimated (n,c,oh,ow); kernel2d: numpy (k,k) float32."""
+    _chk(x, 'x')
+    n, c, h, w = x.shape
+    ks = int(kernel2d.shape[0])
+    key = (str(x.device), ks, float(kernel2d[ks // 2, ks // 2]))
+    kd = _BD_KERNELS.get(key)
+    if kd is None:
+        kd = _BD_KERNELS[key] = torch.from_numpy(kernel2d.copy()).to(x.device).contiguous()
+    oh = (h - 1) // scale + 1 if pad else (h - ks) // scale + 1
+    ow = (w - 1) // scale + 1 if pad else (w - ks) // scale + 1
+    y = torch.empty(n, c, oh, ow, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_downsample_bd(x.data_ptr(), kd.data_ptr(), y.data_ptr(), n * c, h, w, ks,
+                                     scale, 1 if pad else 0, _stream()), 'tg_downsample_bd')
+    return y
