@@ -51,6 +51,8 @@ def parse():
                     help='max frames of the CPU baseline sample (0 disables)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--aten-frames', type=int, default=30,
+                    help='frames of the ATen/MIOpen-on-GPU context baseline (0 disables)')
     return ap.parse_args()
 
 
@@ -114,6 +116,87 @@ def cpu_baseline(sd, scale, deg, c, h, w, max_frames, max_seconds):
     return dict(value=frames / tot, unit='frames/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'{frames} frames of the same {c}x{h}x{w} workload, oracle/tecogan_oracle.py '
                        f'(torch-CPU fp32, oneDNN), nproc={os.cpu_count()}')
+
+
+def aten_gpu_baseline(sd, scale, deg, c, h, w, frames, dev):
+    """Context only: the same frame through stock PyTorch-ROCm ops (ATen / MIOpen fp32 on this
+    GPU) -- i.e. what the unmodified reference's op path does on MI355X -- using the oracle's
+    restatement on device tensors, reference protocol (sync every frame, main.py:249-262)."""
+    from oracle import tecogan_oracle as O
+    sd = {k: v.to(dev) for k, v in sd.items()}
+    tot = 0.0
+    try:
+        with torch.no_grad():
+            def run():
+                a = [torch.rand(1, c, h, w, device=dev), torch.rand(1, c, h, w, device=dev),
+                     torch.rand(1, c, scale * h, scale * w, device=dev)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _aten_step(O, sd, a[0], a[1], a[2], scale, deg)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+            for _ in range(5):
+                run()
+            for _ in range(frames):
+                tot += run()
+    except Exception as e:       # context number only: never fail the bench for it
+        return {'error': repr(e)[:200]}
+    return {'value': frames / tot, 'unit': 'frames/s', 'kind': 'ATen/MIOpen fp32 on the same GPU',
+            'sample': f'{frames} frames, sync every frame'}
+
+
+def _aten_step(O, sd, lr_curr, lr_prev, hr_prev, scale, deg):
+    """FRNet.step with torch.nn.functional ops exactly as the reference composes them."""
+    import torch.nn.functional as F
+    fs = O._sub(sd, 'fnet.')
+    out = torch.cat([lr_curr, lr_prev], 1)
+    for enc in ('encoder1', 'encoder2', 'encoder3'):
+        out = F.leaky_relu(F.conv2d(out, fs[enc + '.0.weight'], fs[enc + '.0.bias'], padding=1), 0.2)
+        out = F.leaky_relu(F.conv2d(out, fs[enc + '.2.weight'], fs[enc + '.2.bias'], padding=1), 0.2)
+        out = F.max_pool2d(out, 2, 2)
+    for dec in ('decoder1', 'decoder2', 'decoder3'):
+        out = F.leaky_relu(F.conv2d(out, fs[dec + '.0.weight'], fs[dec + '.0.bias'], padding=1), 0.2)
+        out = F.leaky_relu(F.conv2d(out, fs[dec + '.2.weight'], fs[dec + '.2.bias'], padding=1), 0.2)
+        out = F.interpolate(out, scale_factor=2, mode='bilinear', align_corners=False)
+    out = F.leaky_relu(F.conv2d(out, fs['flow.0.weight'], fs['flow.0.bias'], padding=1), 0.2)
+    flow = torch.tanh(F.conv2d(out, fs['flow.2.weight'], fs['flow.2.bias'], padding=1)) * 24
+    h, w = lr_curr.shape[2:]
+    flow = F.pad(flow, (0, w - w // 8 * 8, 0, h - h // 8 * 8), 'reflect')
+
+    def up(x):
+        if deg == 'BI':
+            return F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False)
+        k = sd['upsample_func.kernels']
+        n, c, hh, ww = x.shape
+        x = F.pad(x.reshape(n * c, 1, hh, ww), (1, 2, 1, 2), mode='replicate')
+        o = F.conv2d(x, k.view(scale, 1, 4, 1)).permute(0, 2, 1, 3).reshape(n * c, 1, scale * hh, ww + 3)
+        o = F.conv2d(o, k.view(scale, 1, 1, 4)).permute(0, 2, 3, 1).reshape(n, c, scale * hh, scale * ww)
+        return o
+    hr_flow = scale * up(flow)
+    n, c, H, W = hr_prev.shape
+    iu = torch.linspace(-1.0, 1.0, W).view(1, 1, 1, W).expand(n, -1, H, -1)
+    iv = torch.linspace(-1.0, 1.0, H).view(1, 1, H, 1).expand(n, -1, -1, W)
+    grid = torch.cat([iu, iv], 1).to(hr_flow.device)          # host mesh + H2D, as net_utils.py:62-64
+    grid = (grid + torch.cat([hr_flow[:, 0:1] / ((W - 1.0) / 2.0),
+                              hr_flow[:, 1:2] / ((H - 1.0) / 2.0)], 1)).permute(0, 2, 3, 1)
+    warped = F.grid_sample(hr_prev, grid, mode='bilinear', padding_mode='border', align_corners=True)
+    s2d = warped.reshape(n, c, H // scale, scale, W // scale, scale).permute(0, 3, 5, 1, 2, 4) \
+        .reshape(n, scale * scale * c, H // scale, W // scale)
+    ss = O._sub(sd, 'srnet.')
+    out = F.relu(F.conv2d(torch.cat([lr_curr, s2d], 1), ss['conv_in.0.weight'], ss['conv_in.0.bias'],
+                          padding=1))
+    b = 0
+    while f'resblocks.{b}.conv.0.weight' in ss:
+        t = F.relu(F.conv2d(out, ss[f'resblocks.{b}.conv.0.weight'], ss[f'resblocks.{b}.conv.0.bias'],
+                            padding=1))
+        out = F.conv2d(t, ss[f'resblocks.{b}.conv.2.weight'], ss[f'resblocks.{b}.conv.2.bias'],
+                       padding=1) + out
+        b += 1
+    for u in ([0, 2] if scale == 4 else [0]):
+        out = F.relu(F.conv_transpose2d(out, ss[f'conv_up.{u}.weight'], ss[f'conv_up.{u}.bias'],
+                                        stride=2, padding=1, output_padding=1))
+    out = F.conv2d(out, ss['conv_out.weight'], ss['conv_out.bias'], padding=1)
+    return out + up(lr_curr)
 
 
 def main():
@@ -229,6 +312,13 @@ def main():
             result['kernels'] = rows
             result['gpu_ms_per_frame_sum_of_kernels'] = sum(r['ms_per_frame'] for r in rows)
             result['slowest_kernel_class'] = dom['kernel']
+        if world == 1 and args.aten_frames > 0:
+            sd_dev = {k: v.detach() for k, v in net.state_dict().items()}
+            torch.backends.cudnn.benchmark = True          # main.py:216
+            result['aten_gpu_baseline'] = aten_gpu_baseline(sd_dev, s, deg, c, h, w,
+                                                            args.aten_frames, dev)
+            if 'value' in result['aten_gpu_baseline']:
+                result['vs_aten_gpu'] = result['fps_sync_every_frame'] / result['aten_gpu_baseline']['value']
         if world == 1 and args.cpu_frames > 0:
             sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
             result['cpu_baseline'] = cpu_baseline(sd, s, deg, c, h, w, args.cpu_frames,

@@ -229,6 +229,23 @@ int tg_bn_lrelu_train_bwd(const float* x, const float* y, const float* dy,
                           const float* save_invstd, float slope, float* dx,
                           float* dgamma, float* dbeta, int accumulate, float* scratch2c,
                           int n, int c, int hw, tg_stream_t stream);
+/* SyncBatchNorm halves (base_model.py:133): per-channel reductions exposed so the host can
+ * all-reduce the packed vectors over RCCL in between.  sums2c = [sum x | sum x^2] (fwd) or
+ * [sum dz | sum dz*xhat] (bwd), 2*c floats; count / inv_count refer to the GLOBAL batch. */
+int tg_bn_moments(const float* x, float* sums2c, int n, int c, int hw, tg_stream_t stream);
+int tg_bn_finalize_stats(const float* sums2c, float count, float eps, float momentum,
+                         float* mean, float* invstd, float* running_mean,
+                         float* running_var, int c, tg_stream_t stream);
+int tg_bn_lrelu_apply(const float* x, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, float slope, float* y,
+                      int n, int c, int hw, tg_stream_t stream);
+int tg_bn_lrelu_bwd_reduce(const float* x, const float* y, const float* dy,
+                           const float* mean, const float* invstd, float slope,
+                           float* sums2c, int n, int c, int hw, tg_stream_t stream);
+int tg_bn_lrelu_bwd_apply(const float* x, const float* y, const float* dy,
+                          const float* mean, const float* invstd, const float* gamma,
+                          const float* sums2c, float slope, float inv_count, float* dx,
+                          int n, int c, int hw, tg_stream_t stream);
 /* nn.Linear(k, 1) (tecogan_nets.py:375): y[r] = x[r,:].w + b, and backward */
 int tg_linear1_fwd(const float* x, const float* w, const float* b, float* y, int rows,
                    int k, tg_stream_t stream);

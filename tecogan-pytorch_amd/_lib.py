@@ -57,6 +57,11 @@ SIGNATURES = {
     'tg_axpy': (I, [P, P, F, I64, P]),
     'tg_bn_lrelu_train_fwd': (I, [P, P, P, P, P, F, F, F, P, P, P, I, I, I, P]),
     'tg_bn_lrelu_train_bwd': (I, [P, P, P, P, P, P, F, P, P, P, I, P, I, I, I, P]),
+    'tg_bn_moments': (I, [P, P, I, I, I, P]),
+    'tg_bn_finalize_stats': (I, [P, F, F, F, P, P, P, P, I, P]),
+    'tg_bn_lrelu_apply': (I, [P, P, P, P, P, F, P, I, I, I, P]),
+    'tg_bn_lrelu_bwd_reduce': (I, [P, P, P, P, P, F, P, I, I, I, P]),
+    'tg_bn_lrelu_bwd_apply': (I, [P, P, P, P, P, P, P, F, F, P, I, I, I, P]),
     'tg_linear1_fwd': (I, [P, P, P, P, I, I, P]),
     'tg_linear1_bwd': (I, [P, P, P, P, P, P, I, I, I, P]),
     'tg_downsample_bd': (I, [P, P, P, I, I, I, I, I, I, P]),

@@ -569,3 +569,86 @@ extern "C" int tg_downsample_bd(const float* x, const float* kernel2d, float* y,
                      0, ST, x, kernel2d, y, nc, h, w, ksize, scale, pad, oh, ow);
   return tg::check_launch("downsample_bd");
 }
+
+// ---- SyncBatchNorm building blocks (nn.SyncBatchNorm.convert_sync_batchnorm,
+// codes/models/base_model.py:133): the per-channel reductions are exposed separately so
+// the host can all-reduce the packed (sum, sum of squares) / (sum dz, sum dz*xhat) vectors
+// over RCCL between the two halves.  One small all-reduce per BN layer and direction.
+namespace tg {
+__global__ __launch_bounds__(256) void bn_moments_kernel(const float* __restrict__ x, int n, int c,
+                                                         int hw, float* __restrict__ sums2c) {
+  __shared__ float sm[4];
+  int ch = blockIdx.x;
+  float s = 0.f, q = 0.f;
+  for (int b = 0; b < n; ++b) {
+    const float* p = x + ((long long)b * c + ch) * hw;
+    for (int i = threadIdx.x; i < hw; i += 256) { float v = p[i]; s += v; q += v * v; }
+  }
+  float r0 = block_sum(s, sm), r1 = block_sum(q, sm);
+  if (threadIdx.x == 0) { sums2c[ch] = r0; sums2c[c + ch] = r1; }
+}
+// sums2c = global (sum x, sum x^2), count = global element count per channel
+__global__ void bn_finalize_stats_kernel(const float* __restrict__ sums2c, float count, float eps,
+                                         float momentum, float* __restrict__ mean,
+                                         float* __restrict__ invstd, float* __restrict__ run_mean,
+                                         float* __restrict__ run_var, int c) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float m = sums2c[ch] / count;
+  float var = sums2c[c + ch] / count - m * m;
+  var = var < 0.f ? 0.f : var;
+  mean[ch] = m;
+  invstd[ch] = 1.0f / sqrtf(var + eps);
+  if (run_mean) {
+    run_mean[ch] = (1.f - momentum) * run_mean[ch] + momentum * m;
+    run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * (var * count / (count - 1.f));
+  }
+}
+}  // namespace tg
+
+extern "C" int tg_bn_moments(const float* x, float* sums2c, int n, int c, int hw,
+                             tg_stream_t stream) {
+  TG_REQUIRE(x && sums2c && n > 0 && c > 0 && hw > 0, TG_E_ARG, "bn_moments: bad argument");
+  hipLaunchKernelGGL(tg::bn_moments_kernel, dim3(c), dim3(256), 0, ST, x, n, c, hw, sums2c);
+  return tg::check_launch("bn_moments");
+}
+
+extern "C" int tg_bn_finalize_stats(const float* sums2c, float count, float eps, float momentum,
+                                    float* mean, float* invstd, float* running_mean,
+                                    float* running_var, int c, tg_stream_t stream) {
+  TG_REQUIRE(sums2c && mean && invstd && c > 0 && count > 1.f, TG_E_ARG, "bn_finalize_stats: bad argument");
+  hipLaunchKernelGGL(tg::bn_finalize_stats_kernel, dim3(tg::cdiv(c, 256)), dim3(256), 0, ST, sums2c,
+                     count, eps, momentum, mean, invstd, running_mean, running_var, c);
+  return tg::check_launch("bn_finalize_stats");
+}
+
+extern "C" int tg_bn_lrelu_apply(const float* x, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, float slope, float* y,
+                                 int n, int c, int hw, tg_stream_t stream) {
+  TG_REQUIRE(x && mean && invstd && gamma && beta && y, TG_E_ARG, "bn_lrelu_apply: null pointer");
+  long long total = (long long)n * c * hw;
+  hipLaunchKernelGGL(tg::bn_apply_kernel, dim3(tg::grid_for(total)), dim3(256), 0, ST, x, mean, invstd,
+                     gamma, beta, y, total, c, hw, slope);
+  return tg::check_launch("bn_lrelu_apply");
+}
+
+extern "C" int tg_bn_lrelu_bwd_reduce(const float* x, const float* y, const float* dy,
+                                      const float* mean, const float* invstd, float slope,
+                                      float* sums2c, int n, int c, int hw, tg_stream_t stream) {
+  TG_REQUIRE(x && y && dy && mean && invstd && sums2c, TG_E_ARG, "bn_lrelu_bwd_reduce: null pointer");
+  hipLaunchKernelGGL(tg::bn_bwd_reduce_kernel, dim3(c), dim3(256), 0, ST, x, y, dy, mean, invstd, n, c,
+                     hw, slope, sums2c, sums2c + c);
+  return tg::check_launch("bn_lrelu_bwd_reduce");
+}
+
+extern "C" int tg_bn_lrelu_bwd_apply(const float* x, const float* y, const float* dy,
+                                     const float* mean, const float* invstd, const float* gamma,
+                                     const float* sums2c, float slope, float inv_count, float* dx,
+                                     int n, int c, int hw, tg_stream_t stream) {
+  TG_REQUIRE(x && y && dy && mean && invstd && gamma && sums2c && dx, TG_E_ARG,
+             "bn_lrelu_bwd_apply: null pointer");
+  long long total = (long long)n * c * hw;
+  hipLaunchKernelGGL(tg::bn_bwd_apply_kernel, dim3(tg::grid_for(total)), dim3(256), 0, ST, x, y, dy,
+                     mean, invstd, gamma, sums2c, sums2c + c, dx, total, c, hw, slope, inv_count);
+  return tg::check_launch("bn_lrelu_bwd_apply");
+}

@@ -141,14 +141,9 @@ class BaseModel:
         over xGMI when the backend is nccl); payload 10.4 MB (G) / 3.3 MB (D)."""
         if not self.dist:
             return
-        import torch.distributed as dist
         grads = [p.grad for p in net.parameters() if p.requires_grad and p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat)
-        off = 0
-        inv = 1.0 / self.opt['world_size']
-        for g in grads:
-            k = g.numel()
-            g.zero_()
-            ops.axpy_(g.view(-1), flat[off:off + k].contiguous(), inv)
-            off += k
+
+        def scale(dst, src, a):
+            dst.zero_()
+            ops.axpy_(dst.view(-1), src.contiguous(), a)
+        dist_utils.allreduce_mean_(grads, scale_fn=scale)

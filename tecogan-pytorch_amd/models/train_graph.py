@@ -289,9 +289,22 @@ def space_to_depth(tape, x, scale):
     return y
 
 
-def bn_lrelu(tape, bn, x, need_dx=True):
-    """BatchNorm2d (train mode) + LeakyReLU(0.2); bn holds weight/bias/running stats."""
-    y, mean, invstd = ops.bn_lrelu_train_fwd(x, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+def _distributed():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def bn_lrelu(tape, bn, x, need_dx=True, sync=None):
+    """BatchNorm2d (train mode) + LeakyReLU(0.2); bn holds weight/bias/running stats.
+    Under torch.distributed (or sync=True) the statistics are global (SyncBatchNorm)."""
+    if sync is None:
+        sync = _distributed()
+    if sync:
+        y, mean, invstd, count = ops.sync_bn_lrelu_train_fwd(x, bn.weight, bn.bias, bn.running_mean,
+                                                             bn.running_var)
+    else:
+        y, mean, invstd = ops.bn_lrelu_train_fwd(x, bn.weight, bn.bias, bn.running_mean,
+                                                 bn.running_var)
     bn.num_batches_tracked += 1
     if tape is not None:
         def bwd():
@@ -299,9 +312,13 @@ def bn_lrelu(tape, bn, x, need_dx=True):
             if g is None:
                 return
             train = bn.weight.requires_grad
-            dx = ops.bn_lrelu_train_bwd(x, y, g, bn.weight, mean, invstd,
-                                        _grad_buf(bn.weight) if train else None,
-                                        _grad_buf(bn.bias) if train else None, need_dx)
+            gw = _grad_buf(bn.weight) if train else None
+            gb = _grad_buf(bn.bias) if train else None
+            if sync:
+                dx = ops.sync_bn_lrelu_train_bwd(x, y, g, bn.weight, mean, invstd, count, gw, gb,
+                                                 need_dx)
+            else:
+                dx = ops.bn_lrelu_train_bwd(x, y, g, bn.weight, mean, invstd, gw, gb, need_dx)
             if need_dx:
                 tape.add_grad(x, dx)
         tape.record(bwd)

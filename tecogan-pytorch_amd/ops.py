@@ -392,3 +392,60 @@ def downsample_bd(x, kernel2d, scale, pad):
     L.check(L.lib().tg_downsample_bd(x.data_ptr(), kd.data_ptr(), y.data_ptr(), n * c, h, w, ks,
                                      scale, 1 if pad else 0, _stream()), 'tg_downsample_bd')
     return y
+
+
+# ---- SyncBatchNorm (+LeakyReLU): reductions all-reduced over ranks between the halves ----
+def _allreduce_sum_(t):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t)
+        return dist.get_world_size()
+    return 1
+
+
+def sync_bn_lrelu_train_fwd(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5,
+                            slope=0.2):
+    """Same contract as bn_lrelu_train_fwd with statistics over the GLOBAL batch: one
+    all-reduce of the packed (sum, sum^2) vector per layer (equal per-rank batch sizes, as
+    DistributedSampler guarantees)."""
+    _chk(x, 'x')
+    n, c, h, w = x.shape
+    lib = L.lib()
+    sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    L.check(lib.tg_bn_moments(x.data_ptr(), sums.data_ptr(), n, c, h * w, _stream()), 'tg_bn_moments')
+    world = _allreduce_sum_(sums)
+    count = float(n * h * w * world)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+    L.check(lib.tg_bn_finalize_stats(sums.data_ptr(), count, float(eps), float(momentum),
+                                     mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean),
+                                     _ptr(running_var), c, _stream()), 'tg_bn_finalize_stats')
+    y = torch.empty_like(x)
+    L.check(lib.tg_bn_lrelu_apply(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                  beta.data_ptr(), float(slope), y.data_ptr(), n, c, h * w,
+                                  _stream()), 'tg_bn_lrelu_apply')
+    return y, mean, invstd, count
+
+
+def sync_bn_lrelu_train_bwd(x, y, dy, gamma, mean, invstd, count, dgamma=None, dbeta=None,
+                            need_dx=True, slope=0.2):
+    """dgamma/dbeta receive the LOCAL sums (DDP averages parameter gradients afterwards, as
+    SyncBatchNorm does); dx uses the global sums."""
+    n, c, h, w = x.shape
+    lib = L.lib()
+    sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    L.check(lib.tg_bn_lrelu_bwd_reduce(x.data_ptr(), y.data_ptr(), dy.data_ptr(), mean.data_ptr(),
+                                       invstd.data_ptr(), float(slope), sums.data_ptr(), n, c, h * w,
+                                       _stream()), 'tg_bn_lrelu_bwd_reduce')
+    if dgamma is not None:
+        axpy_(dgamma, sums[c:].contiguous(), 1.0)
+        axpy_(dbeta, sums[:c].contiguous(), 1.0)
+    _allreduce_sum_(sums)
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        L.check(lib.tg_bn_lrelu_bwd_apply(x.data_ptr(), y.data_ptr(), dy.data_ptr(), mean.data_ptr(),
+                                          invstd.data_ptr(), gamma.data_ptr(), sums.data_ptr(),
+                                          float(slope), 1.0 / count, dx.data_ptr(), n, c, h * w,
+                                          _stream()), 'tg_bn_lrelu_bwd_apply')
+    return dx

@@ -64,3 +64,26 @@ def reduce_sum_to_master(values, device='cpu'):
     if world > 1:
         dist.reduce(t, dst=0)
     return t
+
+
+def allreduce_mean_(grads, scale_fn=None):
+    """DDP gradient exchange for one network: ONE flat fp32 bucket, all-reduce(SUM), mean
+    written back in place.  With backend nccl this is a single RCCL ring/tree over xGMI
+    (10.4 MB for G, 3.3 MB for D -- latency bound, so one large collective beats the
+    reference's many DDP buckets).  `scale_fn(dst, src_flat_slice, a)` does dst = a * src
+    on the device (HIP axpy); default = torch ops (CPU tensors in the gloo tests)."""
+    rank, world = get_dist_info()
+    if world == 1 or not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    inv = 1.0 / world
+    off = 0
+    for g in grads:
+        k = g.numel()
+        src = flat[off:off + k]
+        if scale_fn is not None:
+            scale_fn(g, src, inv)
+        else:
+            g.copy_(src.view_as(g)).mul_(inv)
+        off += k

@@ -32,9 +32,14 @@ def _worker(rank, world, port, num_seq, out):
         vals[i] = 10.0 + i
     red = D.reduce_sum_to_master(vals)
     tmax = D.max_over_ranks(1.0 + rank)
+    # gradient bucket: rank r holds (r+1) * base; the mean over 2 ranks is 1.5 * base
+    base = [torch.arange(6, dtype=torch.float32).view(2, 3), torch.ones(5), torch.full((1,), 4.0)]
+    grads = [(rank + 1) * b.clone() for b in base]
+    D.allreduce_mean_(grads)
+    gsum = [g.tolist() for g in grads]
     calls = []
     D.master_only(lambda: calls.append(rank))()
-    out[rank] = (mine, red.tolist(), tmax, calls)
+    out[rank] = (mine, red.tolist(), tmax, calls, gsum)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -52,6 +57,8 @@ def test_two_rank_sharding_and_reductions():
     assert a[1] == [10.0 + i for i in range(num_seq)]           # rank 0 holds the full table
     assert a[2] == 2.0 and b[2] == 2.0                          # MAX over ranks everywhere
     assert a[3] == [0] and b[3] == []                           # master_only
+    expect = [[[0.0, 1.5, 3.0], [4.5, 6.0, 7.5]], [1.5] * 5, [6.0]]
+    assert a[4] == expect and b[4] == expect                    # flat-bucket mean, shapes kept
 
 
 def test_single_process_defaults():

@@ -192,3 +192,23 @@ def test_bn_lrelu_and_linear(ops):
     dw, dbb = torch.zeros(1, 1024, device='cuda'), torch.zeros(1, device='cuda')
     dxf = ops.linear1_bwd(dev(xf.detach()), dev(w.detach()), dev(gy), dw, dbb)
     assert relerr(dxf, xf.grad) <= 1e-6 and relerr(dw, w.grad) <= 1e-5 and relerr(dbb, b.grad) <= 1e-6
+
+
+def test_sync_bn_path_equals_fused_bn(ops):
+    """world_size 1: the SyncBatchNorm halves (moments -> finalize -> apply, bwd reduce ->
+    apply) must reproduce the fused single-GPU BatchNorm kernels."""
+    x = dev(rs(1, (4, 16, 9, 7), -2, 2))
+    gamma, beta = dev(1 + 0.2 * rs(2, (16,))), dev(0.1 * rs(3, (16,)))
+    g = dev(rs(4, (4, 16, 9, 7)))
+    rm1, rv1 = torch.zeros(16, device='cuda'), torch.ones(16, device='cuda')
+    rm2, rv2 = torch.zeros(16, device='cuda'), torch.ones(16, device='cuda')
+    y1, m1, i1 = ops.bn_lrelu_train_fwd(x, gamma, beta, rm1, rv1)
+    y2, m2, i2, cnt = ops.sync_bn_lrelu_train_fwd(x, gamma, beta, rm2, rv2)
+    assert cnt == 4 * 9 * 7
+    assert relerr(y2, y1) <= 2e-5 and relerr(m2, m1) <= 1e-5 and relerr(i2, i1) <= 2e-5
+    assert relerr(rm2, rm1) <= 1e-5 and relerr(rv2, rv1) <= 2e-5
+    dg1, db1 = torch.zeros(16, device='cuda'), torch.zeros(16, device='cuda')
+    dg2, db2 = torch.zeros(16, device='cuda'), torch.zeros(16, device='cuda')
+    dx1 = ops.bn_lrelu_train_bwd(x, y1, g, gamma, m1, i1, dg1, db1)
+    dx2 = ops.sync_bn_lrelu_train_bwd(x, y2, g, gamma, m2, i2, cnt, dg2, db2)
+    assert relerr(dx2, dx1) <= 5e-5 and relerr(dg2, dg1) <= 2e-5 and relerr(db2, db1) <= 1e-5

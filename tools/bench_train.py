@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Training-step timing (BASELINE configs[2]/[3]; not the headline metric).
+  python tools/bench_train.py [--crop 256] [--steps 10] [--model TecoGAN]
+One JSON line: steps/s, HR frames/s (= n * 19 / step), per-step ms."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--crop', type=int, default=256)
+    ap.add_argument('--tempo', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--model', default='TecoGAN')
+    a = ap.parse_args()
+    from tecogan_pytorch_amd.models import define_model
+    opt = {
+        'scale': 4, 'dist': False, 'device': 'cuda', 'rank': 0, 'world_size': 1, 'is_train': True,
+        'dataset': {'degradation': {'type': 'BD', 'sigma': 1.5}, 'train': {'crop_size': a.crop}},
+        'model': {'name': a.model,
+                  'generator': {'name': 'FRNet', 'in_nc': 3, 'out_nc': 3, 'nf': 64, 'nb': 10},
+                  'discriminator': {'name': 'STNet', 'in_nc': 3, 'tempo_range': 3}},
+        'train': {'tempo_extent': a.tempo, 'ckpt_dir': '/tmp',
+                  'generator': {'lr': 5e-5, 'betas': [0.9, 0.999]},
+                  'discriminator': {'update_policy': 'adaptive', 'update_threshold': 0.4,
+                                    'crop_border_ratio': 0.75, 'lr': 5e-5, 'betas': [0.9, 0.999]},
+                  'pixel_crit': {'type': 'CB', 'weight': 1, 'reduction': 'mean'},
+                  'warping_crit': {'type': 'CB', 'weight': 1, 'reduction': 'mean'},
+                  'pingpong_crit': {'type': 'CB', 'weight': 0.5, 'reduction': 'mean'},
+                  'gan_crit': {'type': 'GAN', 'weight': 0.01, 'reduction': 'mean'}},
+        'logger': {'decay': 0.99},
+    }
+    if a.model == 'FRVSR':
+        del opt['train']['pingpong_crit'], opt['train']['gan_crit']
+    torch.manual_seed(0)
+    m = define_model(opt)
+    gen = torch.Generator().manual_seed(1)
+    data = [{'gt': torch.rand(a.batch, a.tempo, 3, a.crop + 8, a.crop + 8, generator=gen)}
+            for _ in range(2)]
+    for i in range(a.warmup):
+        m.prepare_training_data(data[i % 2]); m.train()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nupd = 0
+    for i in range(a.steps):
+        m.prepare_training_data(data[i % 2]); m.train()
+        nupd += 1 if m.log_dict.get('l_gan_D', 0) != 0 else 0
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    tt = 2 * a.tempo - 1 if a.model != 'FRVSR' else a.tempo
+    print(json.dumps({'model': a.model, 'crop': a.crop, 'batch': a.batch, 'tempo_extent': a.tempo,
+                      'ms_per_step': 1e3 * dt, 'steps_per_s': 1 / dt,
+                      'hr_frames_per_s': a.batch * tt / dt, 'd_updates': nupd, 'steps': a.steps,
+                      'last_log': {k: float(v) for k, v in m.log_dict.items()},
+                      'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30}))
+
+
+if __name__ == '__main__':
+    main()
