@@ -288,6 +288,15 @@ void tg_frnet_plan_destroy(tg_frnet_plan* plan);
 int tg_frnet_step(tg_frnet_plan* plan, const float* lr_curr, const float* lr_prev,
                   const float* hr_prev, float* hr_out, uint8_t* u8_out,
                   tg_stream_t stream);
+/* The frame in two phases, for clip inference: FNet depends only on the LR frames, so
+ * phase 1 of frame t+1 may run on a second stream while phase 2 of frame t is in flight.
+ *   phases & 1: FNet(lr_curr, lr_prev) -> internal flow slot `flow_slot` (0|1)
+ *   phases & 2: pad/upsample/warp/s2d + SRNet reading that slot -> hr_out (+ u8_out)
+ * The two phases use disjoint workspace regions; the caller orders
+ * phase1(slot) -> phase2(slot) -> next phase1(slot) with stream events. */
+int tg_frnet_step_phase(tg_frnet_plan* plan, int phases, int flow_slot, const float* lr_curr,
+                        const float* lr_prev, const float* hr_prev, float* hr_out,
+                        uint8_t* u8_out, tg_stream_t stream);
 /* number of kernel launches one tg_frnet_step enqueues (for reporting) */
 int tg_frnet_plan_launches(const tg_frnet_plan* plan);
 

@@ -70,6 +70,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_void_p)]),
     'tg_frnet_plan_destroy': (None, [P]),
     'tg_frnet_step': (I, [P, P, P, P, P, P, P]),
+    'tg_frnet_step_phase': (I, [P, I, I, P, P, P, P, P, P]),
     'tg_frnet_plan_launches': (I, [P]),
     'tg_frnet_plan_kinds': (I, []),
     'tg_frnet_kind_name': (C.c_char_p, [I]),

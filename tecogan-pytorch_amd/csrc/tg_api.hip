@@ -26,14 +26,16 @@ struct tg_frnet_plan {
   tg_frnet_cfg cfg;
   std::vector<tg_layer_weights> L;
   float *A, *B, *FLOW, *S2D, *U1, *U2, *PART;
+  float *FA, *FB, *FPART, *FLOW2;   // FNet's own buffers (phase 1 may overlap phase 2 of the previous frame)
   int fh, fw, launches;
   int st_launch[16];
   double st_flops[16], st_bytes[16];
 };
 
+// phase bits: 1 = FNet (lr_curr, lr_prev -> flow slot), 2 = warp + SRNet (flow slot, hr_prev -> hr_out)
 static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
                      const float* hr_prev, float* hr_out, uint8_t* u8_out, tg_stream_t st,
-                     unsigned mask, bool dry);
+                     unsigned mask, bool dry, int phases = 3, int slot = 0);
 
 static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
 
@@ -56,7 +58,7 @@ static size_t fnet_partial_floats(const tg_frnet_cfg* c) {
   return best;
 }
 
-static void carve(const tg_frnet_cfg* c, size_t off[8]) {
+static void carve(const tg_frnet_cfg* c, size_t off[12]) {
   size_t hw = (size_t)c->h * c->w, n = c->n;
   size_t o = 0;
   off[0] = o; o += align64(n * 64 * hw);                       // A
@@ -65,8 +67,12 @@ static void carve(const tg_frnet_cfg* c, size_t off[8]) {
   off[3] = o; o += align64(n * c->scale * c->scale * c->in_nc * hw);  // S2D
   off[4] = o; o += align64(n * c->nf * 4 * hw);                // U1
   off[5] = o; o += (c->scale == 4) ? align64(n * c->nf * 16 * hw) : 0;  // U2
-  off[6] = o; o += align64(fnet_partial_floats(c));            // PART (split-K partial sums)
-  off[7] = o;
+  off[6] = o; o += align64(fnet_partial_floats(c));            // PART (split-K partial sums, SRNet)
+  off[7] = o; o += align64(n * 64 * hw);                       // FA   (FNet ping)
+  off[8] = o; o += align64(n * 64 * hw);                       // FB   (FNet pong)
+  off[9] = o; o += align64(fnet_partial_floats(c));            // FPART (split-K partial sums, FNet)
+  off[10] = o; o += align64(n * 2 * hw);                       // FLOW2 (second flow slot)
+  off[11] = o;
 }
 
 static int cfg_ok(const tg_frnet_cfg* c) {
@@ -78,9 +84,9 @@ static int cfg_ok(const tg_frnet_cfg* c) {
 
 extern "C" size_t tg_frnet_workspace_floats(const tg_frnet_cfg* cfg) {
   if (!cfg_ok(cfg)) return 0;
-  size_t off[8];
+  size_t off[12];
   carve(cfg, off);
-  return off[7];
+  return off[11];
 }
 
 extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weights* layers,
@@ -98,8 +104,10 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   TG_REQUIRE(p, TG_E_ARG, "frnet_plan_create: out of host memory");
   p->cfg = *cfg;
   p->L.assign(layers, layers + n_layers);
-  size_t off[8];
+  size_t off[12];
   carve(cfg, off);
+  p->FA = workspace + off[7]; p->FB = workspace + off[8]; p->FPART = workspace + off[9];
+  p->FLOW2 = workspace + off[10];
   p->PART = workspace + off[6];
   p->A = workspace + off[0]; p->B = workspace + off[1]; p->FLOW = workspace + off[2];
   p->S2D = workspace + off[3]; p->U1 = workspace + off[4];
@@ -137,12 +145,15 @@ enum {
 
 static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
                      const float* hr_prev, float* hr_out, uint8_t* u8_out, tg_stream_t st,
-                     unsigned mask, bool dry) {
+                     unsigned mask, bool dry, int phases, int slot) {
   const tg_frnet_cfg& c = p->cfg;
+  float* const flow_buf = slot ? p->FLOW2 : p->FLOW;
+  bool active = (phases & 1) != 0;     // which phase the launches being issued belong to
+  float* part_buf = p->FPART;
   const int n = c.n, h = c.h, w = c.w, s = c.scale;
   const int64_t hw = (int64_t)h * w;
   int li = 0;
-  float *A = p->A, *B = p->B;
+  float *A = p->FA, *B = p->FB;
   int rc = TG_OK;
   // account + (unless dry / masked out) launch
   auto go = [&](int kind, double flops, double bytes, auto&& fn) {
@@ -151,7 +162,7 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
       p->st_launch[kind] += 1; p->st_flops[kind] += flops; p->st_bytes[kind] += bytes;
       return;
     }
-    if (mask & (1u << kind)) rc = fn();
+    if (active && (mask & (1u << kind))) rc = fn();
   };
   // conv3x3 (+bias+act) [+ MaxPool2d(2,2) when pool]; y receives the final tensor.
   auto conv = [&](const float* x, int64_t xns, int c1, const float* x2, int64_t x2ns, int cin,
@@ -169,10 +180,10 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     if (ks > 1) {
       go(kind, fl, by, [&] {
         return tg::conv3x3_splitk_conv(x, xns, c1, x2, x2ns, lw.w, ocb, n, cin, cout, hh, ww, ks,
-                                       p->PART, st);
+                                       part_buf, st);
       });
       go(K_FINAL, 0, 4.0 * px * cout * (ks + 1), [&] {
-        return tg::conv3x3_splitk_finalize(p->PART, ks, lw.b, act, pool ? 1 : 0, y, n, cout, hh, ww,
+        return tg::conv3x3_splitk_finalize(part_buf, ks, lw.b, act, pool ? 1 : 0, y, n, cout, hh, ww,
                                            st);
       });
       return;
@@ -229,15 +240,17 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     float* ai = A; int fh_ = hh, fw_ = ww;
     go(K_SMALL, 2.0 * 32 * 9 * 2 * n * fh_ * fw_, 4.0 * n * fh_ * fw_ * 34, [&] {
       return tg_conv3x3_small_fwd(ai, (int64_t)32 * fh_ * fw_, lw.w, lw.b, nullptr, TG_UP_NONE, 1,
-                                  p->FLOW, (int64_t)2 * fh_ * fw_, n, 32, 2, fh_, fw_,
+                                  flow_buf, (int64_t)2 * fh_ * fw_, n, 32, 2, fh_, fw_,
                                   TG_ACT_TANH24, st);
     });
   }
   // ---- pad + upsample + warp + space_to_depth (tecogan_nets.py:238-250) -------
+  active = (phases & 2) != 0;
+  part_buf = p->PART;
   const int s2dc = s * s * c.in_nc;
   go(K_WARP, 0,
      4.0 * n * ((double)c.in_nc * s * s * hw * 2 + 2.0 * p->fh * p->fw), [&] {
-       return tg_flowup_warp_s2d_fwd(p->FLOW, p->fh, p->fw, hr_prev, p->S2D, s2dc * hw, nullptr, n,
+       return tg_flowup_warp_s2d_fwd(flow_buf, p->fh, p->fw, hr_prev, p->S2D, s2dc * hw, nullptr, n,
                                      c.in_nc, h, w, s, c.up_mode, st);
      });
   // ---- SRNet (tecogan_nets.py:136-147) ----------------------------------------
@@ -294,6 +307,19 @@ extern "C" int tg_frnet_step_masked(tg_frnet_plan* p, const float* lr_curr, cons
   TG_REQUIRE(p && lr_curr && lr_prev && hr_prev && hr_out, TG_E_ARG, "frnet_step: null pointer");
   TG_REQUIRE(!u8_out || p->cfg.n == 1, TG_E_ARG, "frnet_step: u8 output needs n == 1");
   return step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, u8_out, st, kind_mask, false);
+}
+
+extern "C" int tg_frnet_step_phase(tg_frnet_plan* p, int phases, int flow_slot, const float* lr_curr,
+                                   const float* lr_prev, const float* hr_prev, float* hr_out,
+                                   uint8_t* u8_out, tg_stream_t st) {
+  TG_REQUIRE(p && lr_curr, TG_E_ARG, "frnet_step_phase: null pointer");
+  TG_REQUIRE(phases >= 1 && phases <= 3 && (flow_slot == 0 || flow_slot == 1), TG_E_ARG,
+             "frnet_step_phase: phases=%d slot=%d", phases, flow_slot);
+  TG_REQUIRE(!(phases & 1) || lr_prev, TG_E_ARG, "frnet_step_phase: phase 1 needs lr_prev");
+  TG_REQUIRE(!(phases & 2) || (hr_prev && hr_out), TG_E_ARG, "frnet_step_phase: phase 2 needs hr_prev/hr_out");
+  TG_REQUIRE(!u8_out || p->cfg.n == 1, TG_E_ARG, "frnet_step_phase: u8 output needs n == 1");
+  return step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, u8_out, st, 0xFFFFFFFFu, false, phases,
+                   flow_slot);
 }
 
 extern "C" int tg_frnet_plan_kinds(void) { return K_COUNT; }

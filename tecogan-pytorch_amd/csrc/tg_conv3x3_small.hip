@@ -189,6 +189,131 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmallArgs a) {
   }
 }
 
+
+// ---- v2: 16-byte staging (needs w % 4 == 0 and 16-byte aligned planes) -----------------
+// The LDS patch of a channel covers image columns [x0-4, x0+68): whole float4s, so every
+// global access is one bounds-checked buffer_load_dwordx4 (out-of-image quads read as 0)
+// written back with one ds_write_b128; a thread's six taps of a row are two b128 + one b32.
+constexpr int V_Q = 18;                 // float4 per patch row (72 columns)
+constexpr int V_RS = 76;                // LDS row stride in floats (19 slots: odd)
+constexpr int V_CK = 4;
+constexpr int V_ITEMS = V_CK * S_PH * V_Q;          // 1296 float4 per chunk
+constexpr int V_PER_T = (V_ITEMS + 255) / 256;      // 6
+constexpr unsigned V_OOB = 0x80000000u;
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_in[2][V_CK][S_PH][V_RS];
+  __shared__ float s_w[COUT * 9 * 64];   // [cin][tap][COUT]
+
+  const int tid = threadIdx.x;
+  const int tcx = tid % S_TWT, tcy = tid / S_TWT;
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int x0 = tx * S_TW, y0 = ty * S_TH;
+  const int hw = a.h * a.w;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (long long)n * a.x_ns), 0, a.cin * hw * 4, 0x00020000);
+
+  for (int i = tid; i < a.cin * 9 * COUT; i += 256) {
+    int o = i % COUT, t = (i / COUT) % 9, c = i / (COUT * 9);
+    s_w[i] = a.wt[((size_t)o * a.cin + c) * 9 + t];
+  }
+
+  // per-thread staging slots (fixed for the whole kernel)
+  unsigned voff[V_PER_T];
+  int lds_off[V_PER_T];
+#pragma unroll
+  for (int i = 0; i < V_PER_T; ++i) {
+    int idx = tid + i * 256;
+    int c = idx / (S_PH * V_Q), rem = idx - c * (S_PH * V_Q);
+    int r = rem / V_Q, q = rem - r * V_Q;
+    int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
+    bool ok = idx < V_ITEMS && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+    voff[i] = ok ? (unsigned)((c * hw + gy * a.w + gx) * 4) : V_OOB;
+    lds_off[i] = idx < V_ITEMS ? (c * S_PH + r) * V_RS + 4 * q : -1;
+  }
+  const unsigned plane = (unsigned)hw * 4u;
+  f32x4 rin[V_PER_T];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < V_PER_T; ++i) {
+      // channels past cin fall beyond num_records and read as 0
+      rin[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rsrc, (int)(voff[i] + (unsigned)c0 * plane), 0, 0));
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* base = &s_in[buf][0][0][0];
+#pragma unroll
+    for (int i = 0; i < V_PER_T; ++i)
+      if (lds_off[i] >= 0) *reinterpret_cast<f32x4*>(base + lds_off[i]) = rin[i];
+  };
+
+  float acc[COUT][S_PXT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o)
+#pragma unroll
+    for (int p = 0; p < S_PXT; ++p) acc[o][p] = 0.f;
+
+  const int nchunk = cdiv(a.cin, V_CK);
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    const bool more = ch + 1 < nchunk;
+    if (more) load_chunk((ch + 1) * V_CK);
+#pragma unroll
+    for (int c = 0; c < V_CK; ++c) {
+      const int cg = ch * V_CK + c;
+      if (cg < a.cin) {
+        const float* wc = s_w + cg * 9 * COUT;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* row = &s_in[buf][c][tcy + ky][tcx * S_PXT];
+          f32x4 v0 = *reinterpret_cast<const f32x4*>(row);
+          f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 4);
+          float v2 = row[8];
+          float in6[6] = {v0[3], v1[0], v1[1], v1[2], v1[3], v2};
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+              float wv = wc[(ky * 3 + kx) * COUT + o];
+#pragma unroll
+              for (int p = 0; p < S_PXT; ++p) acc[o][p] += wv * in6[p + kx];
+            }
+          }
+        }
+      }
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int py = y0 + tcy;
+  const int px0 = x0 + tcx * S_PXT;
+  if (py < a.h && px0 < a.w) {          // w % 4 == 0: the four pixels are all inside
+    float v[S_PXT][COUT];
+#pragma unroll
+    for (int p = 0; p < S_PXT; ++p) {
+#pragma unroll
+      for (int o = 0; o < COUT; ++o)
+        v[p][o] = apply_act(acc[o][p] + (a.bias ? a.bias[o] : 0.f), a.act);
+      if (a.up) add_upsampled<COUT>(a, n, py, px0 + p, v[p]);
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+      f32x4 ov = {v[0][o], v[1][o], v[2][o], v[3][o]};
+      *reinterpret_cast<f32x4*>(a.y + (long long)n * a.y_ns + (long long)o * hw +
+                                (long long)py * a.w + px0) = ov;
+    }
+  }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -216,6 +341,18 @@ extern "C" int tg_conv3x3_small_fwd(const float* x, int64_t x_nstride, const flo
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "conv3x3_small: grid %lld", blocks);
   dim3 g((unsigned)blocks), t(256);
   hipStream_t s = (hipStream_t)stream;
+  const bool vec_ok = (w % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
+                      (x_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
+                      ((long long)(cin + 4) * h * w * 4 < (1ll << 31));
+  if (vec_ok) {
+    switch (cout) {
+      case 1: hipLaunchKernelGGL(conv3x3_small_v2_kernel<1>, g, t, 0, s, a); break;
+      case 2: hipLaunchKernelGGL(conv3x3_small_v2_kernel<2>, g, t, 0, s, a); break;
+      case 3: hipLaunchKernelGGL(conv3x3_small_v2_kernel<3>, g, t, 0, s, a); break;
+      default: hipLaunchKernelGGL(conv3x3_small_v2_kernel<4>, g, t, 0, s, a); break;
+    }
+    return check_launch("conv3x3_small_v2");
+  }
   switch (cout) {
     case 1: hipLaunchKernelGGL(conv3x3_small_kernel<1>, g, t, 0, s, a); break;
     case 2: hipLaunchKernelGGL(conv3x3_small_kernel<2>, g, t, 0, s, a); break;

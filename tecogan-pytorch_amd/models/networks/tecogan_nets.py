@@ -271,11 +271,15 @@ class FRNet(nn.Module):
                                   self.srnet.up_mode())
         return self.srnet(lr_curr, s2d)
 
-    def infer_sequence(self, lr_data, device):
+    def infer_sequence(self, lr_data, device, pipeline=True, return_device_tensor=False):
         """lr_data: (t,c,h,w) fp32 (host or device) -> (t, s*h, s*w, c) uint8
         numpy, zero initial state (tecogan_nets.py:254-281).  The whole clip is
         uploaded once, frames are quantised on the device, and there is one
-        host synchronisation at the end instead of one per frame."""
+        host synchronisation at the end instead of one per frame.
+
+        pipeline=True: FNet depends only on the LR frames, so FNet(t+1) runs on a
+        second HIP stream while warp+SRNet(t) runs on the first (two flow slots,
+        ordered by events); the serial part of the recurrence is SRNet alone."""
         tot_frm, c, h, w = lr_data.size()
         s = self.scale
         dev = torch.device(device) if device is not None else lr_data.device
@@ -285,10 +289,42 @@ class FRNet(nn.Module):
               torch.empty(1, c, s * h, s * w, dtype=torch.float32, device=dev)]
         u8 = torch.empty(tot_frm, s * h, s * w, c, dtype=torch.uint8, device=dev)
         with torch.no_grad():
-            for i in range(tot_frm):
-                lr_prev = zeros_lr if i == 0 else lr[i - 1:i]
-                self.step(lr[i:i + 1], lr_prev, hr[i & 1], out=hr[(i + 1) & 1], u8_out=u8[i])
+            if not pipeline or tot_frm < 2:
+                for i in range(tot_frm):
+                    lr_prev = zeros_lr if i == 0 else lr[i - 1:i]
+                    self.step(lr[i:i + 1], lr_prev, hr[i & 1], out=hr[(i + 1) & 1], u8_out=u8[i])
+            else:
+                plan = self._get_plan(1, h, w, dev)
+                lib = L.lib()
+                main = torch.cuda.current_stream(dev)
+                side = self._side_stream(dev)
+                side.wait_stream(main)                      # inputs / weights are ready
+                ev_f = [torch.cuda.Event() for _ in range(tot_frm)]
+                ev_s = [torch.cuda.Event() for _ in range(tot_frm)]
+                for i in range(tot_frm):
+                    lr_prev = zeros_lr if i == 0 else lr[i - 1:i]
+                    if i >= 2:
+                        side.wait_event(ev_s[i - 2])        # flow slot i&1 consumed by frame i-2
+                    L.check(lib.tg_frnet_step_phase(plan.handle, 1, i & 1, lr[i:i + 1].data_ptr(),
+                                                    lr_prev.data_ptr(), None, None, None,
+                                                    side.cuda_stream), 'tg_frnet_step_phase(1)')
+                    ev_f[i].record(side)
+                    main.wait_event(ev_f[i])
+                    L.check(lib.tg_frnet_step_phase(plan.handle, 2, i & 1, lr[i:i + 1].data_ptr(),
+                                                    None, hr[i & 1].data_ptr(),
+                                                    hr[(i + 1) & 1].data_ptr(), u8[i].data_ptr(),
+                                                    main.cuda_stream), 'tg_frnet_step_phase(2)')
+                    ev_s[i].record(main)
+                main.wait_stream(side)
+        if return_device_tensor:
+            return u8
         return u8.cpu().numpy()
+
+    def _side_stream(self, dev):
+        st = getattr(self, '_side', None)
+        if st is None or st.device != dev:
+            st = self._side = torch.cuda.Stream(device=dev)
+        return st
 
     def forward_sequence(self, lr_data):
         """Training unroll (tecogan_nets.py:174-225): lr_data (n,t,c,h,w) -> dict with

@@ -278,6 +278,16 @@ def test_infer_sequence_u8_vs_reference(golden, deg, s):
         assert p == np.inf or p > 60
 
 
+def test_pipelined_clip_inference_is_bit_identical():
+    """FNet(t+1) on a second stream overlapping SRNet(t) must not change a single bit."""
+    net, _ = make_net('BD', 4)
+    clip = smooth_clip(9, 3, 40, 64, seed=4)
+    a = net.infer_sequence(clip, 'cuda', pipeline=False)
+    for _ in range(3):
+        b = net.infer_sequence(clip, 'cuda', pipeline=True)
+        assert np.array_equal(a, b)
+
+
 # --------------------------------------------------- BASELINE full-size checks
 def test_fullsize_A_digest_vs_reference(golden):
     """config 1/2 shape: 4xBD, LR 1x3x134x320, seeded uniform inputs."""
