@@ -78,17 +78,15 @@ def kernel_table(net, plan, bufs, reps=20):
             continue
         mask = 1 << k
 
-        def run():
-            L.check(lib.tg_frnet_step_masked(plan.handle, lr_c.data_ptr(), lr_p.data_ptr(),
-                                             hr_p.data_ptr(), out.data_ptr(), None, mask, stream),
-                    'step_masked')
-        for _ in range(3):
-            run()
+        def run(r):
+            L.check(lib.tg_frnet_replay(plan.handle, lr_c.data_ptr(), lr_p.data_ptr(),
+                                        hr_p.data_ptr(), out.data_ptr(), mask, r, stream),
+                    'tg_frnet_replay')
+        run(3)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        for _ in range(reps):
-            run()
+        run(reps)                 # all replays enqueued by ONE C call: no host gap per replay
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
@@ -97,6 +95,22 @@ def kernel_table(net, plan, bufs, reps=20):
                          tflops=(fl.value / 1e12) / (ms / 1e3) if fl.value else None,
                          gbs=(by.value / 1e9) / (ms / 1e3)))
     return rows
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json, written by tools/summarize_pmc.py); None if absent."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        want = kernel.replace(' ', '').rstrip('>')
+        for k, v in table.items():
+            if k.replace(' ', '').replace('tg::', '').startswith(want):
+                return v
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(sd, scale, deg, c, h, w, max_frames, max_seconds):
@@ -324,7 +338,7 @@ def main():
             ach = dom_mf['tflops']
             result['roofline'] = {
                 'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic(dom_mf['kernel']),
                 'kernel': dom_mf['kernel'], 'launches_per_frame': dom_mf['launches'],
                 'avg_launch_us': 1e3 * dom_mf['ms_per_frame'] / dom_mf['launches'],
                 'algorithmic_gflop_per_launch': dom_mf['gflop'] / dom_mf['launches'],
@@ -334,7 +348,7 @@ def main():
                 wk = warp[0]
                 result['roofline_warp'] = {
                     'bound': 'hbm', 'achieved': wk['gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': wk['gbs'] / HBM_PEAK_GBS, 'traffic': None,
+                    'frac': wk['gbs'] / HBM_PEAK_GBS, 'traffic': pmc_traffic(wk['kernel']),
                     'kernel': wk['kernel'], 'avg_launch_us': 1e3 * wk['ms_per_frame'],
                     'algorithmic_mbytes_per_launch': wk['mbytes']}
             result['kernels'] = rows

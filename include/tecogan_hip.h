@@ -310,6 +310,9 @@ int tg_frnet_plan_kinds(void);
 const char* tg_frnet_kind_name(int kind);
 int tg_frnet_plan_kind_stats(const tg_frnet_plan* plan, int kind, int* launches,
                              double* flops, double* bytes);
+int tg_frnet_replay(tg_frnet_plan* plan, const float* lr_curr, const float* lr_prev,
+                    const float* hr_prev, float* hr_out, unsigned kind_mask, int reps,
+                    tg_stream_t stream);
 int tg_frnet_step_masked(tg_frnet_plan* plan, const float* lr_curr, const float* lr_prev,
                          const float* hr_prev, float* hr_out, uint8_t* u8_out,
                          unsigned kind_mask, tg_stream_t stream);

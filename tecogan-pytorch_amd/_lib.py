@@ -76,6 +76,7 @@ SIGNATURES = {
     'tg_frnet_kind_name': (C.c_char_p, [I]),
     'tg_frnet_plan_kind_stats': (I, [P, I, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]),
+    'tg_frnet_replay': (I, [P, P, P, P, P, C.c_uint, I, P]),
     'tg_frnet_step_masked': (I, [P, P, P, P, P, P, C.c_uint, P]),
 }
 

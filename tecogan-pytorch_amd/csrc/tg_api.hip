@@ -322,6 +322,20 @@ extern "C" int tg_frnet_step_phase(tg_frnet_plan* p, int phases, int flow_slot, 
                    flow_slot);
 }
 
+// measurement helper: enqueue the masked launch list `reps` times from C (no host round
+// trip per replay, so single-launch kernel classes are timed GPU-bound)
+extern "C" int tg_frnet_replay(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
+                               const float* hr_prev, float* hr_out, unsigned kind_mask, int reps,
+                               tg_stream_t st) {
+  TG_REQUIRE(p && lr_curr && lr_prev && hr_prev && hr_out && reps > 0, TG_E_ARG,
+             "frnet_replay: bad argument");
+  for (int i = 0; i < reps; ++i) {
+    int rc = step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, nullptr, st, kind_mask, false);
+    if (rc != TG_OK) return rc;
+  }
+  return TG_OK;
+}
+
 extern "C" int tg_frnet_plan_kinds(void) { return K_COUNT; }
 
 extern "C" const char* tg_frnet_kind_name(int kind) {
