@@ -74,7 +74,11 @@ class BaseModel:
         return net.to(self.device)
 
     def update_learning_rate(self):
-        pass        # shipped TecoGAN configs use a fixed learning rate
+        """base_model.py:138-143."""
+        for name in ('sched_G', 'sched_D'):
+            sched = getattr(self, name, None)
+            if sched is not None:
+                sched.step()
 
     def get_learning_rate(self):
         d = OrderedDict()

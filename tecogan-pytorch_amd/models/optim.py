@@ -47,3 +47,61 @@ def define_criterion(criterion_opt):
     if criterion_opt['type'] == 'GAN':
         return ('GAN', criterion_opt.get('reduction', 'mean'))
     raise ValueError(f'Unrecognized criterion: {criterion_opt["type"]}')
+
+
+class _Schedule:
+    """Closed-form learning-rate schedules (host arithmetic on the optimiser's `lr`)."""
+
+    def __init__(self, optimizer):
+        self.optimizer = optimizer
+        self.base_lr = optimizer.param_groups[0]['lr']
+        self.last_epoch = 0
+
+    def lr_at(self, it):
+        raise NotImplementedError
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.param_groups[0]['lr'] = self.lr_at(self.last_epoch)
+
+
+class MultiStepLR(_Schedule):
+    """lr = base * gamma ** (number of milestones <= iteration), as torch's MultiStepLR
+    (selected by the shipped FRVSR ymls)."""
+
+    def __init__(self, optimizer, milestones, gamma):
+        super().__init__(optimizer)
+        self.milestones, self.gamma = sorted(milestones), gamma
+
+    def lr_at(self, it):
+        return self.base_lr * self.gamma ** sum(1 for m in self.milestones if m <= it)
+
+
+class CosineAnnealingRestartLR(_Schedule):
+    """eta_min + w * 0.5 * (base - eta_min) * (1 + cos(pi * (it - restart) / period))
+    (codes/models/optim/lr_schedules.py:30-78)."""
+
+    def __init__(self, optimizer, periods, restart_weights=(1,), eta_min=0):
+        super().__init__(optimizer)
+        assert len(periods) == len(restart_weights)
+        self.periods, self.weights, self.eta_min = list(periods), list(restart_weights), eta_min
+        self.cum = [sum(self.periods[:i + 1]) for i in range(len(self.periods))]
+
+    def lr_at(self, it):
+        import math
+        idx = next((i for i, p in enumerate(self.cum) if it <= p), len(self.cum) - 1)
+        restart = 0 if idx == 0 else self.cum[idx - 1]
+        return self.eta_min + self.weights[idx] * 0.5 * (self.base_lr - self.eta_min) * (
+            1 + math.cos(math.pi * ((it - restart) / self.periods[idx])))
+
+
+def define_lr_schedule(schedule_opt, optimizer):
+    """codes/models/optim/__init__.py:38-62."""
+    if schedule_opt is None or schedule_opt['type'] == 'FixedLR':
+        return None
+    if schedule_opt['type'] == 'MultiStepLR':
+        return MultiStepLR(optimizer, schedule_opt['milestones'], schedule_opt['gamma'])
+    if schedule_opt['type'] == 'CosineAnnealingRestartLR':
+        return CosineAnnealingRestartLR(optimizer, schedule_opt['periods'],
+                                        schedule_opt['restart_weights'], schedule_opt['eta_min'])
+    raise ValueError(f'Unrecognized lr schedule: {schedule_opt["type"]}')

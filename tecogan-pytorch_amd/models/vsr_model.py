@@ -8,7 +8,7 @@ from .. import ops
 from . import train_graph as TG
 from .base_model import BaseModel
 from .networks import define_generator
-from .optim import Adam, define_criterion
+from .optim import Adam, define_criterion, define_lr_schedule
 
 
 class VSRModel(BaseModel):
@@ -33,6 +33,7 @@ class VSRModel(BaseModel):
         g = self.opt['train']['generator']
         self.optim_G = Adam(self.net_G.parameters(), lr=g['lr'],
                             weight_decay=g.get('weight_decay', 0), betas=g.get('betas', (0.9, 0.999)))
+        self.sched_G = define_lr_schedule(g.get('lr_schedule'), self.optim_G)
 
     # -- loss helpers (value accumulates on the device; gradient returned) -----
     @staticmethod

@@ -9,7 +9,7 @@ import torch
 from .. import ops
 from . import train_graph as TG
 from .networks import define_discriminator
-from .optim import Adam, define_criterion
+from .optim import Adam, define_criterion, define_lr_schedule
 from .vsr_model import VSRModel
 
 
@@ -42,6 +42,7 @@ class VSRGANModel(VSRModel):
         d = self.opt['train']['discriminator']
         self.optim_D = Adam(self.net_D.parameters(), lr=d['lr'],
                             weight_decay=d.get('weight_decay', 0), betas=d.get('betas', (0.9, 0.999)))
+        self.sched_D = define_lr_schedule(d.get('lr_schedule'), self.optim_D)
 
     def _sync_scalars(self, real_stats, fake_stats):
         """mean log-sigmoid of both passes, agreed across ranks with ONE 2-float

@@ -101,3 +101,35 @@ def test_default_init_statistics_match_torch_conv():
     w = net.srnet.resblocks[0].conv['0'].weight
     bound = 1 / (64 * 9) ** 0.5
     assert w.abs().max() <= bound + 1e-7 and w.std() > 0.5 * bound
+
+
+def test_lr_schedules_match_torch():
+    """MultiStepLR (FRVSR ymls) and CosineAnnealingRestartLR closed forms vs torch's own."""
+    import math
+    from tecogan_pytorch_amd.models.optim import MultiStepLR, CosineAnnealingRestartLR, define_lr_schedule
+
+    class Opt:
+        def __init__(self, lr):
+            self.param_groups = [{'lr': lr}]
+    mine = Opt(1e-4)
+    sch = define_lr_schedule({'type': 'MultiStepLR', 'milestones': [3, 7], 'gamma': 0.5}, mine)
+    p = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.SGD([p], lr=1e-4)
+    ref = torch.optim.lr_scheduler.MultiStepLR(ref_opt, milestones=[3, 7], gamma=0.5)
+    for _ in range(10):
+        sch.step(); ref_opt.step(); ref.step()
+        assert abs(mine.param_groups[0]['lr'] - ref_opt.param_groups[0]['lr']) < 1e-12
+    mine = Opt(2e-4)
+    cs = CosineAnnealingRestartLR(mine, [4, 4], [1, 0.5], 1e-7)
+    exp = []
+    for it in range(1, 9):
+        idx = 0 if it <= 4 else 1
+        restart = 0 if idx == 0 else 4
+        exp.append(1e-7 + [1, 0.5][idx] * 0.5 * (2e-4 - 1e-7) * (1 + math.cos(math.pi * (it - restart) / 4)))
+    got = []
+    for _ in range(8):
+        cs.step(); got.append(mine.param_groups[0]['lr'])
+    assert np.allclose(got, exp, rtol=1e-12)
+    assert define_lr_schedule({'type': 'FixedLR'}, mine) is None
+    with pytest.raises(ValueError):
+        define_lr_schedule({'type': 'Nope'}, mine)
