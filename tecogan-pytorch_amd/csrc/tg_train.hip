@@ -90,40 +90,74 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
   }
 }
 
-// transpose of tg_upsample_fwd: dx (nc,h,w) += scatter of mul * dy (nc, s*h, s*w).  dx pre-zeroed.
+// transpose of tg_upsample_fwd in GATHER form (deterministic, no atomics):
+//   dx[r][c] = mul * sum over the outputs (oy, ox) whose stencil touches input (r, c).
+// bicubic: output row oy = s*i + d uses inputs clamp(i-1+p), p = 0..3, so input r is reached only
+// from i in [r-2, r+1] (the clamped border taps fall in the same window); bilinear: output oy uses
+// y0 = floor(src), y1 = min(y0+1, h-1), so input r is reached from oy in [s*(r-1), s*(r+1)+s).
 __global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int nc,
                                     int h, int w, int s, int mode, float mul) {
   const int oh = h * s, ow = w * s;
-  const long long total = (long long)nc * oh * ow;
-  TG_GRID_STRIDE(i, total) {
-    int ox = (int)(i % ow); long long t = i / ow;
-    int oy = (int)(t % oh); int p = (int)(t / oh);
-    float g = mul * dy[i];
-    float* dst = dx + (long long)p * h * w;
+  const long long total = (long long)nc * h * w;
+  TG_GRID_STRIDE(idx, total) {
+    int c = (int)(idx % w); long long t = idx / w;
+    int r = (int)(t % h); int p = (int)(t / h);
+    const float* g = dy + (long long)p * oh * ow;
+    float acc = 0.f;
     if (mode == TG_UP_BICUBIC) {
-      int ii = oy / s, dyy = oy - ii * s, jj = ox / s, dxx = ox - jj * s;
-      float ky[4], kx[4];
-      bicubic_w(dyy, s, ky);
-      bicubic_w(dxx, s, kx);
+      // per-axis weight of output o on this input: sum of the taps that clamp onto it
+      for (int i = r - 2; i <= r + 1; ++i) {
+        if (i < 0 || i >= h) continue;
+        for (int d = 0; d < s; ++d) {
+          float ky[4];
+          bicubic_w(d, s, ky);
+          float wy = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int cq = jj - 1 + q; cq = cq < 0 ? 0 : (cq > w - 1 ? w - 1 : cq);
+          for (int pp = 0; pp < 4; ++pp) {
+            int rp = i - 1 + pp; rp = rp < 0 ? 0 : (rp > h - 1 ? h - 1 : rp);
+            if (rp == r) wy += ky[pp];
+          }
+          if (wy == 0.f) continue;
+          const float* grow = g + (long long)(i * s + d) * ow;
+          float rowacc = 0.f;
+          for (int j = c - 2; j <= c + 1; ++j) {
+            if (j < 0 || j >= w) continue;
+            for (int e = 0; e < s; ++e) {
+              float kx[4];
+              bicubic_w(e, s, kx);
+              float wx = 0.f;
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-          int rp = ii - 1 + pp; rp = rp < 0 ? 0 : (rp > h - 1 ? h - 1 : rp);
-          float wgt = kx[q] * ky[pp];
-          if (wgt != 0.f) atomicAdd(dst + rp * w + cq, g * wgt);
+              for (int q = 0; q < 4; ++q) {
+                int cq = j - 1 + q; cq = cq < 0 ? 0 : (cq > w - 1 ? w - 1 : cq);
+                if (cq == c) wx += kx[q];
+              }
+              if (wx != 0.f) rowacc += wx * grow[j * s + e];
+            }
+          }
+          acc += wy * rowacc;
         }
       }
     } else {
-      int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
-      bilinear_src(oy, s, h, y0, y1, ly0, ly1);
-      bilinear_src(ox, s, w, x0, x1, lx0, lx1);
-      atomicAdd(dst + y0 * w + x0, g * ly0 * lx0);
-      atomicAdd(dst + y0 * w + x1, g * ly0 * lx1);
-      atomicAdd(dst + y1 * w + x0, g * ly1 * lx0);
-      atomicAdd(dst + y1 * w + x1, g * ly1 * lx1);
+      int oy_lo = s * (r - 1), oy_hi = s * (r + 2);
+      int ox_lo = s * (c - 1), ox_hi = s * (c + 2);
+      oy_lo = oy_lo < 0 ? 0 : oy_lo; oy_hi = oy_hi > oh ? oh : oy_hi;
+      ox_lo = ox_lo < 0 ? 0 : ox_lo; ox_hi = ox_hi > ow ? ow : ox_hi;
+      for (int oy = oy_lo; oy < oy_hi; ++oy) {
+        int y0, y1; float ly0, ly1;
+        bilinear_src(oy, s, h, y0, y1, ly0, ly1);
+        float wy = (y0 == r ? ly0 : 0.f) + (y1 == r ? ly1 : 0.f);
+        if (wy == 0.f) continue;
+        float rowacc = 0.f;
+        for (int ox = ox_lo; ox < ox_hi; ++ox) {
+          int x0, x1; float lx0, lx1;
+          bilinear_src(ox, s, w, x0, x1, lx0, lx1);
+          float wx = (x0 == c ? lx0 : 0.f) + (x1 == c ? lx1 : 0.f);
+          if (wx != 0.f) rowacc += wx * g[(long long)oy * ow + ox];
+        }
+        acc += wy * rowacc;
+      }
     }
+    dx[idx] = mul * acc;
   }
 }
 
@@ -409,10 +443,8 @@ extern "C" int tg_upsample_bwd(const float* dy, float* dx, int nc, int h, int w,
                                int up_mode, float mul, tg_stream_t stream) {
   TG_REQUIRE(dy && dx && nc > 0 && h > 0 && w > 0 && scale >= 1, TG_E_ARG, "upsample_bwd: bad argument");
   TG_REQUIRE(up_mode == TG_UP_BICUBIC || up_mode == TG_UP_BILINEAR, TG_E_ARG, "upsample_bwd: mode");
-  hipError_t e = hipMemsetAsync(dx, 0, (size_t)nc * h * w * sizeof(float), ST);
-  TG_REQUIRE(e == hipSuccess, TG_E_HIP, "upsample_bwd: memset: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((long long)nc * h * scale * w * scale, 8192)),
-                     dim3(256), 0, ST, dy, dx, nc, h, w, scale, up_mode, mul);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((long long)nc * h * w, 8192)), dim3(256), 0,
+                     ST, dy, dx, nc, h, w, scale, up_mode, mul);
   return check_launch("upsample_bwd");
 }
 

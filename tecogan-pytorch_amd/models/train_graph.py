@@ -23,6 +23,8 @@ class Tape:
         self.nodes = []
         self.grads = {}
         self.keep = []          # tensors that must outlive backward (id() stability)
+        self.deferred = {}
+        self.deferred_bias = {}
 
     # -- gradient bookkeeping -------------------------------------------------
     def add_grad(self, t, g):
@@ -48,6 +50,37 @@ class Tape:
         for fn in reversed(self.nodes):
             fn()
         self.nodes = []
+        self.flush_deferred()
+
+    # -- deferred parameter gradients -------------------------------------------
+    # A layer is applied once per unrolled frame (19x for SRNet), each time on a small
+    # image.  Its weight gradient is a sum over all applications, so the (dZ, X) pairs
+    # are collected during the reverse sweep and reduced by ONE wgrad launch per layer
+    # over the concatenated batch: 19x fewer launches / split-K reductions, and enough
+    # pixel tiles per launch to fill the GPU.
+    def defer_wgrad(self, key, p, q, target, cb_off=0, post=None):
+        ent = self.deferred.setdefault(key, {'p': [], 'q': [], 'target': target, 'cb_off': cb_off,
+                                             'post': post})
+        ent['p'].append(p)
+        ent['q'].append(q)
+
+    def defer_bias(self, buf, dz):
+        self.deferred_bias.setdefault(id(buf), (buf, []))[1].append(dz)
+
+    def flush_deferred(self):
+        for ent in self.deferred.values():
+            P = ent['p'][0] if len(ent['p']) == 1 else torch.cat(ent['p'], 0)
+            Q = ent['q'][0] if len(ent['q']) == 1 else torch.cat(ent['q'], 0)
+            if ent['post'] is None:
+                ops.wgrad3x3(P, Q, ent['target'], cb_off=ent['cb_off'], accumulate=True)
+            else:
+                ge = torch.zeros(P.shape[1], Q.shape[1], 3, 3, dtype=torch.float32, device=P.device)
+                ops.wgrad3x3(P, Q, ge, accumulate=False)
+                ent['post'](ge)
+        for buf, dzs in self.deferred_bias.values():
+            D = dzs[0] if len(dzs) == 1 else torch.cat(dzs, 0)
+            ops.bias_grad(D, buf, accumulate=True)
+        self.deferred, self.deferred_bias = {}, {}
 
 
 def _grad_buf(p):
@@ -99,10 +132,10 @@ def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=
         dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
         if w.requires_grad:
             gw = _grad_buf(w)
-            ops.wgrad3x3(dz, x, gw, cb_off=0, accumulate=True)
+            tape.defer_wgrad(('w', id(layer), 0), dz, x, gw, 0)
             if x2 is not None:
-                ops.wgrad3x3(dz, x2, gw, cb_off=c1, accumulate=True)
-            ops.bias_grad(dz, _grad_buf(b), accumulate=True)
+                tape.defer_wgrad(('w', id(layer), 1), dz, x2, gw, c1)
+            tape.defer_bias(_grad_buf(b), dz)
         wd = w.detach()
         if need_dx:
             pkd = _CACHE.get(('dg', id(layer), 0), _ver(w), lambda: ops.pack_conv3x3_dgrad(
@@ -130,8 +163,8 @@ def conv3x3_small(tape, layer, x, act=NONE, up_src=None, up_mode=ops.UP_NONE, up
             return
         dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
         if w.requires_grad:
-            ops.wgrad3x3(dz, x, _grad_buf(w), accumulate=True)
-            ops.bias_grad(dz, _grad_buf(b), accumulate=True)
+            tape.defer_wgrad(('w', id(layer), 0), dz, x, _grad_buf(w), 0)
+            tape.defer_bias(_grad_buf(b), dz)
         pkd = _CACHE.get(('dg', id(layer), 0), _ver(w),
                          lambda: ops.pack_conv3x3_dgrad(w.detach().contiguous()))
         tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, cin, pkd[3], ksplit=1))
@@ -174,15 +207,15 @@ def convt3x3s2(tape, layer, x, act=RELU):
         we = _CACHE.get(('cte', id(layer)), _ver(w), lambda: ops.pack_conv3x3(_convt_embed(w.detach())))
         tape.add_grad(x, ops.conv3x3(s, we[0], None, 4 * co, ci, we[3], ksplit=1))
         if w.requires_grad:
-            ge = torch.zeros(ci, 4 * co, 3, 3, dtype=torch.float32, device=x.device)
-            ops.wgrad3x3(x, s, ge, accumulate=False)               # G[ci][(ph,co)][ty][tx]
-            sel = torch.empty(ci, co, 3, 3, dtype=torch.float32, device=x.device)
-            for ky, (py, ty) in _KT.items():
-                for kx, (px, tx) in _KT.items():
-                    ph = py * 2 + px
-                    sel[:, :, ky, kx] = ge[:, ph * co:(ph + 1) * co, ty, tx]     # gather (copy)
-            ops.axpy_(_grad_buf(w), sel, 1.0)
-            ops.bias_grad(dz, _grad_buf(b), accumulate=True)
+            def post(ge):                                          # G[ci][(ph,co)][ty][tx]
+                sel = torch.empty(ci, co, 3, 3, dtype=torch.float32, device=ge.device)
+                for ky, (py, ty) in _KT.items():
+                    for kx, (px, tx) in _KT.items():
+                        ph = py * 2 + px
+                        sel[:, :, ky, kx] = ge[:, ph * co:(ph + 1) * co, ty, tx]   # gather (copy)
+                ops.axpy_(_grad_buf(w), sel, 1.0)
+            tape.defer_wgrad(('ct', id(layer)), x, s, None, 0, post)
+            tape.defer_bias(_grad_buf(b), dz)
     tape.record(bwd)
     return y
 
@@ -220,14 +253,14 @@ def conv4x4s2(tape, holder, x, need_dx=True):
         if g is None:
             return
         if w.requires_grad:
-            ge = torch.zeros(co, 4 * ci, 3, 3, dtype=torch.float32, device=x.device)
-            ops.wgrad3x3(g, s, ge, accumulate=False)
-            sel = torch.empty(co, ci, 4, 4, dtype=torch.float32, device=x.device)
-            for ky, (py, ty) in _K4.items():
-                for kx, (px, tx) in _K4.items():
-                    ph = py * 2 + px
-                    sel[:, :, ky, kx] = ge[:, ph * ci:(ph + 1) * ci, ty, tx]     # gather (copy)
-            ops.axpy_(_grad_buf(w), sel, 1.0)
+            def post(ge):
+                sel = torch.empty(co, ci, 4, 4, dtype=torch.float32, device=ge.device)
+                for ky, (py, ty) in _K4.items():
+                    for kx, (px, tx) in _K4.items():
+                        ph = py * 2 + px
+                        sel[:, :, ky, kx] = ge[:, ph * ci:(ph + 1) * ci, ty, tx]   # gather (copy)
+                ops.axpy_(_grad_buf(w), sel, 1.0)
+            tape.defer_wgrad(('c4', id(holder)), g, s, None, 0, post)
         if need_dx:
             pkd = _CACHE.get(('c4d', id(holder)), _ver(w),
                              lambda: ops.pack_conv3x3_dgrad(_conv4_embed(w.detach())))
