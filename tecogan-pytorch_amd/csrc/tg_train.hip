@@ -52,19 +52,25 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
   }
 }
 
-// db[c] (+)= sum over n, h, w of dy[n][c][h][w]; one block per channel
+// db[c] += sum over n, h, w of dy[n][c][h][w]; grid = (channel, slice): each block reduces a
+// slice of the (n, hw) range and adds its partial with one atomic (db is zeroed first when
+// not accumulating), so large batched gradients (19 frames x HR) fill the GPU.
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy,
                                                         float* __restrict__ db, int n, int c,
-                                                        int hw, int accumulate) {
+                                                        int hw, int nslice) {
   __shared__ float sm[4];
-  int ch = blockIdx.x;
+  const int ch = blockIdx.x, sl = blockIdx.y;
+  const long long total = (long long)n * hw;
+  const long long per = (total + nslice - 1) / nslice;
+  const long long lo = (long long)sl * per;
+  long long hi = lo + per; if (hi > total) hi = total;
   float s = 0.f;
-  for (int b = 0; b < n; ++b) {
-    const float* p = dy + ((long long)b * c + ch) * hw;
-    for (int i = threadIdx.x; i < hw; i += 256) s += p[i];
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    long long b = i / hw; long long r = i - b * hw;
+    s += dy[(b * c + ch) * hw + r];
   }
   float r = block_sum(s, sm);
-  if (threadIdx.x == 0) db[ch] = accumulate ? db[ch] + r : r;
+  if (threadIdx.x == 0) atomicAdd(db + ch, r);
 }
 
 // gradient of MaxPool2d(2,2) floor mode: goes to the FIRST maximal element of the window
@@ -427,7 +433,15 @@ extern "C" int tg_act_bwd(const float* dy, const float* y, float* dx, int64_t n,
 extern "C" int tg_bias_grad(const float* dy, float* db, int n, int c, int hw, int accumulate,
                             tg_stream_t stream) {
   TG_REQUIRE(dy && db && n > 0 && c > 0 && hw > 0, TG_E_ARG, "bias_grad: bad argument");
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(c), dim3(256), 0, ST, dy, db, n, c, hw, accumulate);
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(db, 0, (size_t)c * sizeof(float), ST);
+    TG_REQUIRE(e == hipSuccess, TG_E_HIP, "bias_grad: memset: %s", hipGetErrorString(e));
+  }
+  long long total = (long long)n * hw;
+  int nslice = (int)((total + 16383) / 16384);
+  if (nslice < 1) nslice = 1;
+  if (nslice * c > 4096) nslice = 4096 / c > 0 ? 4096 / c : 1;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(c, nslice), dim3(256), 0, ST, dy, db, n, c, hw, nslice);
   return check_launch("bias_grad");
 }
 
