@@ -278,6 +278,40 @@ def test_infer_sequence_u8_vs_reference(golden, deg, s):
         assert p == np.inf or p > 60
 
 
+def test_step_batched_clips_equal_independent_steps():
+    """n > 1 through the plan (several clips per GPU in one launch list) == per-clip steps."""
+    net, _ = make_net('BD', 4)
+    lc, lp = dev(rs(1, (3, 3, 24, 40), 0, 1)), dev(rs(2, (3, 3, 24, 40), 0, 1))
+    hp = dev(rs(3, (3, 3, 96, 160), 0, 1))
+    with torch.no_grad():
+        both = net.step(lc, lp, hp)
+        for i in range(3):
+            one = net.step(lc[i:i + 1], lp[i:i + 1], hp[i:i + 1])
+            assert err(both[i:i + 1], one) <= 2e-6      # tile shapes may differ (split-K choice)
+
+
+@pytest.mark.parametrize('deg,s,h,w', [('BD', 4, 8, 8), ('BI', 2, 9, 15), ('BD', 2, 15, 8)])
+def test_step_minimum_sizes_vs_oracle(deg, s, h, w):
+    """Smallest legal frames (FNet bottleneck 1x1, reflect pad up to 7 rows/cols)."""
+    net, sd = make_net(deg, s)
+    lc, lp, hp = rs(1, (1, 3, h, w), 0, 1), rs(2, (1, 3, h, w), 0, 1), rs(3, (1, 3, s * h, s * w), 0, 1)
+    with torch.no_grad():
+        ref = O.frnet_step(sd, lc, lp, hp, s, deg)
+        out = net.step(dev(lc), dev(lp), dev(hp))
+    assert err(out, ref) <= 1e-4
+
+
+def test_invalid_shapes_raise():
+    from tecogan_pytorch_amd._lib import TecoganHipError
+    net, _ = make_net('BD', 4)
+    with pytest.raises(TecoganHipError):          # below the 8x8 minimum of the flow estimator
+        net.step(dev(rs(1, (1, 3, 6, 12))), dev(rs(2, (1, 3, 6, 12))), dev(rs(3, (1, 3, 24, 48))))
+    with pytest.raises(TecoganHipError):          # hr_prev of the wrong size
+        net.step(dev(rs(1, (1, 3, 16, 16))), dev(rs(2, (1, 3, 16, 16))), dev(rs(3, (1, 3, 32, 32))))
+    out = net.infer_sequence(torch.rand(1, 3, 16, 24), 'cuda')        # single-frame clip
+    assert out.shape == (1, 64, 96, 3)
+
+
 def test_pipelined_clip_inference_is_bit_identical():
     """FNet(t+1) on a second stream overlapping SRNet(t) must not change a single bit."""
     net, _ = make_net('BD', 4)
