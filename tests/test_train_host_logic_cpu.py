@@ -1,0 +1,61 @@
+"""CPU checks of the host-side training logic that needs no kernel: the
+space-to-depth weight embeddings that let the transposed convs and the
+discriminator's 4x4/stride-2 convs reuse the 3x3/stride-1 MFMA kernels
+(models/train_graph.py), verified against torch's own convs."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import tecogan_pytorch_amd  # noqa: F401
+from tecogan_pytorch_amd.models import train_graph as TG
+from oracle import tecogan_oracle as O
+
+
+def rs(seed, shape):
+    return torch.from_numpy(np.random.RandomState(seed).uniform(-1, 1, shape).astype(np.float32))
+
+
+def test_conv4x4s2_equals_conv3x3_on_space_to_depth():
+    x, w = rs(1, (2, 5, 12, 16)), rs(2, (7, 5, 4, 4))
+    ref = F.conv2d(x, w, None, stride=2, padding=1)
+    we = TG._conv4_embed(w)
+    assert we.shape == (7, 20, 3, 3)
+    out = F.conv2d(O.space_to_depth(x, 2), we, None, padding=1)
+    assert (out - ref).abs().max() <= 1e-5
+    # exactly 16 of the 36 embedded taps per (co, ci) are populated
+    assert int((we != 0).sum()) == 7 * 5 * 16
+
+
+def test_convt_data_gradient_equals_conv3x3_on_space_to_depth():
+    """dX of ConvTranspose2d(k3,s2,p1,op1) = conv3x3(s2d(dY), embed(W))."""
+    x = rs(1, (2, 6, 5, 7)).requires_grad_(True)
+    w = rs(2, (6, 4, 3, 3))
+    y = F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1)
+    dy = rs(3, tuple(y.shape))
+    y.backward(dy)
+    we = TG._convt_embed(w)
+    assert we.shape == (6, 16, 3, 3)
+    dx = F.conv2d(O.space_to_depth(dy, 2), we, None, padding=1)
+    assert (dx - x.grad).abs().max() <= 1e-5
+
+
+def test_embedded_weight_gradient_extraction_roundtrip():
+    """The (ky,kx) -> (phase, tap) maps are bijections onto the populated entries."""
+    for table, k in ((TG._KT, 3), (TG._K4, 4)):
+        seen = set(table.values())
+        assert len(seen) == k and all(0 <= py <= 1 and 0 <= t <= 2 for py, t in seen)
+
+
+def test_tape_accumulates_and_orders():
+    """Tape semantics without any kernel: closures run in reverse, grads keyed by identity."""
+    tape = TG.Tape()
+    order = []
+    a, b = torch.zeros(1), torch.zeros(1)
+    tape.record(lambda: order.append('first'))
+    tape.record(lambda: order.append('second'))
+    g = torch.ones(1)
+    tape.grads[id(a)] = g
+    assert tape.grad(a) is g and tape.grad(b) is None
+    assert tape.pop_grad(a) is g and tape.grad(a) is None
+    tape.backward()
+    assert order == ['second', 'first'] and tape.nodes == []

@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--model', default='TecoGAN')
+    ap.add_argument('--force-d', action='store_true', help='update D every step (threshold = +inf)')
     a = ap.parse_args()
     from tecogan_pytorch_amd.models import define_model
     opt = {
@@ -31,7 +32,7 @@ def main():
                   'discriminator': {'name': 'STNet', 'in_nc': 3, 'tempo_range': 3}},
         'train': {'tempo_extent': a.tempo, 'ckpt_dir': '/tmp',
                   'generator': {'lr': 5e-5, 'betas': [0.9, 0.999]},
-                  'discriminator': {'update_policy': 'adaptive', 'update_threshold': 0.4,
+                  'discriminator': {'update_policy': 'adaptive', 'update_threshold': 1e9 if a.force_d else 0.4,
                                     'crop_border_ratio': 0.75, 'lr': 5e-5, 'betas': [0.9, 0.999]},
                   'pixel_crit': {'type': 'CB', 'weight': 1, 'reduction': 'mean'},
                   'warping_crit': {'type': 'CB', 'weight': 1, 'reduction': 'mean'},
