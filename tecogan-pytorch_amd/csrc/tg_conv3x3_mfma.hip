@@ -50,6 +50,7 @@ struct Conv3x3Args {
   int ksplit;
   float* part;
   long long part_ss;
+  int vec_ok;   // w % 4 == 0 and 16-byte aligned y / res planes: float4 epilogue allowed
 };
 
 // pack OIHW (or IOHW for transposed convs) -> [ocg][chunk][tap][half][ocb][4]
@@ -87,7 +88,9 @@ constexpr unsigned OOB = 0x80000000u;   // >= any num_records we build (tensors 
 // ABL: ablation bits for tools/conv_lab.hip only (0 in the product):
 //   1 = no re-staging inside the chunk loop, 2 = no barrier in the loop,
 //   4 = no epilogue stores, 8 = no LDS operand reads.
-template <int WM, int WN, int NT, bool DUAL, int ABL = 0>
+// OPT bits (tuning switches, selected by the launcher): 1 = epilogue through LDS with
+// 16-byte stores (needs a.vec_ok), 2 = weight chunks staged by LDS-DMA (global_load_lds).
+template <int WM, int WN, int NT, bool DUAL, int ABL = 0, int OPT = 0, int STAGGER = 12>
 __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a) {
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int OCB = WN * NT * 32;
@@ -161,10 +164,29 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
       }
     }
     const f32x4* ws = wsrc + (size_t)ch * W_VEC4;
+    if constexpr (OPT & 2) {
+      // LDS-DMA: each wave instruction moves 1 KiB (64 lanes x 16 B) of the packed chunk
+      // straight into the other weight buffer; no VGPR round trip, no ds_write.
+      constexpr int PIECES = W_FLOATS * 4 / 1024;
+      constexpr int NWAVES = NTHREADS / 64;
+      const char* src = reinterpret_cast<const char*>(ws) + lane * 16;
+      char* dst = reinterpret_cast<char*>(s_w + ((ch + 1) & 1 ? W_FLOATS : 0));
+      // (buffer index = ch & 1; written as an expression of ch so the caller passes only ch)
+      dst = reinterpret_cast<char*>(s_w + (ch & 1) * W_FLOATS);
 #pragma unroll
-    for (int i = 0; i < W_PER_T; ++i) {
-      int idx = tid + i * NTHREADS;
-      rw[i] = ws[idx < W_VEC4 ? idx : W_VEC4 - 1];
+      for (int i = 0; i < (PIECES + NWAVES - 1) / NWAVES; ++i) {
+        int piece = wave + i * NWAVES;
+        if (piece < PIECES)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(src + piece * 1024),
+              (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < W_PER_T; ++i) {
+        int idx = tid + i * NTHREADS;
+        rw[i] = ws[idx < W_VEC4 ? idx : W_VEC4 - 1];
+      }
     }
   };
   auto store_chunk = [&](int buf) {
@@ -172,11 +194,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
 #pragma unroll
     for (int i = 0; i < I_PER_T; ++i)
       if (lds_item[i] >= 0) *reinterpret_cast<f32x4*>(si + lds_item[i]) = rin[i];
-    f32x4* sw = reinterpret_cast<f32x4*>(s_w + buf * W_FLOATS);
+    if constexpr (!(OPT & 2)) {
+      f32x4* sw = reinterpret_cast<f32x4*>(s_w + buf * W_FLOATS);
 #pragma unroll
-    for (int i = 0; i < W_PER_T; ++i) {
-      int idx = tid + i * NTHREADS;
-      if (idx < W_VEC4) sw[idx] = rw[i];
+      for (int i = 0; i < W_PER_T; ++i) {
+        int idx = tid + i * NTHREADS;
+        if (idx < W_VEC4) sw[idx] = rw[i];
+      }
     }
   };
 
@@ -191,6 +215,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   const int b_off = ((wm * 2 + lh) * RS + ll) * 4;
   const int a_off = (lh * OCB + wn * (NT * 32) + ll) * 4;
 
+  if constexpr (OPT & 4) {
+    // De-synchronise the workgroups that share a CU: they run the same instruction stream
+    // and would otherwise hit their staging / barrier points at the same moments, leaving the
+    // MFMA pipe idle.  Offset each residency "layer" by a fraction of a chunk period.
+    const int layer = (blockIdx.x / 256) % 3;
+    for (int i = 0; i < layer; ++i) __builtin_amdgcn_s_sleep(STAGGER);
+  }
   load_chunk(ch_begin);
   store_chunk(ch_begin & 1);
   __syncthreads();
@@ -248,6 +279,44 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
     return;
   }
   const float slope = act_slope(a.act);
+  if constexpr (OPT & 1) {
+    if (a.vec_ok) {      // wave-uniform
+      // accumulators -> LDS [oc][32 px] (stride 36) -> each lane re-reads 4 consecutive
+      // pixels of one channel and issues 16-byte stores: 4x fewer store instructions.
+      constexpr int ES = 36;
+      float* ep = smem + wave * (NT * 32 * ES);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ep[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ES + ll] = acc[t][r];
+      __syncthreads();
+      const int ocw = ocg * OCB + wn * (NT * 32);
+      if (py < a.h) {
+#pragma unroll
+        for (int j = 0; j < NT * 4; ++j) {
+          int idx4 = j * 64 + lane;
+          int ol = idx4 >> 3, p4 = (idx4 & 7) * 4;
+          int oc = ocw + ol;
+          int gx = x0 + p4;
+          if (oc < a.cout && gx < a.w) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(ep + ol * ES + p4);
+            float bb = a.bias ? a.bias[oc] : 0.f;
+            long long off = (long long)oc * hw + (long long)py * a.w + gx;
+            f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+            if (a.res) rr = *reinterpret_cast<const f32x4*>(a.res + (long long)n * a.res_ns + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float q = v[e] + bb;
+              v[e] = (q >= 0.f ? q : q * slope + 0.f) + rr[e];
+            }
+            *reinterpret_cast<f32x4*>(a.y + (long long)n * a.y_ns + off) = v;
+          }
+        }
+      }
+      return;
+    }
+  }
   float bv[NT][16], rv[NT][16];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -272,9 +341,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   }
 }
 
+// 3 = LDS-transposed 16-byte epilogue + LDS-DMA weight staging (measured +2 % on the frame,
+// parity suite green); bit 4 (start-up stagger of co-resident workgroups) measured null.
+#ifndef TG_CONV_OPT
+#define TG_CONV_OPT 3
+#endif
+
 template <int WM, int WN, int NT>
 static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   Conv3x3Args a = a0;
+  a.vec_ok = (a.w % 4 == 0) && ((uintptr_t)a.y % 16 == 0) && (a.y_ns % 4 == 0) &&
+             (!a.res || (((uintptr_t)a.res % 16 == 0) && (a.res_ns % 4 == 0)));
   constexpr int OCB = WN * NT * 32;
   a.tiles_x = cdiv(a.w, TW);
   a.tiles_y = cdiv(a.h, WM);
@@ -285,11 +362,11 @@ static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n * a.ksplit;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "conv3x3: grid %lld", blocks);
   if (a.x2)
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, true>), dim3((unsigned)blocks),
-                       dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, true, 0, TG_CONV_OPT>),
+                       dim3((unsigned)blocks), dim3(WM * WN * 64), lds, stream, a);
   else
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, false>), dim3((unsigned)blocks),
-                       dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, false, 0, TG_CONV_OPT>),
+                       dim3((unsigned)blocks), dim3(WM * WN * 64), lds, stream, a);
   return check_launch("conv3x3_mfma");
 }
 

@@ -6,23 +6,25 @@
 namespace tg { void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr);} }
 using namespace tg;
 
-template <int WM, int WN, int NT, int ABL>
+template <int WM, int WN, int NT, int ABL, int OPT = 0, int STG = 12>
 static float run(const char* name, Conv3x3Args a, int n, int reps, double gflop) {
+  a.vec_ok = (a.w % 4 == 0);
+  a.ksplit = 1;
   constexpr int OCB = WN * NT * 32;
   a.tiles_x = cdiv(a.w, TW); a.tiles_y = cdiv(a.h, WM); a.nocg = cdiv(a.cout, OCB); a.nchunk = cdiv(a.cin, CK);
   size_t lds = 2 * (size_t)((WM + 2) * 2 * RS * 4 + 9 * CK * OCB) * sizeof(float);
   unsigned blocks = a.tiles_x * a.tiles_y * a.nocg * n;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i)
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, false, ABL>), dim3(blocks), dim3(WM * WN * 64), lds, 0, a);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, false, ABL, OPT, STG>), dim3(blocks), dim3(WM * WN * 64), lds, 0, a);
   hipEventRecord(e0, 0);
   for (int i = 0; i < reps; ++i)
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, false, ABL>), dim3(blocks), dim3(WM * WN * 64), lds, 0, a);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, false, ABL, OPT, STG>), dim3(blocks), dim3(WM * WN * 64), lds, 0, a);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   float us = 1e3f * ms / reps;
   printf("%-28s WG=%4u x%3d lds=%6zu  %8.2f us  %7.2f TF/s  (%s)\n", name, blocks, WM * WN * 64, lds, us,
-         gflop / us * 1e-3, hipGetErrorString(hipGetLastError()));
+         gflop / us * 1e3 / 1e3, hipGetErrorString(hipGetLastError()));
   return us;
 }
 
@@ -50,6 +52,19 @@ int main(int argc, char** argv) {
   printf("conv3x3 %d->%d @%dx%d  %.3f GFLOP\n", cin, cout, h, w, gflop);
   const int R = 50;
   run<2, 2, 1, 0>("<2,2,1> base", a, n, R, gflop);
+  run<2, 2, 1, 0, 3>("<2,2,1> OPT3", a, n, R, gflop);
+  run<2, 2, 1, 0, 7, 6>("<2,2,1> OPT7 stagger 6", a, n, R, gflop);
+  run<2, 2, 1, 0, 7, 12>("<2,2,1> OPT7 stagger 12", a, n, R, gflop);
+  run<2, 2, 1, 0, 7, 24>("<2,2,1> OPT7 stagger 24", a, n, R, gflop);
+  run<2, 2, 1, 0, 7, 48>("<2,2,1> OPT7 stagger 48", a, n, R, gflop);
+  run<2, 2, 1, 0, 3>("<2,2,1> OPT3 again", a, n, R, gflop);
+  run<2, 2, 1, 0, 7, 12>("<2,2,1> OPT7 stagger 12 again", a, n, R, gflop);
+  run<2, 2, 1, 0, 1>("<2,2,1> OPT1 lds-epilogue", a, n, R, gflop);
+  run<2, 2, 1, 0, 2>("<2,2,1> OPT2 dma-weights", a, n, R, gflop);
+  run<2, 2, 1, 0, 3>("<2,2,1> OPT3 both", a, n, R, gflop);
+  run<2, 2, 1, 0, 0>("<2,2,1> base (again)", a, n, R, gflop);
+  run<2, 2, 1, 0, 3>("<2,2,1> OPT3 both (again)", a, n, R, gflop);
+  run<4, 1, 2, 0, 3>("<4,1,2> OPT3 both", a, n, R, gflop);
   run<2, 2, 1, 1>("<2,2,1> no-restage", a, n, R, gflop);
   run<2, 2, 1, 3>("<2,2,1> no-restage no-bar", a, n, R, gflop);
   run<2, 2, 1, 4>("<2,2,1> no-epilogue-store", a, n, R, gflop);

@@ -17,3 +17,8 @@ cd $REPO
 ls -R $OUT/prof_$TAG | head -20
 f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && { cp "$f" $OUT/kernel_stats_$TAG.csv; head -25 "$f"; }
+# same, single stream (per-kernel durations not inflated by the FNet/SRNet overlap)
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof1s_$TAG -o kt -- python $REPO/bench.py --steps 30 --warmup 5 --no-roofline --no-pipeline --cpu-frames 0 --aten-frames 0 > $OUT/prof1s_$TAG.log 2>&1
+cd $REPO
+f=$(find $OUT/prof1s_$TAG -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && { cp "$f" $OUT/kernel_stats_1stream_$TAG.csv; head -8 "$f" | cut -c1-150; }
