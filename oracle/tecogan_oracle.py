@@ -483,7 +483,8 @@ def batch_norm_train(x, weight, bias, running_mean, running_var, momentum=0.1, e
 
 
 def discriminator_forward(sd, data, lr_data, bi_data, hr_flow, spatial_size,
-                          crop_border_ratio, use_pp_crit=True, hr_flow_merge=None):
+                          crop_border_ratio, use_pp_crit=True, hr_flow_merge=None,
+                          sd_G=None, scale=4, degradation='BD'):
     """forward_sequence, tecogan_nets.py:384-477, use_pp_crit branch (:408-411).
     `sd` tensors for BN running stats are updated in place.  Returns
     (logits (n_clip,1), [4 feature maps], hr_flow_merge)."""
@@ -494,11 +495,16 @@ def discriminator_forward(sd, data, lr_data, bi_data, hr_flow, spatial_size,
     c_size = int(spatial_size * crop_border_ratio)
     n_pad = (spatial_size - c_size) // 2
     if hr_flow_merge is None:
-        if not use_pp_crit:
-            raise NotImplementedError('oracle covers the shipped use_pp_crit=True path')
         bw = hr_flow[:, 0:t:3]
         idle = torch.zeros_like(bw)
-        fw = hr_flow.flip(1)[:, 1:t:3]
+        if use_pp_crit:
+            fw = hr_flow.flip(1)[:, 1:t:3]
+        else:                                   # tecogan_nets.py:413-425 (extra FNet pass)
+            cur = lr_data[:, 1:t:3].reshape(n_clip, c, lr_h, lr_w)
+            nxt = lr_data[:, 2:t:3].reshape(n_clip, c, lr_h, lr_w)
+            with torch.no_grad():
+                f = fnet_forward(_sub(sd_G, 'fnet.'), cur, nxt)
+                fw = (scale * upsample(f, scale, degradation)).view(n, t // 3, 2, hr_h, hr_w)
         hr_flow_merge = torch.stack([bw, idle, fw], dim=2).reshape(
             n_clip * 3, 2, hr_h, hr_w).detach()
 
@@ -659,3 +665,21 @@ def vsrgan_train_step(sd_G, sd_D, adam_G, adam_D, state, lr_data, gt_data, scale
     log.update({'l_pix_G': l_pix.item(), 'l_warp_G': l_warp.item(), 'l_pp_G': l_pp.item(),
                 'l_gan_G': l_gan.item(), 'p_fake_G': fake_g.mean().item()})
     return log, gG, gD
+
+
+def spatial_discriminator_forward(sd, data, bi_data, use_cond):
+    """SpatialDiscriminator.forward_sequence, tecogan_nets.py:480-534 (train-mode BN)."""
+    n, t, c, h, w = data.shape
+    x = data.reshape(n * t, c, h, w)
+    if use_cond:
+        x = torch.cat([bi_data.reshape(n * t, c, h, w), x], 1)
+    out = _lrelu(_conv(x, sd, 'conv_in.0'))
+    feats = []
+    for i in range(1, 5):
+        p = f'discriminator_block.block{i}'
+        out = F.conv2d(out, sd[p + '.0.weight'], None, stride=2, padding=1)
+        out = batch_norm_train(out, sd[p + '.1.weight'], sd[p + '.1.bias'],
+                               sd[p + '.1.running_mean'], sd[p + '.1.running_var'])
+        out = _lrelu(out)
+        feats.append(out)
+    return F.linear(out.reshape(out.shape[0], -1), sd['dense.weight'], sd['dense.bias']), feats

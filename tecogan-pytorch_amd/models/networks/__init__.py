@@ -1,4 +1,5 @@
-from .tecogan_nets import FRNet, FNet, SRNet, SpatioTemporalDiscriminator
+from .tecogan_nets import (FRNet, FNet, SRNet, SpatioTemporalDiscriminator,
+                           SpatialDiscriminator)
 
 
 def define_generator(opt):
@@ -13,7 +14,7 @@ def define_generator(opt):
 
 
 def define_discriminator(opt):
-    """codes/models/networks/__init__.py:22-47 (STNet; the never-selected SNet is not built)."""
+    """codes/models/networks/__init__.py:22-47 ."""
     net_D_opt = opt['model']['discriminator']
     if opt['dataset']['degradation']['type'] == 'BD':
         spatial_size = opt['dataset']['train']['crop_size']
@@ -24,4 +25,7 @@ def define_discriminator(opt):
             in_nc=net_D_opt['in_nc'], spatial_size=spatial_size,
             tempo_range=net_D_opt['tempo_range'],
             degradation=opt['dataset']['degradation']['type'], scale=opt['scale'])
+    if net_D_opt['name'].lower() == 'snet':
+        return SpatialDiscriminator(in_nc=net_D_opt['in_nc'], spatial_size=spatial_size,
+                                    use_cond=net_D_opt['use_cond'])
     raise ValueError(f'Unrecognized discriminator: {net_D_opt["name"]}')

@@ -502,11 +502,18 @@ class SpatioTemporalDiscriminator(nn.Module):
         n_pad = (s_size - c_size) // 2
 
         if 'hr_flow_merge' not in args_dict:
-            if not args_dict['use_pp_crit']:
-                raise L.TecoganHipError('only the use_pp_crit=True flow construction '
-                                        '(tecogan_nets.py:408-411) is built')
             bw = hr_flow[:, 0:t:3]
-            fw = hr_flow.flip(1)[:, 1:t:3]
+            if args_dict['use_pp_crit']:
+                fw = hr_flow.flip(1)[:, 1:t:3]          # valid: the sequence is time-symmetric
+            else:
+                # forward flow frame1 -> frame2 from an extra FNet pass (tecogan_nets.py:413-425);
+                # detached, so no tape
+                net_G = args_dict['net_G']
+                lr_curr = lr_data[:, 1:t:3].reshape(n_clip, c, lr_h, lr_w).contiguous()
+                lr_next = lr_data[:, 2:t:3].reshape(n_clip, c, lr_h, lr_w).contiguous()
+                lr_flow_fw = net_G.fnet(lr_curr, lr_next)
+                fw = ops.upsample(lr_flow_fw, self.scale, net_G.srnet.up_mode(),
+                                  mul=float(self.scale)).view(n, t // 3, 2, hr_h, hr_w)
             merge = torch.stack([bw, torch.zeros_like(bw), fw], dim=2)
             hr_flow_merge = merge.reshape(n_clip * 3, 2, hr_h, hr_w).contiguous()
         else:
@@ -562,3 +569,52 @@ class SpatioTemporalDiscriminator(nn.Module):
             tape.record(flat_bwd)
         logits = TG.linear1(tape, self.dense, flat, need_dx=True)
         return (logits, feats), {'hr_flow_merge': hr_flow_merge}
+
+
+class SpatialDiscriminator(nn.Module):
+    """Per-frame critic with optional bicubic condition (tecogan_nets.py:480-534); not
+    selected by any shipped config, provided for API completeness."""
+
+    def __init__(self, in_nc, spatial_size, use_cond):
+        super().__init__()
+        self.use_cond = use_cond
+        mult = 2 if use_cond else 1
+        self.conv_in = _block([(0, _Conv(in_nc * mult, 64))])
+        self.discriminator_block = DiscriminatorBlocks()
+        self.dense = _Linear1(256 * spatial_size // 16 * spatial_size // 16)
+
+    def forward(self, data, args_dict):
+        return self.forward_sequence(data, args_dict)
+
+    def step(self, x, tape=None, need_dx=False):
+        out = TG.conv3x3(tape, self.conv_in['0'], x, TG.LRELU, need_dx=need_dx)
+        out, feats = self.discriminator_block(out, tape, need_dx)
+        flat = out.reshape(out.size(0), -1)
+        if tape is not None:
+            def flat_bwd():
+                g = tape.pop_grad(flat)
+                if g is not None:
+                    tape.add_grad(out, g.view_as(out))
+            tape.record(flat_bwd)
+        return TG.linear1(tape, self.dense, flat, need_dx=True), feats
+
+    def forward_sequence(self, data, args_dict):
+        tape = args_dict.get('tape')
+        need_in = bool(args_dict.get('need_input_grad', False))
+        n, t, c, hr_h, hr_w = data.size()
+        frames = data.reshape(n * t, c, hr_h, hr_w).contiguous()
+        track = tape is not None and need_in
+        if self.use_cond:
+            bi = args_dict['bi_data'].reshape(n * t, c, hr_h, hr_w)
+            x = torch.cat([bi, frames], dim=1).contiguous()
+        else:
+            x = frames
+        if track:
+            def input_bwd():
+                g = tape.pop_grad(x)
+                if g is not None:
+                    gd = g[:, c:] if self.use_cond else g
+                    tape.add_grad(data, gd.contiguous().view_as(data).clone())
+            tape.record(input_bwd)
+        pred = self.step(x, tape, need_in)
+        return pred, {}
