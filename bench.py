@@ -225,7 +225,9 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist_on = world > 1
+    # under torch.distributed.run (RANK/WORLD_SIZE set) always go through the process group,
+    # so the N = 1 launch exercises exactly the code the N > 1 launches use
+    dist_on = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -273,9 +275,9 @@ def main():
         t0 = time.perf_counter()
         net.infer_sequence(clip, dev, pipeline=pipe, return_device_tensor=True)      # exactly K steps
         torch.cuda.synchronize()
-        barrier()
+        elapsed = time.perf_counter() - t0       # this rank's K steps; MAX over ranks below
+        barrier()                                # closing bracket (its own latency is not a step)
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
 
         # ---- secondary protocols (rank-local, not part of `value`) -----------------------
         sec = {}

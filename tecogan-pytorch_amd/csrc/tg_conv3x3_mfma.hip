@@ -51,6 +51,7 @@ struct Conv3x3Args {
   float* part;
   long long part_ss;
   int vec_ok;   // w % 4 == 0 and 16-byte aligned y / res planes: float4 epilogue allowed
+  long long* dbg;   // lab instrumentation (ABL & 16): 8 cycle stamps per workgroup
 };
 
 // pack OIHW (or IOHW for transposed convs) -> [ocg][chunk][tap][half][ocb][4]
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
 
   auto load_chunk = [&](int ch) {
     const unsigned cbase = (unsigned)(ch * CK) * plane;
+    if (!((ABL & 32) && ch != ch_begin))      // lab: skip input re-staging
 #pragma unroll
     for (int i = 0; i < I_PER_T; ++i) {
 #pragma unroll
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
       }
     }
     const f32x4* ws = wsrc + (size_t)ch * W_VEC4;
+    if ((ABL & 64) && ch != ch_begin) return;   // lab: skip weight re-staging
     if constexpr (OPT & 2) {
       // LDS-DMA: each wave instruction moves 1 KiB (64 lanes x 16 B) of the packed chunk
       // straight into the other weight buffer; no VGPR round trip, no ds_write.
@@ -222,15 +225,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
     const int layer = (blockIdx.x / 256) % 3;
     for (int i = 0; i < layer; ++i) __builtin_amdgcn_s_sleep(STAGGER);
   }
+  long long tk0 = 0, tk1 = 0, t_mfma = 0, t_sync = 0, t_issue = 0;
+  if constexpr (ABL & 16) tk0 = clock64();
   load_chunk(ch_begin);
   store_chunk(ch_begin & 1);
   __syncthreads();
+  if constexpr (ABL & 16) tk1 = clock64();
 
   for (int ch = ch_begin; ch < ch_end; ++ch) {
+    long long ta = 0, tb = 0, tc = 0;
+    if constexpr (ABL & 16) ta = clock64();
     const int buf = ch & 1;
     const bool more = (ch + 1 < ch_end) && !(ABL & 1);
     if (more) load_chunk(ch + 1);
 
+    if constexpr (ABL & 16) tb = clock64();
     const float* si = s_in + buf * IN_FLOATS + b_off;
     const float* sw = s_w + buf * W_FLOATS + a_off;
     f32x4 bq[2], aq[2][NT];
@@ -254,8 +263,24 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][t][kk], bq[cur][kk], acc[t], 0, 0, 0);
       }
     }
+    if constexpr (ABL & 16) {
+      // wait for the accumulator (i.e. for the last MFMA) before stamping
+      asm volatile("s_nop 0" ::"v"(acc[0][0]));
+      tc = clock64();
+    }
     if (more) store_chunk(buf ^ 1);
     if (!(ABL & 2)) __syncthreads();
+    if constexpr (ABL & 16) {
+      long long td = clock64();
+      t_issue += tb - ta; t_mfma += tc - tb; t_sync += td - tc;
+    }
+  }
+  if constexpr (ABL & 16) {
+    if (a.dbg && tid == 0) {
+      long long* d = a.dbg + (long long)blockIdx.x * 8;
+      d[0] = tk0; d[1] = tk1 - tk0; d[2] = t_issue; d[3] = t_mfma; d[4] = t_sync; d[5] = clock64();
+      d[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID[3:0]
+    }
   }
 
   // ---- epilogue: bias, activation, residual, NCHW store --------------------

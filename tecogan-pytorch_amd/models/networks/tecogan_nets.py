@@ -8,6 +8,7 @@ frame through one C-ABI call (tg_frnet_step) on a cached plan.
 """
 import ctypes
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -323,7 +324,12 @@ class FRNet(nn.Module):
     def _side_stream(self, dev):
         st = getattr(self, '_side', None)
         if st is None or st.device != dev:
-            st = self._side = torch.cuda.Stream(device=dev)
+            # ROCm maps streams round-robin onto GPU_MAX_HW_QUEUES (default 4) hardware
+            # queues; with RCCL's own streams alive the side stream can land on the SAME
+            # queue as the main stream and the overlap silently disappears.  A stream of a
+            # different priority class is mapped separately.
+            prio = int(os.environ.get('TG_SIDE_STREAM_PRIORITY', '-1'))
+            st = self._side = torch.cuda.Stream(device=dev, priority=prio)
         return st
 
     def forward_sequence(self, lr_data):

@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_lab.hip -o tools/conv_lab
 #include "../tecogan-pytorch_amd/csrc/tg_conv3x3_mfma.hip"
 #include <vector>
+#include <type_traits>
 #include <cstdlib>
 namespace tg { void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr);} }
 using namespace tg;
@@ -50,8 +51,67 @@ int main(int argc, char** argv) {
   a.c1 = cin; a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = TG_ACT_RELU;
   double gflop = 2.0 * cin * 9 * cout * (double)n * h * w / 1e9;
   printf("conv3x3 %d->%d @%dx%d  %.3f GFLOP\n", cin, cout, h, w, gflop);
+  {
+    int nb = 0;
+    size_t lds = 2 * (size_t)((2 + 2) * 2 * RS * 4 + 9 * CK * 64) * sizeof(float);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)conv3x3_mfma_kernel<2, 2, 1, false, 0, 3>, 256, lds);
+    hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)conv3x3_mfma_kernel<2, 2, 1, false, 0, 3>);
+    printf("occupancy API: %d blocks/CU for <2,2,1> OPT3 (dyn LDS %zu B, numRegs %d, static LDS %zu)\n", nb, lds, fa.numRegs, (size_t)fa.sharedSizeBytes);
+    for (size_t l = 16384; l <= 65536; l += 8192) {
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)conv3x3_mfma_kernel<2, 2, 1, false, 0, 3>, 256, l);
+      printf("   dyn LDS %6zu -> %d blocks/CU\n", l, nb);
+    }
+  }
   const int R = 50;
   run<2, 2, 1, 0>("<2,2,1> base", a, n, R, gflop);
+  auto anatomy = [&](auto tag, const char* name) {
+    constexpr int OPTV = decltype(tag)::value;
+    long long* dbg; unsigned nb = 670;
+    hipMalloc(&dbg, nb * 8 * sizeof(long long)); hipMemset(dbg, 0, nb * 8 * sizeof(long long));
+    Conv3x3Args ad = a; ad.dbg = dbg;
+    run<2, 2, 1, 16, OPTV>(name, ad, n, 5, gflop);
+    std::vector<long long> h(nb * 8);
+    hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    double pro = 0, iss = 0, mf = 0, sy = 0, life = 0;
+    for (unsigned i = 0; i < nb; ++i) { pro += h[i*8+1]; iss += h[i*8+2]; mf += h[i*8+3]; sy += h[i*8+4]; life += h[i*8+5] - h[i*8]; }
+    printf("  cycles/WG avg: prologue %.0f | load-issue %.0f  mfma-block %.0f  store+barrier %.0f | lifetime %.0f (ideal mfma 8x36x64 = 18432)\n",
+           pro / nb, iss / nb, mf / nb, sy / nb, life / nb);
+    // per-XCD view (s_memtime is only comparable inside one XCD)
+    for (int x = 0; x < 8; ++x) {
+      long long lo = -1, hi = 0; double lf = 0; int cnt = 0; long long first_end = -1;
+      for (unsigned i = 0; i < nb; ++i) if ((h[i*8+6] & 15) == x) {
+        if (lo < 0 || h[i*8] < lo) lo = h[i*8];
+        if (h[i*8+5] > hi) hi = h[i*8+5];
+        if (first_end < 0 || h[i*8+5] < first_end) first_end = h[i*8+5];
+        lf += h[i*8+5] - h[i*8]; ++cnt;
+      }
+      long long last_start = 0; for (unsigned i = 0; i < nb; ++i) if ((h[i*8+6] & 15) == x && h[i*8] > last_start) last_start = h[i*8];
+      if (cnt) printf("   XCD %d: %3d WGs  span %6lld  avg lifetime %6.0f  last start +%lld  first end +%lld\n", x, cnt, hi - lo, lf / cnt, last_start - lo, first_end - lo);
+    }
+    hipFree(dbg);
+  };
+  run<3, 2, 1, 0, 3>("<3,2,1> OPT3 (6 waves)", a, n, R, gflop);
+  run<2, 2, 1, 0, 3>("<2,2,1> OPT3", a, n, R, gflop);
+  run<3, 2, 1, 0, 3>("<3,2,1> OPT3 (6 waves)", a, n, R, gflop);
+  run<2, 2, 1, 0, 3>("<2,2,1> OPT3", a, n, R, gflop);
+  run<3, 2, 1, 0, 3>("<3,2,1> OPT3 (6 waves)", a, n, R, gflop);
+  run<5, 2, 1, 0, 3>("<5,2,1> OPT3 (10 waves)", a, n, R, gflop);
+  run<2, 2, 1, 32, 3>("<2,2,1> OPT3 no input restage", a, n, R, gflop);
+  run<2, 2, 1, 64, 3>("<2,2,1> OPT3 no weight restage", a, n, R, gflop);
+  run<2, 2, 1, 96, 3>("<2,2,1> OPT3 neither", a, n, R, gflop);
+  run<2, 2, 1, 0, 3>("<2,2,1> OPT3 full", a, n, R, gflop);
+  run<3, 2, 1, 0, 3>("<3,2,1> OPT3 (6 waves)", a, n, R, gflop);
+  run<2, 2, 1, 0, 3>("<2,2,1> OPT3", a, n, R, gflop);
+  run<3, 2, 1, 0, 3>("<3,2,1> OPT3 (6 waves)", a, n, R, gflop);
+  run<2, 2, 1, 0, 3>("<2,2,1> OPT3", a, n, R, gflop);
+  run<3, 2, 1, 0, 3>("<3,2,1> OPT3 (6 waves)", a, n, R, gflop);
+  run<5, 2, 1, 0, 3>("<5,2,1> OPT3 (10 waves)", a, n, R, gflop);
+  run<2, 2, 1, 32, 3>("<2,2,1> OPT3 no input restage", a, n, R, gflop);
+  run<2, 2, 1, 64, 3>("<2,2,1> OPT3 no weight restage", a, n, R, gflop);
+  run<2, 2, 1, 0, 3>("<2,2,1> OPT3 full", a, n, R, gflop);
+  anatomy(std::integral_constant<int, 0>{}, "<2,2,1> OPT0 instrumented");
+  anatomy(std::integral_constant<int, 1>{}, "<2,2,1> OPT1 instrumented");
+  anatomy(std::integral_constant<int, 3>{}, "<2,2,1> OPT3 instrumented");
   run<2, 2, 1, 0, 3>("<2,2,1> OPT3", a, n, R, gflop);
   run<2, 2, 1, 0, 7, 6>("<2,2,1> OPT7 stagger 6", a, n, R, gflop);
   run<2, 2, 1, 0, 7, 12>("<2,2,1> OPT7 stagger 12", a, n, R, gflop);
