@@ -173,9 +173,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
       constexpr int PIECES = W_FLOATS * 4 / 1024;
       constexpr int NWAVES = NTHREADS / 64;
       const char* src = reinterpret_cast<const char*>(ws) + lane * 16;
-      char* dst = reinterpret_cast<char*>(s_w + ((ch + 1) & 1 ? W_FLOATS : 0));
-      // (buffer index = ch & 1; written as an expression of ch so the caller passes only ch)
-      dst = reinterpret_cast<char*>(s_w + (ch & 1) * W_FLOATS);
+      char* dst = reinterpret_cast<char*>(s_w + (ch & 1) * W_FLOATS);   // chunk ch lives in buffer ch & 1
 #pragma unroll
       for (int i = 0; i < (PIECES + NWAVES - 1) / NWAVES; ++i) {
         int piece = wave + i * NWAVES;

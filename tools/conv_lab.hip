@@ -25,7 +25,7 @@ static float run(const char* name, Conv3x3Args a, int n, int reps, double gflop)
   float ms; hipEventElapsedTime(&ms, e0, e1);
   float us = 1e3f * ms / reps;
   printf("%-28s WG=%4u x%3d lds=%6zu  %8.2f us  %7.2f TF/s  (%s)\n", name, blocks, WM * WN * 64, lds, us,
-         gflop / us * 1e3 / 1e3, hipGetErrorString(hipGetLastError()));
+         gflop / us * 1e3, hipGetErrorString(hipGetLastError()));   // GFLOP/us = PFLOP/s; x1000 = TFLOP/s
   return us;
 }
 
