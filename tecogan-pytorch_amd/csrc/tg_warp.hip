@@ -8,13 +8,12 @@
 // (0.3 MB) and hr_prev (8.2 MB) and writes the 48-channel SRNet input slice
 // (8.2 MB) -- 16.8 MB of algorithmic traffic instead of ~75 MB.
 //
-// Thread mapping: one thread = one LR column `ox` of one HR row `hy`, i.e. the
-// `s` horizontally adjacent HR pixels that space_to_depth scatters to `s`
-// different channel planes.  For a fixed (sy, sx, c) plane consecutive lanes
-// write consecutive `ox`: every store instruction is a contiguous 256-byte
-// row segment; the vertical bicubic partial sums of the flow are shared by
-// the s pixels of a thread.
+// Thread mapping: a block is one 256-pixel HR row segment with lane <-> HR x, so the
+// bilinear gathers of a wave read ~contiguous addresses; the LR-flow terms of the segment
+// are staged once in LDS, and the warped values are transposed through LDS so that each
+// wave stores 64 consecutive LR columns of one (sy, sx, c) plane (256 contiguous bytes).
 #include "tg_common.h"
+#include <cstdlib>
 
 namespace tg {
 
@@ -45,86 +44,290 @@ struct FusedArgs {
   float* hr_flow_out;    // optional (n,2,S*h,S*w)
   long long out_ns;
   int n, c, h, w, fh, fw, up_mode;
+  // per-axis constants of the sampling grid, computed once on the host with the same IEEE
+  // fp32 operations the reference performs per call: step = 2/(N-1), half = (N-1)/2 and
+  // rhalf = RN(1/half) for the division below.
+  float step_x, step_y, half_x, half_y, rhalf_x, rhalf_y;
+  int in_aligned, out_aligned;   // 16-byte alignment of hr_prev / out (base and clip stride)
 };
 
-template <int S, int C>
-__global__ __launch_bounds__(256) void flowup_warp_s2d_kernel(FusedArgs a) {
-  const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int hy = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int n = blockIdx.z;
-  const int HH = S * a.h, WW = S * a.w;
-  if (ox >= a.w || hy >= HH) return;
-  const int oy = hy / S, sy = hy - oy * S;
-  const float* f0 = a.lr_flow + (long long)n * 2 * a.fh * a.fw;
-  const float* f1 = f0 + a.fh * a.fw;
+// x / d for a loop-invariant d with r = RN(1/d): the refinement tail of the IEEE division
+// expansion (two residual corrections), correctly rounded for the normal-range operands
+// of this path -- 5 FMA-class instructions instead of the ~12 of a generic fp32 divide.
+// tools/div_lab.hip checks it bit-for-bit against `x / d` on the device.
+__device__ __forceinline__ float div_const(float x, float d, float r) {
+  float q = x * r;
+  float e = __builtin_fmaf(-d, q, x);
+  q = __builtin_fmaf(e, r, q);
+  e = __builtin_fmaf(-d, q, x);
+  return __builtin_fmaf(e, r, q);
+}
 
-  float fxv[S], fyv[S];
-  if (a.up_mode == TG_UP_BICUBIC) {
-    float ky[4];
-    bicubic_w(sy, S, ky);
-    int rr[4], cc[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      rr[p] = reflect_src(clampi(oy - 1 + p, 0, a.h - 1), a.fh);
-      cc[p] = reflect_src(clampi(ox - 1 + p, 0, a.w - 1), a.fw);
+template <int AUX = 0>
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, AUX));
+}
+template <int AUX = 0>
+__device__ __forceinline__ void bstore(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, AUX);
+}
+
+// warp_coord (tg_common.h) with the loop-invariant pieces hoisted
+__device__ __forceinline__ float warp_coord_c(int i, int n, float flow, float step, float half,
+                                              float rhalf) {
+  float g = linspace_m1p1(i, n, step) + div_const(flow, half, rhalf);
+  float p = (g + 1.0f) * half;
+  p = p < 0.f ? 0.f : p;
+  p = p > (float)(n - 1) ? (float)(n - 1) : p;
+  return p;
+}
+
+// The kernel is bound by the texture-address unit, which spends ~16 cycles on every wave
+// memory instruction whatever its width (rocprofv3: TA busy 75-95 % of the kernel with
+// dword gathers and dword stores), so the design minimises the NUMBER of wave memory
+// instructions per pixel:
+//
+// Block = R consecutive HR rows of one LR row (R divides S) x a 256-pixel HR column
+// segment; each thread owns 2 horizontally adjacent pixels x R/2 rows.
+//   1. the LR-flow patch of the block (4 source rows x NV columns x 2 channels, reflect pad
+//      + replicate clamp folded into the index) is loaded ONCE into LDS; the vertical 4-tap
+//      sums per (HR row, LR column) are formed from LDS (bilinear: the two source rows of
+//      every HR row are loaded directly); S threads stage the horizontal bicubic weights,
+//   2. every thread finishes its flows with the horizontal taps from LDS, evaluates the
+//      sampling positions exactly as the reference does, and gathers, per channel and
+//      source row, ONE 16-byte lane starting at pixel a's x0: it holds a's (x0, x0+1) taps
+//      and -- when b samples the same source row 0..2 elements further right, which a
+//      smooth flow makes the usual case -- b's as well.  Lanes where it does not load b's
+//      taps separately (8-byte pairs).  The TA cost of a gather is per active lane,
+//      independent of the lane width (measured), so sharing halves it.  A tap at N
+//      (x0+1 == W or y0+1 == H) has weight exactly 0 because positions are clamped to
+//      N-1: the lane may read the neighbouring element (or the buffer's out-of-range 0)
+//      and the row offset is simply dropped -- no predication,
+//   3. the R x C x 256 results are transposed through LDS and leave as dwordx4 stores:
+//      16 lanes x 16 B = 256 contiguous bytes of one (sy, sx, c) plane.
+// Measured alternatives (tools/warp_lab.py, 8 clips per launch): dword gathers +20 %;
+// staging a flow-shifted window of the previous frame in LDS and sampling from LDS +-0 at
+// zero flow and slower as soon as the flow varies inside a block; XCD-banded block order
+// +4 %; nontemporal stores +-0; nontemporal gathers +30 %.
+// All offsets are 32-bit against block-uniform buffer resources.
+#ifndef TG_WARP_ABL
+#define TG_WARP_ABL 0   // lab only (tools/warp_lab.py): 1 no stores, 2 one tap row instead of two, 4 no flow loads
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int S, int C, int R>
+__global__ __launch_bounds__(256) void flowup_warp_s2d_kernel(FusedArgs a) {
+  constexpr int SEG = 256;
+  constexpr int NV = SEG / S + 3;          // LR columns touched by the segment
+  constexpr int OXB = SEG / S;             // LR columns produced by the segment
+  constexpr int OUT_ITEMS = R * S * C * (OXB / 4);
+  constexpr int PS = OXB + 16;             // staged plane stride: the S sub-pixel phases land in disjoint banks
+  static_assert(S % R == 0 && R % 2 == 0, "rows of a block share one LR row; two row groups");
+  __shared__ float s_raw[2][4][NV + 1];    // [flow channel][source row][LR column]
+  __shared__ float2 s_fl[R][2][NV + 1];    // [row][slot][LR column] -> (flow x, flow y)
+  __shared__ __attribute__((aligned(16))) float s_kx[S][4];
+  __shared__ __attribute__((aligned(16))) float s_out[R * S * C * PS];
+
+  const int t = threadIdx.x;
+  const int HH = S * a.h, WW = S * a.w;
+  const int nseg = (WW + SEG - 1) / SEG, nrb = HH / R;
+  int tile = blockIdx.x;
+  if (tile >= nseg * nrb * a.n) return;
+  // integer division runs on the VALU; readfirstlane tells the compiler the results are
+  // wave-uniform (otherwise every buffer access is wrapped in a waterfall loop)
+  const int seg = __builtin_amdgcn_readfirstlane(tile % nseg);
+  tile /= nseg;
+  const int rb = __builtin_amdgcn_readfirstlane(tile % nrb);
+  const int n = __builtin_amdgcn_readfirstlane(tile / nrb);
+  const int x0 = seg * SEG;
+  const int hy0 = rb * R;
+  const int oy = hy0 / S, sy0 = hy0 - oy * S;
+  const unsigned fhw = (unsigned)(a.fh * a.fw);
+  const unsigned hrhw = (unsigned)(HH * WW);
+  const unsigned lrhw = (unsigned)(a.h * a.w);
+  const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.lr_flow + (size_t)n * 2 * fhw), 0, 2 * fhw * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.hr_prev + (size_t)n * C * hrhw), 0, C * hrhw * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+      a.out + (size_t)n * a.out_ns, 0, S * S * C * lrhw * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+      a.hr_flow_out ? a.hr_flow_out + (size_t)n * 2 * hrhw : a.out, 0, 2 * hrhw * 4, 0x00020000);
+  const int jbase = x0 / S - 1;
+  const bool bicubic = a.up_mode == TG_UP_BICUBIC;
+  const bool vec_out = (a.w & 3) == 0 && a.out_aligned;   // dwordx4 stores need 16-byte rows
+
+  // ---- 1. LR-flow terms
+  if (bicubic) {
+    for (int it = t; it < 2 * 4 * NV; it += 256) {
+      const int k = it % NV, p = (it / NV) & 3, ch = it / (4 * NV);
+      const unsigned cc = (unsigned)reflect_src(clampi(jbase + k, 0, a.w - 1), a.fw);
+      const unsigned o = ((unsigned)reflect_src(clampi(oy - 1 + p, 0, a.h - 1), a.fh) * a.fw + cc) * 4u;
+      s_raw[ch][p][k] = (TG_WARP_ABL & 4) ? 0.01f : bload(rf, o, ch * fhw * 4u);
     }
-    float vx[4], vy[4];
+    if (t >= 256 - S) {
+      float k[4];
+      bicubic_w(t - (256 - S), S, k);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 4; ++q) s_kx[t - (256 - S)][q] = k[q];
+    }
+    __syncthreads();
+    for (int it = t; it < R * NV; it += 256) {
+      const int r = it / NV, k = it - r * NV;
+      float ky[4];
+      bicubic_w(sy0 + r, S, ky);
       float sx_ = 0.f, sy_ = 0.f;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        sx_ += ky[p] * f0[rr[p] * a.fw + cc[q]];
-        sy_ += ky[p] * f1[rr[p] * a.fw + cc[q]];
-      }
-      vx[q] = sx_; vy[q] = sy_;
-    }
-#pragma unroll
-    for (int d = 0; d < S; ++d) {
-      float kx[4];
-      bicubic_w(d, S, kx);
-      float ax = 0.f, ay = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { ax += kx[q] * vx[q]; ay += kx[q] * vy[q]; }
-      fxv[d] = (float)S * ax;
-      fyv[d] = (float)S * ay;
+      for (int p = 0; p < 4; ++p) { sx_ += ky[p] * s_raw[0][p][k]; sy_ += ky[p] * s_raw[1][p][k]; }
+      s_fl[r][0][k] = make_float2(sx_, sy_);
     }
   } else {
-    int y0, y1; float ly0, ly1;
-    bilinear_src(hy, S, a.h, y0, y1, ly0, ly1);
-    y0 = reflect_src(y0, a.fh); y1 = reflect_src(y1, a.fh);
-#pragma unroll
-    for (int d = 0; d < S; ++d) {
-      int x0, x1; float lx0, lx1;
-      bilinear_src(ox * S + d, S, a.w, x0, x1, lx0, lx1);
-      x0 = reflect_src(x0, a.fw); x1 = reflect_src(x1, a.fw);
-      float tx_ = lx0 * f0[y0 * a.fw + x0] + lx1 * f0[y0 * a.fw + x1];
-      float bx_ = lx0 * f0[y1 * a.fw + x0] + lx1 * f0[y1 * a.fw + x1];
-      float ty_ = lx0 * f1[y0 * a.fw + x0] + lx1 * f1[y0 * a.fw + x1];
-      float by_ = lx0 * f1[y1 * a.fw + x0] + lx1 * f1[y1 * a.fw + x1];
-      fxv[d] = (float)S * (ly0 * tx_ + ly1 * bx_);
-      fyv[d] = (float)S * (ly0 * ty_ + ly1 * by_);
+    for (int it = t; it < R * NV; it += 256) {
+      const int r = it / NV, k = it - r * NV;
+      const unsigned cc = (unsigned)reflect_src(clampi(jbase + k, 0, a.w - 1), a.fw);
+      int y0, y1; float ly0, ly1;
+      bilinear_src(hy0 + r, S, a.h, y0, y1, ly0, ly1);
+      unsigned o0 = ((unsigned)reflect_src(y0, a.fh) * a.fw + cc) * 4u;
+      unsigned o1 = ((unsigned)reflect_src(y1, a.fh) * a.fw + cc) * 4u;
+      s_fl[r][0][k] = make_float2(bload(rf, o0, 0), bload(rf, o0, fhw * 4u));
+      s_fl[r][1][k] = make_float2(bload(rf, o1, 0), bload(rf, o1, fhw * 4u));
     }
   }
+  __syncthreads();
 
-  if (a.hr_flow_out) {
-    float* fo = a.hr_flow_out + (long long)n * 2 * HH * WW + (long long)hy * WW + ox * S;
+  // ---- 2. flows, sampling positions, gathers.  Thread -> 2 horizontally adjacent pixels
+  //         (a, b) x RPT rows; the tile is 256 columns x R rows.
+  constexpr int RPT = R / 2;
+  const int tp = t & 127, r0 = (t >> 7) * RPT;
+  const int hxa = x0 + 2 * tp;
+  if (hxa < WW) {
+    const bool live_b = hxa + 1 < WW;
+    float fx[2][RPT], fy[2][RPT];
+    if (bicubic) {
 #pragma unroll
-    for (int d = 0; d < S; ++d) { fo[d] = fxv[d]; fo[(long long)HH * WW + d] = fyv[d]; }
+      for (int e = 0; e < 2; ++e) {
+        const int k0 = (2 * tp + e) / S, dx = (2 * tp + e) - k0 * S;   // x0 is a multiple of S
+        const f32x4 kx = *reinterpret_cast<const f32x4*>(s_kx[dx]);
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+          float ax = 0.f, ay = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float2 v = s_fl[r0 + j][0][k0 + q];
+            ax += kx[q] * v.x; ay += kx[q] * v.y;
+          }
+          fx[e][j] = (float)S * ax; fy[e][j] = (float)S * ay;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        int c0, c1; float lx0, lx1;
+        bilinear_src(hxa + e, S, a.w, c0, c1, lx0, lx1);     // indices into the padded LR row
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+          int y0, y1; float ly0, ly1;
+          bilinear_src(hy0 + r0 + j, S, a.h, y0, y1, ly0, ly1);
+          const float2 t0 = s_fl[r0 + j][0][c0 - jbase], t1 = s_fl[r0 + j][0][c1 - jbase];
+          const float2 b0 = s_fl[r0 + j][1][c0 - jbase], b1 = s_fl[r0 + j][1][c1 - jbase];
+          float tx_ = lx0 * t0.x + lx1 * t1.x, bx_ = lx0 * b0.x + lx1 * b1.x;
+          float ty_ = lx0 * t0.y + lx1 * t1.y, by_ = lx0 * b0.y + lx1 * b1.y;
+          fx[e][j] = (float)S * (ly0 * tx_ + ly1 * bx_);
+          fy[e][j] = (float)S * (ly0 * ty_ + ly1 * by_);
+        }
+      }
+    }
+    if (a.hr_flow_out) {
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        const unsigned o = ((unsigned)(hy0 + r0 + j) * WW + hxa) * 4u;
+        bstore(fx[0][j], ro, o, 0); bstore(fy[0][j], ro, o, hrhw * 4u);
+        if (live_b) { bstore(fx[1][j], ro, o + 4u, 0); bstore(fy[1][j], ro, o + 4u, hrhw * 4u); }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+      const int r = r0 + j;
+      // positions, tap offsets and weights of both pixels
+      unsigned o0[2], o1[2]; int ixy[2][2];
+      float w00[2], w01[2], w10[2], w11[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float px = warp_coord_c(hxa + e, WW, fx[e][j], a.step_x, a.half_x, a.rhalf_x);
+        const float py = warp_coord_c(hy0 + r, HH, fy[e][j], a.step_y, a.half_y, a.rhalf_y);
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const float wx1 = px - fx0, wx0 = 1.0f - wx1;
+        const float wy1 = py - fy0, wy0 = 1.0f - wy1;
+        const int ix = (int)fx0, iy = (int)fy0;
+        ixy[e][0] = ix; ixy[e][1] = iy;
+        o0[e] = ((unsigned)iy * WW + ix) * 4u;
+        o1[e] = o0[e] + (iy + 1 <= HH - 1 ? (unsigned)WW * 4u : 0u);
+        w00[e] = wy0 * wx0; w01[e] = wy0 * wx1; w10[e] = wy1 * wx0; w11[e] = wy1 * wx1;
+      }
+      // pixel b's taps lie inside pixel a's 16-byte lanes when both sample the same source
+      // row and b starts 0..2 elements to the right (the usual case for a smooth flow)
+      const int d = ixy[1][0] - ixy[0][0];
+      const bool shared = ixy[1][1] == ixy[0][1] && (unsigned)d <= 2u;
+      float va[C], vb[C];
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        const unsigned pl = ch * hrhw * 4u;
+        const f32x4 t4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (int)o0[0], (int)pl, 0));
+        const f32x4 b4 = (TG_WARP_ABL & 2) ? t4 : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (int)o1[0], (int)pl, 0));
+        va[ch] = ((t4[0] * w00[0] + t4[1] * w01[0]) + b4[0] * w10[0]) + b4[1] * w11[0];
+        const float t0 = d == 0 ? t4[0] : (d == 1 ? t4[1] : t4[2]);
+        const float t1 = d == 0 ? t4[1] : (d == 1 ? t4[2] : t4[3]);
+        const float b0 = d == 0 ? b4[0] : (d == 1 ? b4[1] : b4[2]);
+        const float b1 = d == 0 ? b4[1] : (d == 1 ? b4[2] : b4[3]);
+        vb[ch] = ((t0 * w00[1] + t1 * w01[1]) + b0 * w10[1]) + b1 * w11[1];
+      }
+      if (!shared) {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+          const unsigned pl = ch * hrhw * 4u;
+          const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ri, (int)o0[1], (int)pl, 0));
+          const f32x2 b2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ri, (int)o1[1], (int)pl, 0));
+          vb[ch] = ((t2[0] * w00[1] + t2[1] * w01[1]) + b2[0] * w10[1]) + b2[1] * w11[1];
+        }
+      }
+      const int oxa = (2 * tp) / S, sxa = 2 * tp - oxa * S;
+      const int oxb = (2 * tp + 1) / S, sxb = 2 * tp + 1 - oxb * S;
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        s_out[((r * S + sxa) * C + ch) * PS + oxa] = va[ch];
+        s_out[((r * S + sxb) * C + ch) * PS + oxb] = vb[ch];
+      }
+    }
   }
+  __syncthreads();
 
-  const float* img = a.hr_prev + (long long)n * C * HH * WW;
-  float* ob = a.out + (long long)n * a.out_ns + (long long)oy * a.w + ox;
-  const long long lrhw = (long long)a.h * a.w;
+  // ---- 3. space_to_depth: staged as s_out[(r, sx, ch)][ox]
+  if (vec_out) {
+    // item -> (plane = (r, sx, ch), quad of 4 LR columns); 16 lanes cover one plane row
 #pragma unroll
-  for (int d = 0; d < S; ++d) {
-    const int hx = ox * S + d;
-    float px = warp_coord(hx, WW, fxv[d]);
-    float py = warp_coord(hy, HH, fyv[d]);
+    for (int i = 0; i < (OUT_ITEMS + 255) / 256; ++i) {
+      const int it = t + i * 256;
+      const int q = it % (OXB / 4), pl = it / (OXB / 4);
+      const int ox = x0 / S + 4 * q;
+      if (it < OUT_ITEMS && ox < a.w) {
+        const int r = pl / (S * C), rem = pl - r * (S * C);   // rem = sx * C + ch
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&s_out[pl * PS + 4 * q]);
+        const unsigned o = ((unsigned)((sy0 + r) * S * C + rem) * lrhw + (unsigned)oy * a.w + ox) * 4u;
+        if ((TG_WARP_ABL & 1) && v[0] != 12345.678f) continue;
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(int)))) int, v), rout, (int)o, 0, 0);
+      }
+    }
+  } else {
+    const int sx = t / OXB, oxl = t - sx * OXB;
+    const int ox = x0 / S + oxl;
+    if (ox < a.w) {
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) {
-      float v = warp_sample(img + (long long)ch * HH * WW, HH, WW, px, py);
-      ob[(long long)((sy * S + d) * C + ch) * lrhw] = v;
+      for (int r = 0; r < R; ++r) {
+        const unsigned o = ((unsigned)(((sy0 + r) * S + sx) * C) * lrhw + (unsigned)oy * a.w + ox) * 4u;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch)
+          bstore(s_out[((r * S + sx) * C + ch) * PS + oxl], rout, o, ch * lrhw * 4u);
+      }
     }
   }
 }
@@ -245,11 +448,19 @@ extern "C" int tg_flowup_warp_s2d_fwd(const float* lr_flow, int fh, int fw, cons
   TG_REQUIRE(up_mode == TG_UP_BICUBIC || up_mode == TG_UP_BILINEAR, TG_E_ARG,
              "flowup_warp_s2d: up_mode=%d", up_mode);
   TG_REQUIRE(scale * h >= 2 && scale * w >= 2, TG_E_SHAPE, "flowup_warp_s2d: degenerate size");
-  FusedArgs a{lr_flow, hr_prev, out, hr_flow_out, out_nstride, n, c, h, w, fh, fw, up_mode};
-  dim3 g(cdiv(w, 64), cdiv(scale * h, 4), n), t(256);
+  TG_REQUIRE((long long)scale * scale * c * h * w < (1ll << 31), TG_E_SHAPE,
+             "flowup_warp_s2d: frame too large for 32-bit offsets");
+  const float nx = (float)(scale * w - 1), ny = (float)(scale * h - 1);
+  FusedArgs a{lr_flow, hr_prev, out, hr_flow_out, out_nstride, n, c, h, w, fh, fw, up_mode,
+              2.0f / nx, 2.0f / ny, nx / 2.0f, ny / 2.0f, 1.0f / (nx / 2.0f), 1.0f / (ny / 2.0f),
+              ((uintptr_t)hr_prev & 15) == 0 && (n == 1 || ((long long)c * scale * scale * h * w) % 4 == 0),
+              ((uintptr_t)out & 15) == 0 && (n == 1 || out_nstride % 4 == 0)};
+  const int rows = scale;
+  const int tiles = cdiv(scale * w, 256) * (scale * h / rows) * n;
+  dim3 g(tiles), t(256);
   hipStream_t s = (hipStream_t)stream;
-  if (scale == 4) hipLaunchKernelGGL((flowup_warp_s2d_kernel<4, 3>), g, t, 0, s, a);
-  else hipLaunchKernelGGL((flowup_warp_s2d_kernel<2, 3>), g, t, 0, s, a);
+  if (scale == 4) hipLaunchKernelGGL((flowup_warp_s2d_kernel<4, 3, 4>), g, t, 0, s, a);
+  else hipLaunchKernelGGL((flowup_warp_s2d_kernel<2, 3, 2>), g, t, 0, s, a);
   return check_launch("flowup_warp_s2d");
 }
 
