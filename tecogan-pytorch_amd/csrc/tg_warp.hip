@@ -114,14 +114,15 @@ __device__ __forceinline__ float warp_coord_c(int i, int n, float flow, float st
 #define TG_WARP_ABL 0   // lab only (tools/warp_lab.py): 1 no stores, 2 one tap row instead of two, 4 no flow loads
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int S, int C, int R>
-__global__ __launch_bounds__(256) void flowup_warp_s2d_kernel(FusedArgs a) {
+template <int S, int C, int R, int RPT>
+__global__ __launch_bounds__(128 * (R / RPT)) void flowup_warp_s2d_kernel(FusedArgs a) {
   constexpr int SEG = 256;
+  constexpr int NT = 128 * (R / RPT);      // threads: 128 pixel pairs x R/RPT row groups
   constexpr int NV = SEG / S + 3;          // LR columns touched by the segment
   constexpr int OXB = SEG / S;             // LR columns produced by the segment
   constexpr int OUT_ITEMS = R * S * C * (OXB / 4);
   constexpr int PS = OXB + 16;             // staged plane stride: the S sub-pixel phases land in disjoint banks
-  static_assert(S % R == 0 && R % 2 == 0, "rows of a block share one LR row; two row groups");
+  static_assert(S % R == 0 && R % RPT == 0, "rows of a block share one LR row; two row groups");
   __shared__ float s_raw[2][4][NV + 1];    // [flow channel][source row][LR column]
   __shared__ float2 s_fl[R][2][NV + 1];    // [row][slot][LR column] -> (flow x, flow y)
   __shared__ __attribute__((aligned(16))) float s_kx[S][4];
@@ -158,20 +159,20 @@ __global__ __launch_bounds__(256) void flowup_warp_s2d_kernel(FusedArgs a) {
 
   // ---- 1. LR-flow terms
   if (bicubic) {
-    for (int it = t; it < 2 * 4 * NV; it += 256) {
+    for (int it = t; it < 2 * 4 * NV; it += NT) {
       const int k = it % NV, p = (it / NV) & 3, ch = it / (4 * NV);
       const unsigned cc = (unsigned)reflect_src(clampi(jbase + k, 0, a.w - 1), a.fw);
       const unsigned o = ((unsigned)reflect_src(clampi(oy - 1 + p, 0, a.h - 1), a.fh) * a.fw + cc) * 4u;
       s_raw[ch][p][k] = (TG_WARP_ABL & 4) ? 0.01f : bload(rf, o, ch * fhw * 4u);
     }
-    if (t >= 256 - S) {
+    if (t >= NT - S) {
       float k[4];
-      bicubic_w(t - (256 - S), S, k);
+      bicubic_w(t - (NT - S), S, k);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s_kx[t - (256 - S)][q] = k[q];
+      for (int q = 0; q < 4; ++q) s_kx[t - (NT - S)][q] = k[q];
     }
     __syncthreads();
-    for (int it = t; it < R * NV; it += 256) {
+    for (int it = t; it < R * NV; it += NT) {
       const int r = it / NV, k = it - r * NV;
       float ky[4];
       bicubic_w(sy0 + r, S, ky);
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void flowup_warp_s2d_kernel(FusedArgs a) {
       s_fl[r][0][k] = make_float2(sx_, sy_);
     }
   } else {
-    for (int it = t; it < R * NV; it += 256) {
+    for (int it = t; it < R * NV; it += NT) {
       const int r = it / NV, k = it - r * NV;
       const unsigned cc = (unsigned)reflect_src(clampi(jbase + k, 0, a.w - 1), a.fw);
       int y0, y1; float ly0, ly1;
@@ -196,7 +197,6 @@ __global__ __launch_bounds__(256) void flowup_warp_s2d_kernel(FusedArgs a) {
 
   // ---- 2. flows, sampling positions, gathers.  Thread -> 2 horizontally adjacent pixels
   //         (a, b) x RPT rows; the tile is 256 columns x R rows.
-  constexpr int RPT = R / 2;
   const int tp = t & 127, r0 = (t >> 7) * RPT;
   const int hxa = x0 + 2 * tp;
   if (hxa < WW) {
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(256) void flowup_warp_s2d_kernel(FusedArgs a) {
   if (vec_out) {
     // item -> (plane = (r, sx, ch), quad of 4 LR columns); 16 lanes cover one plane row
 #pragma unroll
-    for (int i = 0; i < (OUT_ITEMS + 255) / 256; ++i) {
-      const int it = t + i * 256;
+    for (int i = 0; i < (OUT_ITEMS + NT - 1) / NT; ++i) {
+      const int it = t + i * NT;
       const int q = it % (OXB / 4), pl = it / (OXB / 4);
       const int ox = x0 / S + 4 * q;
       if (it < OUT_ITEMS && ox < a.w) {
@@ -318,9 +318,10 @@ __global__ __launch_bounds__(256) void flowup_warp_s2d_kernel(FusedArgs a) {
       }
     }
   } else {
-    const int sx = t / OXB, oxl = t - sx * OXB;
-    const int ox = x0 / S + oxl;
-    if (ox < a.w) {
+    for (int it = t; it < S * OXB; it += NT) {
+      const int sx = it / OXB, oxl = it - sx * OXB;
+      const int ox = x0 / S + oxl;
+      if (ox >= a.w) continue;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const unsigned o = ((unsigned)(((sy0 + r) * S + sx) * C) * lrhw + (unsigned)oy * a.w + ox) * 4u;
@@ -457,10 +458,19 @@ extern "C" int tg_flowup_warp_s2d_fwd(const float* lr_flow, int fh, int fw, cons
               ((uintptr_t)out & 15) == 0 && (n == 1 || out_nstride % 4 == 0)};
   const int rows = scale;
   const int tiles = cdiv(scale * w, 256) * (scale * h / rows) * n;
-  dim3 g(tiles), t(256);
   hipStream_t s = (hipStream_t)stream;
-  if (scale == 4) hipLaunchKernelGGL((flowup_warp_s2d_kernel<4, 3, 4>), g, t, 0, s, a);
-  else hipLaunchKernelGGL((flowup_warp_s2d_kernel<2, 3, 2>), g, t, 0, s, a);
+  // rows per thread.  One frame (670 tiles at 134x320 LR) cannot fill the chip, and the kernel
+  // is then bound by the per-wave dependency chain: 1 row per thread = twice the waves, half
+  // the chain (7.1 vs 8.0 us).  Many clips per launch are throughput-bound and prefer fewer,
+  // longer waves (46 vs 49 us at 8 clips).  TG_WARP_RPT overrides (lab).
+  static const int rpt_env = [] { const char* e = getenv("TG_WARP_RPT"); return e ? atoi(e) : 0; }();
+  const int rpt = rpt_env ? rpt_env : (tiles <= 2048 ? 1 : 2);
+  if (scale == 4) {
+    if (rpt == 2) hipLaunchKernelGGL((flowup_warp_s2d_kernel<4, 3, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((flowup_warp_s2d_kernel<4, 3, 4, 1>), dim3(tiles), dim3(512), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((flowup_warp_s2d_kernel<2, 3, 2, 1>), dim3(tiles), dim3(256), 0, s, a);
+  }
   return check_launch("flowup_warp_s2d");
 }
 

@@ -227,6 +227,57 @@ def test_fused_flowup_warp_s2d_vs_oracle(ops, deg, s, h, w):
     assert err(out, ref) <= 5e-5, err(out, ref)
 
 
+def _camera_flow(n, fh, fw, pan, zoom, roll, seed):
+    """LR flow of a camera motion: per-clip pan (LR px) + zoom + roll about the centre."""
+    g = np.random.RandomState(seed)
+    ys, xs = np.meshgrid(np.arange(fh, dtype=np.float32) - fh / 2,
+                         np.arange(fw, dtype=np.float32) - fw / 2, indexing='ij')
+    out = np.empty((n, 2, fh, fw), np.float32)
+    for i in range(n):
+        px, py = (g.rand(2) - 0.5) * 2 * pan
+        z, r = (g.rand() - 0.5) * 2 * zoom, (g.rand() - 0.5) * 2 * roll
+        out[i, 0] = px + z * xs - r * ys
+        out[i, 1] = py + z * ys + r * xs
+    return torch.from_numpy(out)
+
+
+@pytest.mark.parametrize('deg,s,h,w', [('BD', 4, 20, 72), ('BI', 2, 24, 136), ('BD', 2, 18, 130),
+                                       ('BI', 4, 12, 66)])
+@pytest.mark.parametrize('pan,zoom,roll', [(0.0, 0.0, 0.0), (1.0, 0.01, 0.005), (3.0, 0.05, 0.02),
+                                           (40.0, 0.0, 0.0)])
+def test_fused_flowup_warp_s2d_smooth_flow(ops, deg, s, h, w, pan, zoom, roll):
+    """Smooth flows take the kernel's shared-gather path (two adjacent pixels served by one
+    16-byte lane); several 256-pixel segments per row incl. a partial one; a 40-LR-pixel pan
+    pushes most samples onto the clamped frame border."""
+    fh, fw = h // 2 * 2, w // 2 * 2
+    lr_flow = _camera_flow(2, fh, fw, pan, zoom, roll, seed=h + w)
+    hr_prev = rs(5, (2, 3, s * h, s * w))
+    pad = O.reflect_pad_br(lr_flow, h - fh, w - fw)
+    hr_flow = s * O.upsample(pad, s, deg)
+    ref = O.space_to_depth(O.backward_warp(hr_prev, hr_flow), s)
+    out, hf = ops.flowup_warp_s2d(dev(lr_flow), dev(hr_prev), h, w, s, ops.UP_MODE[deg],
+                                  want_hr_flow=True)
+    assert err(hf, hr_flow) <= 2e-5 * max(1.0, pan)
+    assert err(out, ref) <= 5e-5 * max(1.0, pan / 4), err(out, ref)
+
+
+def test_fused_flowup_warp_s2d_many_clips_bitwise(ops):
+    """> 2048 tiles per launch switches the kernel to 2 rows per thread; same arithmetic, so
+    the batched launch must reproduce the per-clip launches bit for bit."""
+    s, h, w, n = 4, 48, 64, 44
+    lr_flow = torch.cat([_camera_flow(n // 2, h, w, 2.0, 0.02, 0.01, seed=3),
+                         rs(8, (n // 2, 2, h, w), -4, 4)])
+    hr_prev = rs(9, (n, 3, s * h, s * w))
+    fl, pv = dev(lr_flow), dev(hr_prev)
+    big = ops.flowup_warp_s2d(fl, pv, h, w, s, ops.UP_BICUBIC)
+    for i in (0, 7, n // 2, n - 1):
+        one = ops.flowup_warp_s2d(fl[i:i + 1].contiguous(), pv[i:i + 1].contiguous(), h, w, s,
+                                  ops.UP_BICUBIC)
+        assert torch.equal(big[i:i + 1], one), i
+    ref = O.space_to_depth(O.backward_warp(hr_prev[:2], s * O.upsample(lr_flow[:2], s, 'BD')), s)
+    assert err(big[:2], ref) <= 5e-5
+
+
 # ------------------------------------------------------------------- networks
 CFGS = [('BD', 4), ('BI', 2), ('BD', 2)]
 
