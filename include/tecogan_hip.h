@@ -207,6 +207,23 @@ int tg_depth_to_space(const float* x, float* y, int n, int c, int h, int w, int 
  * dx = grad_scale * d / sqrt(d^2+eps)  (d = x - y); loss_accum or dx may be NULL. */
 int tg_charbonnier(const float* x, const float* y, int64_t n, float eps, float loss_scale,
                    float* loss_accum, float grad_scale, float* dx, tg_stream_t stream);
+/* VGGFeatureExtractor input normalisation (codes/models/networks/vgg_nets.py:29):
+ * y = (x - mean[c]) / std[c];  mean == NULL means 0 (the op's backward: dx = dy / std[c]). */
+int tg_channel_norm(const float* x, const float* mean, const float* std, float* y, int n,
+                    int c, int64_t hw, tg_stream_t stream);
+/* CosineSimilarityLoss (codes/models/optim/losses.py:53-62; F.cosine_similarity dim=1) of two
+ * (n,c,h,w) feature maps, as used for the perceptual loss at vsrgan_model.py:226-241:
+ * *loss_accum += loss_scale * sum_pixels(1 - cos);  da = grad_scale * d(sum_pixels(1 - cos))/da.
+ * Either output may be NULL. */
+int tg_cosine_loss(const float* a, const float* b, int n, int c, int64_t hw, float eps,
+                   float loss_scale, float* loss_accum, float grad_scale, float* da,
+                   tg_stream_t stream);
+/* nn.L1Loss / nn.MSELoss selected by define_criterion (codes/models/optim/__init__.py:10-14):
+ * *loss_accum += loss_scale * sum(v), dx = grad_scale * dv/dx, v = |x-y| or (x-y)^2. */
+#define TG_LOSS_L1 1
+#define TG_LOSS_MSE 2
+int tg_pixel_loss(const float* x, const float* y, int64_t n, int mode, float loss_scale,
+                  float* loss_accum, float grad_scale, float* dx, tg_stream_t stream);
 /* VanillaGANLoss (optim/losses.py:6-14) against a constant target, plus the statistics
  * VSRGANModel.train logs (vsrgan_model.py:163-164,194-195):
  * stats3[0] += scale*sum(bce), [1] += scale*sum(x), [2] += scale*sum(log(sigmoid(x)+1e-8));

@@ -465,6 +465,58 @@ def bce_with_logits(x, status, reduction='mean'):
     return v.mean() if reduction == 'mean' else v.sum()
 
 
+def pointwise_criterion(kind, x, y, reduction='mean'):
+    """define_criterion's element-wise losses, optim/__init__.py:10-18."""
+    if kind == 'CB':
+        return charbonnier(x, y, reduction)
+    d = x - y
+    v = d.abs() if kind == 'L1' else d * d
+    return v.mean() if reduction == 'mean' else v.sum()
+
+
+def cosine_similarity_loss(x, y, eps=1e-8):
+    """CosineSimilarityLoss, losses.py:53-62: 1 - mean over pixels of the channel-wise cosine;
+    F.cosine_similarity = sum_c x/max(|x|,eps) * y/max(|y|,eps)  (ATen, torch >= 1.12)."""
+    # linalg.vector_norm (not sqrt(sum)): its gradient at a zero vector is the subgradient 0,
+    # as in ATen's cosine_similarity, so a zero feature vector yields y/(eps|y|), not NaN
+    xn = torch.linalg.vector_norm(x, 2, dim=1, keepdim=True).clamp_min(eps)
+    yn = torch.linalg.vector_norm(y, 2, dim=1, keepdim=True).clamp_min(eps)
+    return 1.0 - ((x / xn) * (y / yn)).sum(1).mean()
+
+
+# --------------------------------------------------------------------------
+# VGG19 perceptual features   (codes/models/networks/vgg_nets.py:6-38;
+# architecture = torchvision vgg19 "E": conv indices below, ReLU after each, 'M' = maxpool2)
+# --------------------------------------------------------------------------
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M',
+             512, 512, 512, 512, 'M']
+VGG_MEAN, VGG_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def vgg19_features(sd, x, feature_indexs=(8, 17, 26, 35)):
+    """sd: {'features.N.weight', 'features.N.bias'}; x in [0,1].  Features are read after the
+    layer with the given index of torchvision's `vgg19().features` (ReLU / pool layers)."""
+    mean = torch.tensor(VGG_MEAN, dtype=x.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(VGG_STD, dtype=x.dtype).view(1, 3, 1, 1)
+    out = (x - mean) / std
+    feats, i = [], 0
+    for v in VGG19_CFG:
+        if v == 'M':
+            out = F.max_pool2d(out, 2, 2)
+            if i in feature_indexs:
+                feats.append(out)
+            i += 1
+        else:
+            out = F.relu(F.conv2d(out, sd[f'features.{i}.weight'], sd[f'features.{i}.bias'],
+                                  padding=1))
+            if i + 1 in feature_indexs:
+                feats.append(out)
+            i += 2
+        if i > max(feature_indexs):
+            break
+    return feats
+
+
 # --------------------------------------------------------------------------
 # D1  SpatioTemporalDiscriminator   (tecogan_nets.py:318-477)
 # --------------------------------------------------------------------------
@@ -601,13 +653,16 @@ def vsr_train_step(sd_G, adam_G, lr_data, gt_data, scale, degradation, lr=1e-4,
 
 
 # --------------------------------------------------------------------------
-# T1  VSRGANModel.train   (codes/models/vsrgan_model.py:98-286), feature_crit and
-#     feature_matching_crit disabled (BASELINE config 3: "G+D+warp losses")
+# T1  VSRGANModel.train   (codes/models/vsrgan_model.py:98-286); the perceptual and
+#     feature-matching terms are optional (BASELINE config 3 runs without them)
 # --------------------------------------------------------------------------
 def vsrgan_train_step(sd_G, sd_D, adam_G, adam_D, state, lr_data, gt_data, scale, degradation,
                       spatial_size, tempo_extent, lr_G=5e-5, lr_D=5e-5, pix_w=1.0, warp_w=1.0,
                       pp_w=0.5, gan_w=0.01, crop_border_ratio=0.75, update_threshold=0.4,
-                      reduction='mean'):
+                      reduction='mean', sd_F=None, feat_w=0.2, feature_layers=(8, 17, 26, 35),
+                      fm=None):
+    """sd_F: VGG19 weights -> perceptual loss (:226-241).  fm = dict(kind, weight, layer_norm,
+    reduction) -> feature-matching loss (:255-271)."""
     n, t, c, lr_h, lr_w = lr_data.shape
     gt_h, gt_w = gt_data.shape[3:]
     bi = upsample(lr_data.reshape(n * t, c, lr_h, lr_w), scale, degradation).view(
@@ -621,7 +676,7 @@ def vsrgan_train_step(sd_G, sd_D, adam_G, adam_D, state, lr_data, gt_data, scale
     hr = out['hr_data']
     kw = dict(lr_data=lr_data, bi_data=bi, hr_flow=out['hr_flow'], spatial_size=spatial_size,
               crop_border_ratio=crop_border_ratio)
-    real, _, merge = discriminator_forward(PD, gt_data, **kw)                 # :148
+    real, real_feats, merge = discriminator_forward(PD, gt_data, **kw)        # :148
     fake, _, _ = discriminator_forward(PD, hr.detach(), hr_flow_merge=merge, **kw)   # :154
     lreal = torch.log(torch.sigmoid(real) + 1e-8).mean()                      # :163-164
     lfake = torch.log(torch.sigmoid(fake) + 1e-8).mean()
@@ -652,9 +707,24 @@ def vsrgan_train_step(sd_G, sd_D, adam_G, adam_D, state, lr_data, gt_data, scale
     hr_fw = hr[:, :tempo_extent - 1]                                          # :246-247
     hr_bw = hr[:, tempo_extent:].flip(1)
     l_pp = pp_w * charbonnier(hr_fw, hr_bw, reduction)
-    fake_g, _, _ = discriminator_forward(PDf, hr, hr_flow_merge=merge, **kw)  # :275
+    extra = 0.0
+    if sd_F is not None:                                                      # :226-241
+        hr_f = vgg19_features(sd_F, hr.reshape(-1, c, gt_h, gt_w), feature_layers)
+        with torch.no_grad():
+            gt_f = vgg19_features(sd_F, gt_data.reshape(-1, c, gt_h, gt_w), feature_layers)
+        l_feat = feat_w * sum(cosine_similarity_loss(a, b) for a, b in zip(hr_f, gt_f))
+        extra = extra + l_feat
+        log['l_feat_G'] = l_feat.item()
+    fake_g, fake_feats, _ = discriminator_forward(PDf, hr, hr_flow_merge=merge, **kw)  # :257/:275
+    if fm is not None:                                                        # :255-271
+        ln = fm.get('layer_norm', [12.0, 14.0, 24.0, 100.0])
+        l_fm = fm.get('weight', 1) * sum(
+            pointwise_criterion(fm['kind'], ff, rf.detach(), fm.get('reduction', 'mean')) / ln[i]
+            for i, (ff, rf) in enumerate(zip(fake_feats, real_feats)))
+        extra = extra + l_fm
+        log['l_fm_G'] = l_fm.item()
     l_gan = gan_w * bce_with_logits(fake_g, True, reduction)
-    (l_pix + l_warp + l_pp + l_gan).backward()
+    (l_pix + l_warp + l_pp + l_gan + extra).backward()
     gG = {k: v.grad for k, v in PG.items() if torch.is_tensor(v) and v.requires_grad
           and v.grad is not None}
     with torch.no_grad():

@@ -52,6 +52,9 @@ SIGNATURES = {
     'tg_backward_warp_bwd': (I, [P, P, P, P, P, I, I, I, I, P]),
     'tg_depth_to_space': (I, [P, P, I, I, I, I, I, P]),
     'tg_charbonnier': (I, [P, P, I64, F, F, P, F, P, P]),
+    'tg_channel_norm': (I, [P, P, P, P, I, I, I64, P]),
+    'tg_cosine_loss': (I, [P, P, I, I, I64, F, F, P, F, P, P]),
+    'tg_pixel_loss': (I, [P, P, I64, I, F, P, F, P, P]),
     'tg_bce_logits': (I, [P, I64, F, F, P, F, P, P]),
     'tg_adam_step': (I, [P, P, P, P, I64, F, F, F, F, F, I, P]),
     'tg_axpy': (I, [P, P, F, I64, P]),

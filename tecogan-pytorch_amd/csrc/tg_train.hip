@@ -252,6 +252,78 @@ __global__ __launch_bounds__(256) void charbonnier_kernel(const float* __restric
   if (threadIdx.x == 0 && loss) atomicAdd(loss, r * scale);
 }
 
+// ---- feature (VGG) / feature-matching losses ---------------------------------------------
+// y = (x - mean[c]) / std[c]  (VGGFeatureExtractor.forward, vgg_nets.py:29).
+// mean == nullptr -> 0, which is also the op's backward: dx = dy / std[c].
+__global__ __launch_bounds__(256) void channel_norm_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ stdv,
+                                                           float* __restrict__ y, long long total,
+                                                           int c, long long hw) {
+  TG_GRID_STRIDE(i, total) {
+    int ch = (int)((i / hw) % c);
+    float m = mean ? mean[ch] : 0.f;
+    y[i] = (x[i] - m) / stdv[ch];
+  }
+}
+
+// CosineSimilarityLoss (optim/losses.py:53-62) over dim=1 of (n,c,h,w):
+//   cos_p = sum_c (a/max(|a|,eps)) (b/max(|b|,eps));  loss += scale * sum_p (1 - cos_p)
+//   da = -gscale * dcos/da,  dcos/da_c = b_c/(|a|'|b|') - [|a| > eps] cos a_c/|a|^2
+// (clamp_min passes no gradient to the norm below eps, as autograd does).
+// One thread per pixel; consecutive threads read consecutive addresses of each channel plane.
+__global__ __launch_bounds__(256) void cosine_loss_kernel(const float* __restrict__ a,
+                                                          const float* __restrict__ b, long long npix,
+                                                          int c, long long hw, float eps, float scale,
+                                                          float* __restrict__ loss, float gscale,
+                                                          float* __restrict__ da) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  TG_GRID_STRIDE(p, npix) {
+    const long long base = (p / hw) * c * hw + (p % hw);
+    float dot = 0.f, aa = 0.f, bb = 0.f;
+    for (int ch = 0; ch < c; ++ch) {
+      float av = a[base + ch * hw], bv = b[base + ch * hw];
+      dot += av * bv; aa += av * av; bb += bv * bv;
+    }
+    const float na = sqrtf(aa), nb = sqrtf(bb);
+    const float nac = fmaxf(na, eps), nbc = fmaxf(nb, eps);
+    const float inv = 1.0f / (nac * nbc);
+    const float cs = dot * inv;
+    s += 1.0f - cs;
+    if (da) {
+      const float k = na > eps ? cs / (nac * nac) : 0.f;
+      for (int ch = 0; ch < c; ++ch) {
+        float av = a[base + ch * hw], bv = b[base + ch * hw];
+        da[base + ch * hw] = -gscale * (bv * inv - k * av);
+      }
+    }
+  }
+  float r = block_sum(s, sm);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, r * scale);
+}
+
+// nn.L1Loss / nn.MSELoss (optim/__init__.py:10-14): mode 1 = |d|, 2 = d^2
+__global__ __launch_bounds__(256) void pixel_loss_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ y, long long n,
+                                                         int mode, float scale, float* __restrict__ loss,
+                                                         float gscale, float* __restrict__ dx) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  TG_GRID_STRIDE(i, n) {
+    float d = x[i] - y[i];
+    if (mode == 1) {
+      s += fabsf(d);
+      if (dx) dx[i] = gscale * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+    } else {
+      s += d * d;
+      if (dx) dx[i] = gscale * 2.f * d;
+    }
+  }
+  float r = block_sum(s, sm);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, r * scale);
+}
+
 // BCE-with-logits against a constant target t; also mean(x) and mean(log(sigmoid(x)+1e-8))
 // stats[0] += scale*sum(loss), stats[1] += scale*sum(x), stats[2] += scale*sum(log(sig+1e-8))
 __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, long long n,
@@ -490,6 +562,36 @@ extern "C" int tg_charbonnier(const float* x, const float* y, int64_t n, float e
   hipLaunchKernelGGL(charbonnier_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, x, y,
                      (long long)n, eps, loss_scale, loss_accum, grad_scale, dx);
   return check_launch("charbonnier");
+}
+
+extern "C" int tg_channel_norm(const float* x, const float* mean, const float* stdv, float* y, int n,
+                               int c, int64_t hw, tg_stream_t stream) {
+  TG_REQUIRE(x && stdv && y, TG_E_ARG, "channel_norm: null pointer");
+  TG_REQUIRE(n > 0 && c > 0 && hw > 0, TG_E_SHAPE, "channel_norm: n=%d c=%d hw=%lld", n, c, (long long)hw);
+  long long total = (long long)n * c * hw;
+  hipLaunchKernelGGL(channel_norm_kernel, dim3(grid_for(total)), dim3(256), 0, ST, x, mean, stdv, y,
+                     total, c, (long long)hw);
+  return check_launch("channel_norm");
+}
+
+extern "C" int tg_cosine_loss(const float* a, const float* b, int n, int c, int64_t hw, float eps,
+                              float loss_scale, float* loss_accum, float grad_scale, float* da,
+                              tg_stream_t stream) {
+  TG_REQUIRE(a && b && (loss_accum || da), TG_E_ARG, "cosine_loss: bad argument");
+  TG_REQUIRE(n > 0 && c > 0 && hw > 0, TG_E_SHAPE, "cosine_loss: n=%d c=%d hw=%lld", n, c, (long long)hw);
+  long long npix = (long long)n * hw;
+  hipLaunchKernelGGL(cosine_loss_kernel, dim3(grid_for(npix, 2048)), dim3(256), 0, ST, a, b, npix, c,
+                     (long long)hw, eps, loss_scale, loss_accum, grad_scale, da);
+  return check_launch("cosine_loss");
+}
+
+extern "C" int tg_pixel_loss(const float* x, const float* y, int64_t n, int mode, float loss_scale,
+                             float* loss_accum, float grad_scale, float* dx, tg_stream_t stream) {
+  TG_REQUIRE(x && y && n > 0 && (loss_accum || dx), TG_E_ARG, "pixel_loss: bad argument");
+  TG_REQUIRE(mode == TG_LOSS_L1 || mode == TG_LOSS_MSE, TG_E_ARG, "pixel_loss: mode=%d", mode);
+  hipLaunchKernelGGL(pixel_loss_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST, x, y, (long long)n,
+                     mode, loss_scale, loss_accum, grad_scale, dx);
+  return check_launch("pixel_loss");
 }
 
 extern "C" int tg_bce_logits(const float* x, int64_t n, float target, float scale, float* stats3,

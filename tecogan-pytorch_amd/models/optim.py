@@ -39,14 +39,32 @@ class Adam:
 
 
 def define_criterion(criterion_opt):
-    """codes/models/optim/__init__.py:5-35 for the criteria the shipped configs use."""
+    """codes/models/optim/__init__.py:5-35: (type, reduction) descriptors; the arithmetic is in
+    the HIP loss kernels."""
     if criterion_opt is None:
         return None
-    if criterion_opt['type'] == 'CB':
-        return ('CB', criterion_opt.get('reduction', 'mean'))
-    if criterion_opt['type'] == 'GAN':
-        return ('GAN', criterion_opt.get('reduction', 'mean'))
+    kind = criterion_opt['type']
+    if kind in ('CB', 'L1', 'MSE', 'GAN'):
+        return (kind, criterion_opt.get('reduction', 'mean'))
+    if kind == 'CosineSimilarity':
+        return (kind, 'mean')                      # losses.py:53-62 takes no reduction
+    if kind == 'LSGAN':
+        raise NotImplementedError('LSGAN criterion: no shipped configuration selects it; '
+                                  'not built on the HIP path')
     raise ValueError(f'Unrecognized criterion: {criterion_opt["type"]}')
+
+
+def pointwise_loss(crit, x, y, weight, acc):
+    """weight * crit(x, y) for the element-wise criteria: the value is accumulated into the
+    device scalar `acc`, the gradient w.r.t. x is returned."""
+    kind, reduction = crit
+    scale = weight / x.numel() if reduction == 'mean' else weight
+    if kind == 'CB':
+        return ops.charbonnier(x, y, acc, scale, grad_scale=scale)
+    if kind in ('L1', 'MSE'):
+        return ops.pixel_loss(x, y, ops.LOSS_L1 if kind == 'L1' else ops.LOSS_MSE, acc, scale,
+                              grad_scale=scale)
+    raise ValueError(f'{kind} is not an element-wise criterion')
 
 
 class _Schedule:

@@ -137,7 +137,13 @@ def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=
                 tape.defer_wgrad(('w', id(layer), 1), dz, x2, gw, c1)
             tape.defer_bias(_grad_buf(b), dz)
         wd = w.detach()
-        if need_dx:
+        if need_dx and c1 <= 4 and cout <= 64 and x2 is None:
+            # data gradient onto an image (VGG's first conv): cout -> <=4 channels is the small
+            # kernel's shape; its weights are the 180-degree rotated, transposed taps
+            wdg = _CACHE.get(('dgs', id(layer)), _ver(w),
+                             lambda: wd.flip(2, 3).permute(1, 0, 2, 3).contiguous())
+            tape.add_grad(x, ops.conv3x3_small(dz, wdg, None))
+        elif need_dx:
             pkd = _CACHE.get(('dg', id(layer), 0), _ver(w), lambda: ops.pack_conv3x3_dgrad(
                 wd[:, :c1].contiguous()))
             tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, c1, pkd[3], ksplit=1))
@@ -307,6 +313,31 @@ def backward_warp(tape, x, flow, need_dimg=True, need_dflow=True):
                 tape.add_grad(x, dimg)
             if need_dflow:
                 tape.add_grad(flow, dflow)
+        tape.record(bwd)
+    return y
+
+
+def view(tape, x, shape):
+    """Reshape of a contiguous tensor (gradients are keyed by tensor identity, so the
+    re-viewed tensor needs its own node)."""
+    y = x.view(shape)
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is not None:
+                tape.add_grad(x, g.view(x.shape))
+        tape.record(bwd)
+    return y
+
+
+def channel_norm(tape, x, mean, std):
+    """(x - mean[c]) / std[c]  (vgg_nets.py:29)."""
+    y = ops.channel_norm(x, mean, std)
+    if tape is not None:
+        def bwd():
+            g = tape.pop_grad(y)
+            if g is not None:
+                tape.add_grad(x, ops.channel_norm(g, None, std))
         tape.record(bwd)
     return y
 

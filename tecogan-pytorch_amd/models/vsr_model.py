@@ -8,7 +8,7 @@ from .. import ops
 from . import train_graph as TG
 from .base_model import BaseModel
 from .networks import define_generator
-from .optim import Adam, define_criterion, define_lr_schedule
+from .optim import Adam, define_criterion, define_lr_schedule, pointwise_loss
 
 
 class VSRModel(BaseModel):
@@ -37,9 +37,8 @@ class VSRModel(BaseModel):
 
     # -- loss helpers (value accumulates on the device; gradient returned) -----
     @staticmethod
-    def _cb(x, y, weight, reduction, acc):
-        scale = weight / x.numel() if reduction == 'mean' else weight
-        return ops.charbonnier(x, y, acc, scale, grad_scale=scale)
+    def _crit(crit, x, y, weight, acc):
+        return pointwise_loss(crit, x, y, weight, acc)
 
     def train(self):
         """vsr_model.py:61-95."""
@@ -50,13 +49,13 @@ class VSRModel(BaseModel):
         self.hr_data = out['hr_data']
         losses = torch.zeros(2, dtype=torch.float32, device=self.device)
         pix_w = self.opt['train']['pixel_crit'].get('weight', 1.0)
-        tape.add_grad(out['hr_data'], self._cb(out['hr_data'], self.gt_data.contiguous(), pix_w,
-                                               self.pix_crit[1], losses[0:1]))
+        tape.add_grad(out['hr_data'], self._crit(self.pix_crit, out['hr_data'],
+                                                 self.gt_data.contiguous(), pix_w, losses[0:1]))
         if self.warp_crit is not None:
             lr_warp = TG.backward_warp(tape, out['lr_prev'], out['lr_flow'], need_dimg=False)
             warp_w = self.opt['train']['warping_crit'].get('weight', 1.0)
-            tape.add_grad(lr_warp, self._cb(lr_warp, out['lr_curr'], warp_w, self.warp_crit[1],
-                                            losses[1:2]))
+            tape.add_grad(lr_warp, self._crit(self.warp_crit, lr_warp, out['lr_curr'], warp_w,
+                                              losses[1:2]))
         tape.backward()
         self.allreduce_grads(self.net_G)
         self.optim_G.step()

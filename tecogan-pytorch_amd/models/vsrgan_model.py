@@ -1,7 +1,8 @@
 """VSRGANModel (TecoGAN): generator + spatio-temporal discriminator with the
 adaptive D update, ping-pong loss and vanilla GAN loss
-(codes/models/vsrgan_model.py).  feature_crit (VGG) / feature_matching_crit
-are not built."""
+(codes/models/vsrgan_model.py), the VGG19 perceptual loss (feature_crit, :226-241) and the
+discriminator feature-matching loss (feature_matching_crit, :255-271)."""
+import os
 from collections import OrderedDict
 
 import torch
@@ -9,7 +10,8 @@ import torch
 from .. import ops
 from . import train_graph as TG
 from .networks import define_discriminator
-from .optim import Adam, define_criterion, define_lr_schedule
+from .networks.vgg_nets import VGGFeatureExtractor
+from .optim import Adam, define_criterion, define_lr_schedule, pointwise_loss
 from .vsr_model import VSRModel
 
 
@@ -28,14 +30,35 @@ class VSRGANModel(VSRModel):
                 self.load_network(self.net_D, load_path_D)
 
     def set_criterions(self):
+        """vsrgan_model.py:50-72."""
         tr = self.opt['train']
-        if tr.get('feature_crit') is not None or tr.get('feature_matching_crit') is not None:
-            raise NotImplementedError('feature_crit / feature_matching_crit need the VGG19 extractor '
-                                      '(torchvision weights): not built on the HIP path yet')
         self.pix_crit = define_criterion(tr.get('pixel_crit'))
         self.warp_crit = define_criterion(tr.get('warping_crit'))
+        self.feat_crit = define_criterion(tr.get('feature_crit'))
+        if self.feat_crit is not None:
+            if self.feat_crit[0] != 'CosineSimilarity':
+                raise NotImplementedError(f'feature_crit type {self.feat_crit[0]}: the shipped '
+                                          'configurations use CosineSimilarity')
+            fc = tr['feature_crit']
+            self.net_F = VGGFeatureExtractor(fc.get('feature_layers', [8, 17, 26, 35])).to(self.device)
+            self._load_vgg(fc)
         self.pp_crit = define_criterion(tr.get('pingpong_crit'))
+        self.fm_crit = define_criterion(tr.get('feature_matching_crit'))
         self.gan_crit = define_criterion(tr.get('gan_crit'))
+
+    def _load_vgg(self, fc):
+        """The reference downloads torchvision's ImageNet weights (vgg_nets.py:10).  Here they
+        are read from `train.feature_crit.load_path` (or $TECOGAN_VGG19_PTH): a torchvision
+        vgg19 state dict.  `init: default` keeps the seeded default initialisation instead
+        (benchmarks / parity tests only) -- never silently."""
+        path = fc.get('load_path') or os.environ.get('TECOGAN_VGG19_PTH')
+        if path:
+            self.net_F.load_vgg19_state_dict(torch.load(path, map_location='cpu'))
+        elif fc.get('init') != 'default':
+            raise FileNotFoundError(
+                'feature_crit needs the ImageNet VGG19 weights: set train.feature_crit.load_path '
+                '(or TECOGAN_VGG19_PTH) to a torchvision vgg19 state dict, or train.feature_crit.init: '
+                'default to run with untrained features')
 
     def set_optimizers(self):
         super().set_optimizers()
@@ -84,7 +107,7 @@ class VSRGANModel(VSRModel):
         d_in.update(out)
         tape_D = TG.Tape()
         d_in['tape'] = tape_D
-        (real_pred, _), d_out = self.net_D(gt_data, d_in)
+        (real_pred, real_feats), d_out = self.net_D(gt_data, d_in)
         d_in.update(d_out)
         (fake_pred, _), _ = self.net_D(hr_data, d_in)        # no input grad: == hr_data.detach()
 
@@ -115,22 +138,30 @@ class VSRGANModel(VSRModel):
         # === generator === (D frozen, already updated: :201-202 after :188)
         for p in self.net_D.parameters():
             p.requires_grad = False
-        losses = torch.zeros(3, dtype=torch.float32, device=self.device)
+        losses = torch.zeros(5, dtype=torch.float32, device=self.device)   # pix warp pp feat fm
         if self.pix_crit is not None:
             w_ = opt_tr['pixel_crit'].get('weight', 1)
-            tape_G.add_grad(hr_data, self._cb(hr_data, gt_data, w_, self.pix_crit[1], losses[0:1]))
+            tape_G.add_grad(hr_data, pointwise_loss(self.pix_crit, hr_data, gt_data, w_, losses[0:1]))
         if self.warp_crit is not None:
             lr_warp = TG.backward_warp(tape_G, out['lr_prev'], out['lr_flow'], need_dimg=False)
             w_ = opt_tr['warping_crit'].get('weight', 1)
-            tape_G.add_grad(lr_warp, self._cb(lr_warp, out['lr_curr'], w_, self.warp_crit[1],
-                                              losses[1:2]))
+            tape_G.add_grad(lr_warp, pointwise_loss(self.warp_crit, lr_warp, out['lr_curr'], w_,
+                                                    losses[1:2]))
+        if self.feat_crit is not None:     # perceptual loss (:226-241)
+            hr_merge = TG.view(tape_G, hr_data, (-1, c, gt_h, gt_w))
+            hr_feats = self.net_F(hr_merge, tape_G)
+            gt_feats = self.net_F(gt_data.reshape(-1, c, gt_h, gt_w).contiguous())   # detached
+            w_ = opt_tr['feature_crit'].get('weight', 1)
+            for hf, gf in zip(hr_feats, gt_feats):
+                sc = w_ / (hf.shape[0] * hf.shape[2] * hf.shape[3])         # 1 - mean(cos)
+                tape_G.add_grad(hf, ops.cosine_loss(hf, gf, losses[3:4], sc, grad_scale=sc))
+            del gt_feats
         if self.pp_crit is not None:
             te = opt_tr['tempo_extent']
             hr_fw = hr_data[:, :te - 1].contiguous()
             hr_bw = hr_data[:, te:].flip(1).contiguous()
             w_ = opt_tr['pingpong_crit'].get('weight', 1)
-            scale = w_ / hr_fw.numel() if self.pp_crit[1] == 'mean' else w_
-            g = ops.charbonnier(hr_fw, hr_bw, losses[2:3], scale, grad_scale=scale)
+            g = pointwise_loss(self.pp_crit, hr_fw, hr_bw, w_, losses[2:3])
             full = torch.zeros_like(hr_data)
             full[:, :te - 1] = g
             tape_G.add_grad(hr_data, full)
@@ -139,7 +170,14 @@ class VSRGANModel(VSRModel):
             tape_G.add_grad(hr_data, self._neg(full2))
         d_in['tape'] = tape_G
         d_in['need_input_grad'] = True
-        (fake_pred_G, _), _ = self.net_D(hr_data, d_in)
+        (fake_pred_G, fake_feats), _ = self.net_D(hr_data, d_in)
+        if self.fm_crit is not None:       # feature matching (:255-271); real features are
+            fo = opt_tr['feature_matching_crit']                     # those of the D pass above
+            layer_norm = fo.get('layer_norm', [12.0, 14.0, 24.0, 100.0])
+            w_ = fo.get('weight', 1)
+            for i, (ff, rf) in enumerate(zip(fake_feats, real_feats)):
+                tape_G.add_grad(ff, pointwise_loss(self.fm_crit, ff, rf, w_ / layer_norm[i],
+                                                   losses[4:5]))
         st_g = torch.zeros(3, dtype=torch.float32, device=self.device)
         gan_w = opt_tr['gan_crit'].get('weight', 1)
         tape_G.add_grad(fake_pred_G, ops.bce_logits(fake_pred_G, 1.0, st_g, 1.0 / n_clip,
@@ -161,8 +199,12 @@ class VSRGANModel(VSRModel):
             self.log_dict['l_pix_G'] = ls[0]
         if self.warp_crit is not None:
             self.log_dict['l_warp_G'] = ls[1]
+        if self.feat_crit is not None:
+            self.log_dict['l_feat_G'] = ls[3]
         if self.pp_crit is not None:
             self.log_dict['l_pp_G'] = ls[2]
+        if self.fm_crit is not None:
+            self.log_dict['l_fm_G'] = ls[4]
         self.log_dict['l_gan_G'] = gan_w * sg[0]
         self.log_dict['p_fake_G'] = sg[1]
 

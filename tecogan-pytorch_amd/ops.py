@@ -310,6 +310,45 @@ def charbonnier(x, y, loss_accum, loss_scale, grad_scale=None, eps=1e-6):
     return dx
 
 
+LOSS_L1, LOSS_MSE = 1, 2
+
+
+def pixel_loss(x, y, mode, loss_accum, loss_scale, grad_scale=None):
+    """L1 / MSE: loss_accum[0] += loss_scale * sum v(x-y); returns scaled d loss / dx or None."""
+    _chk(x, 'x'); _chk(y, 'y')
+    if x.shape != y.shape:
+        raise L.TecoganHipError(f'pixel_loss: {tuple(x.shape)} vs {tuple(y.shape)}')
+    dx = torch.empty_like(x) if grad_scale is not None else None
+    L.check(L.lib().tg_pixel_loss(x.data_ptr(), y.data_ptr(), x.numel(), int(mode), float(loss_scale),
+                                  _ptr(loss_accum), float(grad_scale or 0.0), _ptr(dx), _stream()),
+            'tg_pixel_loss')
+    return dx
+
+
+def channel_norm(x, mean, std):
+    """(x - mean[c]) / std[c] over (n,c,h,w); mean None = 0."""
+    _chk(x, 'x'); _chk(std, 'std')
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    L.check(L.lib().tg_channel_norm(x.data_ptr(), _ptr(mean), std.data_ptr(), y.data_ptr(), n, c, h * w,
+                                    _stream()), 'tg_channel_norm')
+    return y
+
+
+def cosine_loss(a, b, loss_accum, loss_scale, grad_scale=None, eps=1e-8):
+    """loss_accum[0] += loss_scale * sum_pixels (1 - cos_c(a, b)); returns the scaled gradient
+    w.r.t. a or None."""
+    _chk(a, 'a'); _chk(b, 'b')
+    if a.shape != b.shape:
+        raise L.TecoganHipError(f'cosine_loss: {tuple(a.shape)} vs {tuple(b.shape)}')
+    n, c, h, w = a.shape
+    da = torch.empty_like(a) if grad_scale is not None else None
+    L.check(L.lib().tg_cosine_loss(a.data_ptr(), b.data_ptr(), n, c, h * w, float(eps),
+                                   float(loss_scale), _ptr(loss_accum), float(grad_scale or 0.0),
+                                   _ptr(da), _stream()), 'tg_cosine_loss')
+    return da
+
+
 def bce_logits(x, target, stats3, scale, grad_scale=None):
     _chk(x, 'x')
     dx = torch.empty_like(x) if grad_scale is not None else None

@@ -107,3 +107,24 @@ def smooth_clip(t, c, h, w, seed=0, shift=1.5):
         img += rs.uniform(-0.02, 0.02, img.shape).astype(np.float32)
         frames.append(np.clip(img, 0, 1))
     return torch.from_numpy(np.stack(frames).astype(np.float32))
+
+
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M',
+             512, 512, 512, 512, 'M']
+
+
+def vgg19_state_dict(seed=0):
+    """`features.N.weight/bias` of torchvision's vgg19 layout (configuration E) with
+    procedural He-scaled weights: the ImageNet weights cannot be obtained offline, and the
+    parity of the perceptual-loss arithmetic does not depend on their values."""
+    sd, cin, i = {}, 3, 0
+    for v in VGG19_CFG:
+        if v == 'M':
+            i += 1
+            continue
+        # gain sqrt(2): keeps post-ReLU activations O(1) through 16 layers
+        _conv(sd, f'features.{i}', v, cin, 3, seed, gain=float(np.sqrt(2.0)))
+        sd[f'features.{i}.bias'] = sd[f'features.{i}.bias'] * 0.1 + 0.01
+        cin = v
+        i += 2
+    return sd
