@@ -167,6 +167,22 @@ int tg_maxpool2_fwd(const float* x, float* y, int nc, int h, int w,
 int tg_quantize_u8_hwc(const float* x, uint8_t* y, int c, int h, int w,
                        tg_stream_t stream);
 
+/* uint8 HWC frames -> fp32 CHW in [0,1], the `gt.permute(0,3,1,2).float() / 255.0` of
+ * BaseModel.prepare_inference_data (codes/models/base_model.py:112).
+ * x (n,h,w,c) uint8 -> y (n,c,h,w) fp32. */
+int tg_dequantize_u8_hwc(const uint8_t* x, float* y, int n, int c, int h, int w,
+                         tg_stream_t stream);
+
+/* MetricCalculator.compute_PSNR (codes/metrics/metric_calculator.py:228-244) on uint8 HWC
+ * frames resident on the device: sse[f] = sum of squared differences of frame f, exact
+ * (integers), on the Y channel of rgb_to_ycbcr (codes/utils/data_utils.py:56-77) when
+ * y_only, else over the three RGB channels.  PSNR = 20 log10(255 / sqrt(sse / count)). */
+int tg_psnr_sse_u8(const uint8_t* true_hwc, const uint8_t* pred_hwc, uint64_t* sse,
+                   int frames, int h, int w, int y_only, tg_stream_t stream);
+/* Y channel of rgb_to_ycbcr for n RGB triples (n,3) uint8 -> (n) uint8; exposed so the
+ * conversion can be checked exhaustively against numpy. */
+int tg_luma_u8(const uint8_t* rgb, uint8_t* y, int64_t n, tg_stream_t stream);
+
 /* ========================================================================
  * Training side: backward kernels.
  * Conv data gradients reuse tg_conv3x3_fwd with weights packed by

@@ -43,6 +43,9 @@ SIGNATURES = {
     'tg_upsample_fwd': (I, [P, P, I, I, I, I, I, F, P]),
     'tg_maxpool2_fwd': (I, [P, P, I, I, I, P]),
     'tg_quantize_u8_hwc': (I, [P, P, I, I, I, P]),
+    'tg_dequantize_u8_hwc': (I, [P, P, I, I, I, I, P]),
+    'tg_psnr_sse_u8': (I, [P, P, P, I, I, I, I, P]),
+    'tg_luma_u8': (I, [P, P, I64, P]),
     'tg_wgrad3x3_workspace_floats': (SZ, [I, I, I, I, I]),
     'tg_wgrad3x3': (I, [P, I64, P, I64, P, P, I, I, I, I, I, I, I, I, P]),
     'tg_act_bwd': (I, [P, P, P, I64, I, P]),

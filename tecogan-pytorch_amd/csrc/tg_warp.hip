@@ -428,6 +428,67 @@ __global__ void quantize_u8_hwc_kernel(const float* __restrict__ x, uint8_t* __r
   }
 }
 
+// uint8 HWC frames -> fp32 CHW in [0,1]: `gt.permute(0,3,1,2).float() / 255.0`
+// (base_model.py:112).  x (n,h,w,c) uint8 -> y (n,c,h,w), true division.
+__global__ void dequantize_u8_hwc_kernel(const uint8_t* __restrict__ x, float* __restrict__ y,
+                                         int c, int h, int w, long long total) {
+  const long long hw = (long long)h * w;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long p = i % hw; long long t = i / hw;
+    int ch = (int)(t % c); long long f = t / c;
+    y[i] = (float)x[(f * hw + p) * c + ch] / 255.0f;
+  }
+}
+
+// Y of rgb_to_ycbcr (data_utils.py:56-77): uint8(round(clip(r*T00 + g*T10 + b*T20 + 16)))
+// in float64, products and sums rounded separately, left to right (numpy's matmul loop);
+// rint = round-half-even like np.round.
+__device__ __forceinline__ int luma_u8(int r, int g, int b) {
+  double v = __dadd_rn(__dadd_rn(__dmul_rn((double)r, 0.256788235294118),
+                                 __dmul_rn((double)g, 0.504129411764706)),
+                       __dmul_rn((double)b, 0.097905882352941));
+  v = __dadd_rn(v, 16.0);
+  v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+  return (int)rint(v);
+}
+
+// compute_PSNR's sum of squared differences (metric_calculator.py:228-240) per frame, exact
+// (integers): y_only = 1 -> on the Y channel, 0 -> over the three RGB channels.
+__global__ __launch_bounds__(256) void psnr_sse_u8_kernel(const uint8_t* __restrict__ a,
+                                                          const uint8_t* __restrict__ b,
+                                                          unsigned long long* __restrict__ sse,
+                                                          long long hw, int y_only) {
+  __shared__ unsigned long long sm[4];
+  const int f = blockIdx.y;
+  const uint8_t* pa = a + (long long)f * hw * 3;
+  const uint8_t* pb = b + (long long)f * hw * 3;
+  unsigned long long s = 0;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < hw;
+       p += (long long)gridDim.x * blockDim.x) {
+    int ar = pa[3 * p], ag = pa[3 * p + 1], ab = pa[3 * p + 2];
+    int br = pb[3 * p], bg = pb[3 * p + 1], bb = pb[3 * p + 2];
+    if (y_only) {
+      int d = luma_u8(ar, ag, ab) - luma_u8(br, bg, bb);
+      s += (unsigned long long)(d * d);
+    } else {
+      int d0 = ar - br, d1 = ag - bg, d2 = ab - bb;
+      s += (unsigned long long)(d0 * d0 + d1 * d1 + d2 * d2);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sse + f, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+// test hook for luma_u8: y[i] = Y(rgb[i])
+__global__ void luma_u8_kernel(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ y, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    y[i] = (uint8_t)luma_u8(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+}
+
 static inline int grid1d(long long total) {
   long long b = (total + 255) / 256;
   return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -526,4 +587,35 @@ extern "C" int tg_quantize_u8_hwc(const float* x, uint8_t* y, int c, int h, int 
   hipLaunchKernelGGL(quantize_u8_hwc_kernel, dim3(grid1d(total)), dim3(256), 0,
                      (hipStream_t)stream, x, y, c, h, w);
   return check_launch("quantize_u8");
+}
+
+extern "C" int tg_dequantize_u8_hwc(const uint8_t* x, float* y, int n, int c, int h, int w,
+                                    tg_stream_t stream) {
+  TG_REQUIRE(x && y, TG_E_ARG, "dequantize_u8: null pointer");
+  TG_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, TG_E_SHAPE, "dequantize_u8: n=%d c=%d h=%d w=%d", n, c, h, w);
+  long long total = (long long)n * c * h * w;
+  hipLaunchKernelGGL(dequantize_u8_hwc_kernel, dim3(grid1d(total)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, c, h, w, total);
+  return check_launch("dequantize_u8");
+}
+
+extern "C" int tg_psnr_sse_u8(const uint8_t* true_hwc, const uint8_t* pred_hwc, uint64_t* sse,
+                              int frames, int h, int w, int y_only, tg_stream_t stream) {
+  TG_REQUIRE(true_hwc && pred_hwc && sse, TG_E_ARG, "psnr_sse_u8: null pointer");
+  TG_REQUIRE(frames > 0 && frames < 65536 && h > 0 && w > 0, TG_E_SHAPE,
+             "psnr_sse_u8: frames=%d h=%d w=%d", frames, h, w);
+  const long long hw = (long long)h * w;
+  if (hipMemsetAsync(sse, 0, sizeof(uint64_t) * frames, (hipStream_t)stream) != hipSuccess)
+    return check_launch("psnr_sse_u8 memset");
+  long long bx = (hw + 1023) / 1024;
+  hipLaunchKernelGGL(psnr_sse_u8_kernel, dim3((unsigned)(bx > 512 ? 512 : bx), frames), dim3(256), 0,
+                     (hipStream_t)stream, true_hwc, pred_hwc, (unsigned long long*)sse, hw, y_only);
+  return check_launch("psnr_sse_u8");
+}
+
+extern "C" int tg_luma_u8(const uint8_t* rgb, uint8_t* y, int64_t n, tg_stream_t stream) {
+  TG_REQUIRE(rgb && y && n > 0, TG_E_ARG, "luma_u8: bad argument");
+  hipLaunchKernelGGL(luma_u8_kernel, dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, rgb, y,
+                     (long long)n);
+  return check_launch("luma_u8");
 }

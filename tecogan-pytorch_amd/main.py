@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import yaml
 
-from .metrics.psnr import compute_psnr
+from .metrics.psnr import compute_psnr, compute_psnr_device
 from .models import define_model
 from .models.networks import define_generator
 from .utils import dist_utils
@@ -119,9 +119,11 @@ def test(opt, sequences):
     for idx in dist_utils.shard_indices(len(sequences)):
         data = sequences[idx]
         model.prepare_inference_data(data)
-        hr_seq = model.infer()
-        gt = data['gt'].numpy()
-        vals[idx] = float(np.mean([compute_psnr(gt[i], hr_seq[i]) for i in range(len(hr_seq))]))
+        # output frames stay on the GPU; the GT clip goes up as raw uint8; the squared-error
+        # sums come from the HIP kernel (metric_calculator.py:228-244 without the host trip)
+        hr_seq = model.infer(device_output=True).contiguous()
+        gt = data['gt'].to(hr_seq.device).contiguous()
+        vals[idx] = float(np.mean(compute_psnr_device(gt, hr_seq)))
     red = dist_utils.reduce_sum_to_master(vals, device=opt['device'] if opt['dist'] else 'cpu')
     if rank == 0:
         for d, v in zip(sequences, red.tolist()):

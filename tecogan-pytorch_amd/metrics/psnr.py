@@ -21,3 +21,18 @@ def compute_psnr(true_img, pred_img, colorspace='y'):
     diff = true_img.astype(np.float64) - pred_img.astype(np.float64)
     rmse = np.sqrt(np.mean(np.power(diff, 2)))
     return np.inf if rmse == 0 else 20 * np.log10(255.0 / rmse)
+
+
+def compute_psnr_device(true_u8, pred_u8, colorspace='y'):
+    """compute_PSNR for whole clips resident on the GPU: (t,h,w,3) uint8 CUDA tensors ->
+    list of per-frame dB values.  The squared-error sums are exact integers computed by the
+    HIP kernel; only the final 20*log10(255/rmse) per frame is host arithmetic."""
+    from .. import ops
+    sse = ops.psnr_sse_u8(true_u8, pred_u8, y_only=(colorspace == 'y')).tolist()
+    t, h, w, c = true_u8.shape
+    count = h * w * (1 if colorspace == 'y' else c)
+    out = []
+    for s_ in sse:
+        rmse = np.sqrt(s_ / count)
+        out.append(np.inf if rmse == 0 else 20 * np.log10(255.0 / rmse))
+    return out

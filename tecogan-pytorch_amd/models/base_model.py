@@ -65,7 +65,11 @@ class BaseModel:
         else:
             scale = self.opt['scale']
             sigma = self.opt['dataset']['degradation'].get('sigma', 1.5)
-            gt = data['gt'].permute(0, 3, 1, 2).float().div(255.0).to(self.device).contiguous()
+            gt = data['gt']
+            if gt.dtype == torch.uint8:         # raw bytes over PCIe, converted by the HIP kernel
+                gt = ops.dequantize_u8_hwc(gt.to(self.device).contiguous())
+            else:
+                gt = gt.permute(0, 3, 1, 2).float().div(255.0).to(self.device).contiguous()
             lr = ops.downsample_bd(gt, gaussian_kernel2d(sigma), scale, pad=True).permute(0, 2, 3, 1)
         self.lr_data = lr.permute(0, 3, 1, 2)
 

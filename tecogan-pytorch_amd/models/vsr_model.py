@@ -64,11 +64,16 @@ class VSRModel(BaseModel):
         if self.warp_crit is not None:
             self.log_dict['l_warp_G'] = vals[1]
 
-    def infer(self):
-        """vsr_model.py:97-113: temporal padding, inference, crop the padding back."""
+    def infer(self, device_output=False):
+        """vsr_model.py:97-113: temporal padding, inference, crop the padding back.
+        device_output=True keeps the (t,H,W,3) uint8 result on the GPU (for the on-device
+        PSNR) instead of returning the reference's numpy array."""
         lr_data, n_pad_front = self.pad_sequence(self.lr_data)
         self.net_G.eval()
-        hr_seq = self.net_G(lr_data, self.device)
+        if device_output:
+            hr_seq = self.net_G.infer_sequence(lr_data, self.device, return_device_tensor=True)
+        else:
+            hr_seq = self.net_G(lr_data, self.device)
         return hr_seq[n_pad_front:]
 
     def save(self, current_iter):

@@ -199,6 +199,43 @@ def quantize_u8_hwc(x):
     return out
 
 
+def _chk_u8(t, name):
+    if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+        raise L.TecoganHipError(f'{name}: expected a contiguous CUDA uint8 tensor, got '
+                                f'{t.dtype} {t.device} contiguous={t.is_contiguous()}')
+    return t
+
+
+def dequantize_u8_hwc(x):
+    """(n,h,w,c) uint8 on device -> (n,c,h,w) fp32 in [0,1] (= permute + float + /255)."""
+    _chk_u8(x, 'x')
+    n, h, w, c = x.shape
+    out = torch.empty(n, c, h, w, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_dequantize_u8_hwc(x.data_ptr(), out.data_ptr(), n, c, h, w, _stream()),
+            'tg_dequantize_u8_hwc')
+    return out
+
+
+def psnr_sse_u8(true_hwc, pred_hwc, y_only=True):
+    """Per-frame sum of squared differences of (t,h,w,3) uint8 device tensors -> int64 (t,)."""
+    _chk_u8(true_hwc, 'true'); _chk_u8(pred_hwc, 'pred')
+    if true_hwc.shape != pred_hwc.shape or true_hwc.dim() != 4 or true_hwc.shape[3] != 3:
+        raise L.TecoganHipError(f'psnr_sse_u8: shapes {tuple(true_hwc.shape)} / {tuple(pred_hwc.shape)}')
+    t, h, w, _ = true_hwc.shape
+    sse = torch.empty(t, dtype=torch.int64, device=true_hwc.device)
+    L.check(L.lib().tg_psnr_sse_u8(true_hwc.data_ptr(), pred_hwc.data_ptr(), sse.data_ptr(), t, h, w,
+                                   1 if y_only else 0, _stream()), 'tg_psnr_sse_u8')
+    return sse
+
+
+def luma_u8(rgb):
+    """(n,3) uint8 -> (n,) uint8, the Y channel of rgb_to_ycbcr."""
+    _chk_u8(rgb, 'rgb')
+    out = torch.empty(rgb.shape[0], dtype=torch.uint8, device=rgb.device)
+    L.check(L.lib().tg_luma_u8(rgb.data_ptr(), out.data_ptr(), rgb.shape[0], _stream()), 'tg_luma_u8')
+    return out
+
+
 # ---------------------------------------------------------------------------
 # training-side wrappers (backward kernels, losses, optimiser)
 # ---------------------------------------------------------------------------

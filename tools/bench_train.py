@@ -22,6 +22,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--model', default='TecoGAN')
     ap.add_argument('--force-d', action='store_true', help='update D every step (threshold = +inf)')
+    ap.add_argument('--feature-crit', action='store_true',
+                    help='add the VGG19 perceptual loss of the shipped TecoGAN yml (weight 0.2, layers '
+                         '8/17/26/35; default-initialised VGG weights: the timing does not depend on them)')
+    ap.add_argument('--fm-crit', action='store_true', help='add the discriminator feature-matching loss (CB)')
     a = ap.parse_args()
     from tecogan_pytorch_amd.models import define_model
     opt = {
@@ -42,6 +46,11 @@ def main():
     }
     if a.model == 'FRVSR':
         del opt['train']['pingpong_crit'], opt['train']['gan_crit']
+    if a.feature_crit:
+        opt['train']['feature_crit'] = {'type': 'CosineSimilarity', 'weight': 0.2, 'reduction': 'mean',
+                                        'feature_layers': [8, 17, 26, 35], 'init': 'default'}
+    if a.fm_crit:
+        opt['train']['feature_matching_crit'] = {'type': 'CB', 'weight': 1.0, 'reduction': 'mean'}
     torch.manual_seed(0)
     m = define_model(opt)
     gen = torch.Generator().manual_seed(1)
@@ -59,7 +68,7 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     tt = 2 * a.tempo - 1 if a.model != 'FRVSR' else a.tempo
     print(json.dumps({'model': a.model, 'crop': a.crop, 'batch': a.batch, 'tempo_extent': a.tempo,
-                      'ms_per_step': 1e3 * dt, 'steps_per_s': 1 / dt,
+                      'feature_crit': a.feature_crit, 'fm_crit': a.fm_crit, 'ms_per_step': 1e3 * dt, 'steps_per_s': 1 / dt,
                       'hr_frames_per_s': a.batch * tt / dt, 'd_updates': nupd, 'steps': a.steps,
                       'last_log': {k: float(v) for k, v in m.log_dict.items()},
                       'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30}))
