@@ -199,6 +199,16 @@ int tg_wgrad3x3(const float* p, int64_t p_nstride, const float* q, int64_t q_nst
                 float* grad, float* workspace, int n, int ca, int cb, int cb_total,
                 int cb_off, int h, int w, int accumulate, tg_stream_t stream);
 
+/* tg_wgrad3x3 / tg_bias_grad over a batch that lives in `nseg` (<= 64) separately allocated
+ * segments of `n_per_seg` images each -- the per-frame tensors of a layer that is applied
+ * once per unrolled frame (FRNet.forward_sequence, tecogan_nets.py:174-225).  p_list / q_list /
+ * dy_list are HOST arrays of device pointers; they are read during the call only. */
+int tg_wgrad3x3_multi(const float* const* p_list, const float* const* q_list, int nseg,
+                      int64_t p_nstride, int64_t q_nstride, float* grad, float* workspace,
+                      int n_per_seg, int ca, int cb, int cb_total, int cb_off, int h, int w,
+                      int accumulate, tg_stream_t stream);
+int tg_bias_grad_multi(const float* const* dy_list, int nseg, float* db, int n_per_seg, int c,
+                       int hw, int accumulate, tg_stream_t stream);
 /* dx = dy * act'(.), expressed through the activation OUTPUT y (ReLU, LeakyReLU(0.2),
  * tanh*24).  dx may alias dy. */
 int tg_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int act,

@@ -55,7 +55,8 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
 // db[c] += sum over n, h, w of dy[n][c][h][w]; grid = (channel, slice): each block reduces a
 // slice of the (n, hw) range and adds its partial with one atomic (db is zeroed first when
 // not accumulating), so large batched gradients (19 frames x HR) fill the GPU.
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy,
+struct BiasGradSegs { const float* seg[64]; };
+__global__ __launch_bounds__(256) void bias_grad_kernel(BiasGradSegs dy, int n_per_seg,
                                                         float* __restrict__ db, int n, int c,
                                                         int hw, int nslice) {
   __shared__ float sm[4];
@@ -67,7 +68,9 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
   float s = 0.f;
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     long long b = i / hw; long long r = i - b * hw;
-    s += dy[(b * c + ch) * hw + r];
+    const int sg = (int)(b / n_per_seg);
+    const long long lb = b - (long long)sg * n_per_seg;
+    s += dy.seg[sg][(lb * c + ch) * hw + r];
   }
   float r = block_sum(s, sm);
   if (threadIdx.x == 0) atomicAdd(db + ch, r);
@@ -502,19 +505,38 @@ extern "C" int tg_act_bwd(const float* dy, const float* y, float* dx, int64_t n,
   return check_launch("act_bwd");
 }
 
-extern "C" int tg_bias_grad(const float* dy, float* db, int n, int c, int hw, int accumulate,
-                            tg_stream_t stream) {
-  TG_REQUIRE(dy && db && n > 0 && c > 0 && hw > 0, TG_E_ARG, "bias_grad: bad argument");
+static int bias_grad_launch(const float* const* dy_list, int nseg, float* db, int n_per_seg, int c,
+                            int hw, int accumulate, tg_stream_t stream) {
+  TG_REQUIRE(dy_list && db && nseg >= 1 && nseg <= 64 && n_per_seg > 0 && c > 0 && hw > 0, TG_E_ARG,
+             "bias_grad: bad argument");
+  BiasGradSegs segs{};
+  for (int i = 0; i < nseg; ++i) {
+    TG_REQUIRE(dy_list[i], TG_E_ARG, "bias_grad: null segment %d", i);
+    segs.seg[i] = dy_list[i];
+  }
   if (!accumulate) {
     hipError_t e = hipMemsetAsync(db, 0, (size_t)c * sizeof(float), ST);
     TG_REQUIRE(e == hipSuccess, TG_E_HIP, "bias_grad: memset: %s", hipGetErrorString(e));
   }
+  const int n = nseg * n_per_seg;
   long long total = (long long)n * hw;
   int nslice = (int)((total + 16383) / 16384);
   if (nslice < 1) nslice = 1;
   if (nslice * c > 4096) nslice = 4096 / c > 0 ? 4096 / c : 1;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(c, nslice), dim3(256), 0, ST, dy, db, n, c, hw, nslice);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(c, nslice), dim3(256), 0, ST, segs, n_per_seg, db, n, c, hw,
+                     nslice);
   return check_launch("bias_grad");
+}
+
+extern "C" int tg_bias_grad(const float* dy, float* db, int n, int c, int hw, int accumulate,
+                            tg_stream_t stream) {
+  TG_REQUIRE(dy, TG_E_ARG, "bias_grad: null pointer");
+  return bias_grad_launch(&dy, 1, db, n, c, hw, accumulate, stream);
+}
+
+extern "C" int tg_bias_grad_multi(const float* const* dy_list, int nseg, float* db, int n_per_seg,
+                                  int c, int hw, int accumulate, tg_stream_t stream) {
+  return bias_grad_launch(dy_list, nseg, db, n_per_seg, c, hw, accumulate, stream);
 }
 
 extern "C" int tg_maxpool2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w,

@@ -31,9 +31,14 @@ constexpr int WG_A_FLOATS = 64 * WG_CSA;
 constexpr int WG_B_FLOATS = 64 * WG_CSB;
 constexpr unsigned WG_OOB = 0x80000000u;
 
+constexpr int WG_MAXSEG = 64;
 struct WgradArgs {
-  const float* p;   // (n, ca, h, w)  unshifted operand (dZ)
-  const float* q;   // (n, cb, h, w)  shifted operand (X)
+  // The batch may be split over up to WG_MAXSEG separately allocated segments of n_per_seg
+  // images each (the unrolled frames of a recurrent layer): image i lives in segment
+  // i / n_per_seg.  pseg = unshifted operand (dZ) (n_per_seg, ca, h, w); qseg = shifted (X).
+  const float* pseg[WG_MAXSEG];
+  const float* qseg[WG_MAXSEG];
+  int n_per_seg;
   float* part;      // [nsplit][ca][cb_total][9] raw partial sums
   long long p_ns, q_ns;
   int ca, cb, cb_total, cb_off;   // G is written at columns [cb_off, cb_off+cb) of a cb_total-wide matrix
@@ -76,10 +81,12 @@ __global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) {
     int rem = tile - n * (a.tiles_x * a.tiles_y);
     int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     int x0 = tx * WG_TW, y0 = ty * WG_R;
+    const int seg = __builtin_amdgcn_readfirstlane(n / a.n_per_seg);
+    const int ln = __builtin_amdgcn_readfirstlane(n - seg * a.n_per_seg);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.p + (long long)n * a.p_ns), 0, a.ca * hw * 4, 0x00020000);
+        const_cast<float*>(a.pseg[seg] + (long long)ln * a.p_ns), 0, a.ca * hw * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.q + (long long)n * a.q_ns), 0, a.cb * hw * 4, 0x00020000);
+        const_cast<float*>(a.qseg[seg] + (long long)ln * a.q_ns), 0, a.cb * hw * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
       int idx = tid + i * 256;
@@ -173,19 +180,39 @@ __global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) {
   }
 }
 
-// g[e] = (accumulate ? g[e] : 0) + sum_s part[s][e]  over the written column range
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ g,
-                                    int nsplit, int ca, int cb, int cb_total, int cb_off,
-                                    int accumulate) {
+// g[e] = (accumulate ? g[e] : 0) + sum_s part[s][e]  over the written column range.
+// A block reduces 64 consecutive outputs; its 4 waves take interleaved quarters of the splits
+// (coalesced 256-byte rows, 4 independent chains per thread) and are combined through LDS in a
+// fixed order, so the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part,
+                                                           float* __restrict__ g, int nsplit, int ca,
+                                                           int cb, int cb_total, int cb_off,
+                                                           int accumulate) {
+  __shared__ float sm[4][64];
   const long long stride = (long long)ca * cb_total * 9;
   const long long total = (long long)ca * cb * 9;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
+  const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + o;
+  long long e = 0;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < total) {
     int t = (int)(i % 9); long long r = i / 9;
     int bj = (int)(r % cb); int ai = (int)(r / cb);
-    long long e = ((long long)ai * cb_total + cb_off + bj) * 9 + t;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[k * stride + e];
+    e = ((long long)ai * cb_total + cb_off + bj) * 9 + t;
+    const float* p = part + e;
+    int k = sg;
+    for (; k + 12 < nsplit; k += 16) {
+      s0 += p[(long long)k * stride];
+      s1 += p[(long long)(k + 4) * stride];
+      s2 += p[(long long)(k + 8) * stride];
+      s3 += p[(long long)(k + 12) * stride];
+    }
+    for (; k < nsplit; k += 4) s0 += p[(long long)k * stride];
+  }
+  sm[sg][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sg == 0 && i < total) {
+    float s = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
     g[e] = accumulate ? g[e] + s : s;
   }
 }
@@ -209,17 +236,26 @@ extern "C" size_t tg_wgrad3x3_workspace_floats(int n, int ca, int cb_total, int 
   return (size_t)wgrad_nsplit(n, h, w, ca, cb_total) * ca * cb_total * 9;
 }
 
-extern "C" int tg_wgrad3x3(const float* p, int64_t p_nstride, const float* q, int64_t q_nstride,
-                           float* grad, float* workspace, int n, int ca, int cb, int cb_total,
-                           int cb_off, int h, int w, int accumulate, tg_stream_t stream) {
-  TG_REQUIRE(p && q && grad && workspace, TG_E_ARG, "wgrad3x3: null pointer");
-  TG_REQUIRE(n > 0 && ca > 0 && cb > 0 && h > 0 && w > 0 && cb_off >= 0 && cb_off + cb <= cb_total,
-             TG_E_SHAPE, "wgrad3x3: n=%d ca=%d cb=%d (+%d of %d) h=%d w=%d", n, ca, cb, cb_off,
+static int wgrad_launch(const float* const* p_list, const float* const* q_list, int nseg,
+                        int64_t p_nstride, int64_t q_nstride, float* grad, float* workspace,
+                        int n_per_seg, int ca, int cb, int cb_total, int cb_off, int h, int w,
+                        int accumulate, tg_stream_t stream) {
+  TG_REQUIRE(p_list && q_list && grad && workspace, TG_E_ARG, "wgrad3x3: null pointer");
+  TG_REQUIRE(nseg >= 1 && nseg <= WG_MAXSEG, TG_E_ARG, "wgrad3x3: %d segments (1..%d)", nseg, WG_MAXSEG);
+  TG_REQUIRE(n_per_seg > 0 && ca > 0 && cb > 0 && h > 0 && w > 0 && cb_off >= 0 &&
+                 cb_off + cb <= cb_total, TG_E_SHAPE,
+             "wgrad3x3: n=%dx%d ca=%d cb=%d (+%d of %d) h=%d w=%d", nseg, n_per_seg, ca, cb, cb_off,
              cb_total, h, w);
   TG_REQUIRE((long long)(ca > cb ? ca : cb) * h * w * 4 < (1ll << 31), TG_E_SHAPE,
              "wgrad3x3: one batch item must be < 2 GiB");
   WgradArgs a{};
-  a.p = p; a.q = q; a.part = workspace; a.p_ns = p_nstride; a.q_ns = q_nstride;
+  for (int i = 0; i < nseg; ++i) {
+    TG_REQUIRE(p_list[i] && q_list[i], TG_E_ARG, "wgrad3x3: null segment %d", i);
+    a.pseg[i] = p_list[i]; a.qseg[i] = q_list[i];
+  }
+  const int n = nseg * n_per_seg;
+  a.n_per_seg = n_per_seg;
+  a.part = workspace; a.p_ns = p_nstride; a.q_ns = q_nstride;
   a.ca = ca; a.cb = cb; a.cb_total = cb_total; a.cb_off = cb_off; a.n = n; a.h = h; a.w = w;
   a.tiles_x = cdiv(w, WG_TW); a.tiles_y = cdiv(h, WG_R);
   a.ntiles = n * a.tiles_x * a.tiles_y;
@@ -238,9 +274,23 @@ extern "C" int tg_wgrad3x3(const float* p, int64_t p_nstride, const float* q, in
   int rc = check_launch("wgrad3x3_mfma");
   if (rc != TG_OK) return rc;
   long long total = (long long)ca * cb * 9;
-  int rb = (int)((total + 255) / 256);
-  if (rb > 2048) rb = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, workspace, grad, a.nsplit, ca, cb,
-                     cb_total, cb_off, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace,
+                     grad, a.nsplit, ca, cb, cb_total, cb_off, accumulate);
   return check_launch("wgrad_reduce");
+}
+
+extern "C" int tg_wgrad3x3(const float* p, int64_t p_nstride, const float* q, int64_t q_nstride,
+                           float* grad, float* workspace, int n, int ca, int cb, int cb_total,
+                           int cb_off, int h, int w, int accumulate, tg_stream_t stream) {
+  TG_REQUIRE(p && q, TG_E_ARG, "wgrad3x3: null pointer");
+  return wgrad_launch(&p, &q, 1, p_nstride, q_nstride, grad, workspace, n, ca, cb, cb_total, cb_off, h,
+                      w, accumulate, stream);
+}
+
+extern "C" int tg_wgrad3x3_multi(const float* const* p_list, const float* const* q_list, int nseg,
+                                 int64_t p_nstride, int64_t q_nstride, float* grad, float* workspace,
+                                 int n_per_seg, int ca, int cb, int cb_total, int cb_off, int h,
+                                 int w, int accumulate, tg_stream_t stream) {
+  return wgrad_launch(p_list, q_list, nseg, p_nstride, q_nstride, grad, workspace, n_per_seg, ca, cb,
+                      cb_total, cb_off, h, w, accumulate, stream);
 }

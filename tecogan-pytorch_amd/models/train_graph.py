@@ -68,18 +68,34 @@ class Tape:
         self.deferred_bias.setdefault(id(buf), (buf, []))[1].append(dz)
 
     def flush_deferred(self):
+        def same(ts):
+            return all(t.shape == ts[0].shape and t.is_contiguous() for t in ts)
         for ent in self.deferred.values():
-            P = ent['p'][0] if len(ent['p']) == 1 else torch.cat(ent['p'], 0)
-            Q = ent['q'][0] if len(ent['q']) == 1 else torch.cat(ent['q'], 0)
+            multi = len(ent['p']) > 1 and same(ent['p']) and same(ent['q'])
             if ent['post'] is None:
-                ops.wgrad3x3(P, Q, ent['target'], cb_off=ent['cb_off'], accumulate=True)
+                if multi:      # one launch over the per-frame tensors where they lie
+                    ops.wgrad3x3_multi(ent['p'], ent['q'], ent['target'], cb_off=ent['cb_off'],
+                                       accumulate=True)
+                else:
+                    P = ent['p'][0] if len(ent['p']) == 1 else torch.cat(ent['p'], 0)
+                    Q = ent['q'][0] if len(ent['q']) == 1 else torch.cat(ent['q'], 0)
+                    ops.wgrad3x3(P, Q, ent['target'], cb_off=ent['cb_off'], accumulate=True)
             else:
-                ge = torch.zeros(P.shape[1], Q.shape[1], 3, 3, dtype=torch.float32, device=P.device)
-                ops.wgrad3x3(P, Q, ge, accumulate=False)
+                p0, q0 = ent['p'][0], ent['q'][0]
+                ge = torch.zeros(p0.shape[1], q0.shape[1], 3, 3, dtype=torch.float32, device=p0.device)
+                if multi:
+                    ops.wgrad3x3_multi(ent['p'], ent['q'], ge, accumulate=False)
+                else:
+                    P = p0 if len(ent['p']) == 1 else torch.cat(ent['p'], 0)
+                    Q = q0 if len(ent['q']) == 1 else torch.cat(ent['q'], 0)
+                    ops.wgrad3x3(P, Q, ge, accumulate=False)
                 ent['post'](ge)
         for buf, dzs in self.deferred_bias.values():
-            D = dzs[0] if len(dzs) == 1 else torch.cat(dzs, 0)
-            ops.bias_grad(D, buf, accumulate=True)
+            if len(dzs) > 1 and same(dzs):
+                ops.bias_grad_multi(dzs, buf, accumulate=True)
+            else:
+                D = dzs[0] if len(dzs) == 1 else torch.cat(dzs, 0)
+                ops.bias_grad(D, buf, accumulate=True)
         self.deferred, self.deferred_bias = {}, {}
 
 
@@ -90,17 +106,18 @@ def _grad_buf(p):
 
 
 class ConvCache:
-    """Per-layer packed weights for the training step (forward, data-gradient and
-    the space-to-depth embeddings), rebuilt when the parameter version changes."""
+    """Per-layer packed weights for the training step (forward, data-gradient and the
+    space-to-depth embeddings), rebuilt when the parameter version changes.  The entries live
+    ON the layer object: a process-wide table keyed by id(layer) would hand a new model the
+    stale packs of a freed one whose id, storage address and version counters it re-uses."""
 
-    def __init__(self):
-        self.store = {}
-
-    def get(self, key, version, build):
-        ent = self.store.get(key)
+    @staticmethod
+    def get(owner, key, version, build):
+        store = owner.__dict__.setdefault('_tg_pack_cache', {})
+        ent = store.get(key)
         if ent is None or ent[0] != version:
             ent = (version, build())
-            self.store[key] = ent
+            store[key] = ent
         return ent[1]
 
 
@@ -140,15 +157,15 @@ def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=
         if need_dx and c1 <= 4 and cout <= 64 and x2 is None:
             # data gradient onto an image (VGG's first conv): cout -> <=4 channels is the small
             # kernel's shape; its weights are the 180-degree rotated, transposed taps
-            wdg = _CACHE.get(('dgs', id(layer)), _ver(w),
+            wdg = _CACHE.get(layer, ('dgs',), _ver(w),
                              lambda: wd.flip(2, 3).permute(1, 0, 2, 3).contiguous())
             tape.add_grad(x, ops.conv3x3_small(dz, wdg, None))
         elif need_dx:
-            pkd = _CACHE.get(('dg', id(layer), 0), _ver(w), lambda: ops.pack_conv3x3_dgrad(
+            pkd = _CACHE.get(layer, ('dg', 0), _ver(w), lambda: ops.pack_conv3x3_dgrad(
                 wd[:, :c1].contiguous()))
             tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, c1, pkd[3], ksplit=1))
         if x2 is not None and need_dx2:
-            pkd = _CACHE.get(('dg', id(layer), 1), _ver(w), lambda: ops.pack_conv3x3_dgrad(
+            pkd = _CACHE.get(layer, ('dg', 1), _ver(w), lambda: ops.pack_conv3x3_dgrad(
                 wd[:, c1:].contiguous()))
             tape.add_grad(x2, ops.conv3x3(dz, pkd[0], None, cout, cin - c1, pkd[3], ksplit=1))
     tape.record(bwd)
@@ -171,7 +188,7 @@ def conv3x3_small(tape, layer, x, act=NONE, up_src=None, up_mode=ops.UP_NONE, up
         if w.requires_grad:
             tape.defer_wgrad(('w', id(layer), 0), dz, x, _grad_buf(w), 0)
             tape.defer_bias(_grad_buf(b), dz)
-        pkd = _CACHE.get(('dg', id(layer), 0), _ver(w),
+        pkd = _CACHE.get(layer, ('dg', 0), _ver(w),
                          lambda: ops.pack_conv3x3_dgrad(w.detach().contiguous()))
         tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, cin, pkd[3], ksplit=1))
     tape.record(bwd)
@@ -210,7 +227,7 @@ def convt3x3s2(tape, layer, x, act=RELU):
             return
         dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
         s = ops.space_to_depth(dz, 2)                              # (n, 4co, h, w)
-        we = _CACHE.get(('cte', id(layer)), _ver(w), lambda: ops.pack_conv3x3(_convt_embed(w.detach())))
+        we = _CACHE.get(layer, ('cte',), _ver(w), lambda: ops.pack_conv3x3(_convt_embed(w.detach())))
         tape.add_grad(x, ops.conv3x3(s, we[0], None, 4 * co, ci, we[3], ksplit=1))
         if w.requires_grad:
             def post(ge):                                          # G[ci][(ph,co)][ty][tx]
@@ -249,7 +266,7 @@ def conv4x4s2(tape, holder, x, need_dx=True):
     w = holder.weight
     co, ci = w.shape[:2]
     s = ops.space_to_depth(x, 2)
-    pk = _CACHE.get(('c4f', id(holder)), _ver(w), lambda: ops.pack_conv3x3(_conv4_embed(w.detach())))
+    pk = _CACHE.get(holder, ('c4f',), _ver(w), lambda: ops.pack_conv3x3(_conv4_embed(w.detach())))
     y = ops.conv3x3(s, pk[0], None, 4 * ci, co, pk[3])
     if tape is None:
         return y
@@ -268,7 +285,7 @@ def conv4x4s2(tape, holder, x, need_dx=True):
                 ops.axpy_(_grad_buf(w), sel, 1.0)
             tape.defer_wgrad(('c4', id(holder)), g, s, None, 0, post)
         if need_dx:
-            pkd = _CACHE.get(('c4d', id(holder)), _ver(w),
+            pkd = _CACHE.get(holder, ('c4d',), _ver(w),
                              lambda: ops.pack_conv3x3_dgrad(_conv4_embed(w.detach())))
             ds = ops.conv3x3(g, pkd[0], None, co, 4 * ci, pkd[3], ksplit=1)
             tape.add_grad(x, ops.depth_to_space(ds, 2))

@@ -280,6 +280,60 @@ def wgrad3x3(p, q, grad, cb_off=0, accumulate=True):
     return grad
 
 
+MAX_SEGS = 64
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def wgrad3x3_multi(p_list, q_list, grad, cb_off=0, accumulate=True):
+    """wgrad3x3 over the concatenation of equally shaped (p_i, q_i) pairs without concatenating
+    them: one launch reads up to MAX_SEGS separately allocated segments."""
+    if len(p_list) != len(q_list) or not p_list:
+        raise L.TecoganHipError('wgrad3x3_multi: empty or mismatched lists')
+    for t in list(p_list) + list(q_list):
+        _chk(t, 'segment')
+    _chk(grad, 'grad')
+    n, ca, h, w = p_list[0].shape
+    cb = q_list[0].shape[1]
+    cb_total = grad.shape[1]
+    for p_, q_ in zip(p_list, q_list):
+        if p_.shape != p_list[0].shape or q_.shape != q_list[0].shape or q_.shape[0] != n \
+                or q_.shape[2:] != p_.shape[2:]:
+            raise L.TecoganHipError('wgrad3x3_multi: segments must share one shape')
+    if grad.shape[0] != ca or grad.shape[2:] != (3, 3):
+        raise L.TecoganHipError(f'wgrad3x3_multi: grad {tuple(grad.shape)}')
+    lib = L.lib()
+    for i in range(0, len(p_list), MAX_SEGS):
+        ps, qs = p_list[i:i + MAX_SEGS], q_list[i:i + MAX_SEGS]
+        nfl = lib.tg_wgrad3x3_workspace_floats(n * len(ps), ca, cb_total, h, w)
+        ws = _wgrad_workspace(grad.device, nfl)
+        L.check(lib.tg_wgrad3x3_multi(_ptr_array(ps), _ptr_array(qs), len(ps), ca * h * w, cb * h * w,
+                                      grad.data_ptr(), ws.data_ptr(), n, ca, cb, cb_total, cb_off, h, w,
+                                      1 if (accumulate or i > 0) else 0, _stream()), 'tg_wgrad3x3_multi')
+    return grad
+
+
+def bias_grad_multi(dy_list, db, accumulate=True):
+    if not dy_list:
+        raise L.TecoganHipError('bias_grad_multi: empty list')
+    for t in dy_list:
+        _chk(t, 'segment')
+        if t.shape != dy_list[0].shape:
+            raise L.TecoganHipError('bias_grad_multi: segments must share one shape')
+    _chk(db, 'db')
+    n, c = dy_list[0].shape[:2]
+    hw = dy_list[0].numel() // (n * c)
+    for i in range(0, len(dy_list), MAX_SEGS):
+        seg = dy_list[i:i + MAX_SEGS]
+        L.check(L.lib().tg_bias_grad_multi(_ptr_array(seg), len(seg), db.data_ptr(), n, c, hw,
+                                           1 if (accumulate or i > 0) else 0, _stream()),
+                'tg_bias_grad_multi')
+    return db
+
+
 def act_bwd(dy, y, act, out=None):
     _chk(dy, 'dy'); _chk(y, 'y')
     if out is None:

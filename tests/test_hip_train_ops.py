@@ -212,3 +212,29 @@ def test_sync_bn_path_equals_fused_bn(ops):
     dx1 = ops.bn_lrelu_train_bwd(x, y1, g, gamma, m1, i1, dg1, db1)
     dx2 = ops.sync_bn_lrelu_train_bwd(x, y2, g, gamma, m2, i2, cnt, dg2, db2)
     assert relerr(dx2, dx1) <= 5e-5 and relerr(dg2, dg1) <= 2e-5 and relerr(db2, db1) <= 1e-5
+
+
+def test_wgrad_and_bias_grad_over_segments_match_concatenation(ops):
+    """The per-frame (dZ, X) tensors of an unrolled layer are reduced where they lie: the
+    multi-segment launch walks the same tiles in the same order as the launch over the
+    concatenated batch, so the weight gradient is bit-identical."""
+    g = torch.Generator().manual_seed(11)
+    segs, n, ca, cb, h, w = 5, 2, 64, 48, 18, 34
+    P = [torch.randn(n, ca, h, w, generator=g).cuda() for _ in range(segs)]
+    Q = [torch.randn(n, cb, h, w, generator=g).cuda() for _ in range(segs)]
+    ref = torch.zeros(ca, cb + 3, 3, 3, device='cuda')
+    ops.wgrad3x3(torch.cat(P), torch.cat(Q), ref, cb_off=3, accumulate=False)
+    out = torch.full_like(ref, 7.0)
+    out[:, 3:] = 0
+    ops.wgrad3x3_multi(P, Q, out, cb_off=3, accumulate=True)
+    assert torch.equal(out[:, 3:], ref[:, 3:])
+    assert torch.all(out[:, :3] == 7.0)                   # columns outside the slice untouched
+    db_ref = torch.zeros(ca, device='cuda')
+    ops.bias_grad(torch.cat(P), db_ref, accumulate=False)
+    db = torch.ones(ca, device='cuda')
+    ops.bias_grad_multi(P, db, accumulate=True)
+    assert torch.allclose(db - 1.0, db_ref, rtol=1e-5, atol=1e-3)
+    with pytest.raises(Exception):
+        ops.wgrad3x3_multi(P, Q[:-1], out)
+    with pytest.raises(Exception):
+        ops.wgrad3x3_multi(P[:2] + [P[2][:, :, :-1].contiguous()], Q[:3], out)
