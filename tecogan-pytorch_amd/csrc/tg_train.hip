@@ -17,6 +17,9 @@ static inline int grid_for(long long total, int cap = 4096) {
   long long b = (total + 255) / 256;
   return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
+// one block per channel: 16 waves when the channel plane is large (early discriminator
+// layers: 12 x 128 x 128 elements per channel), 4 otherwise
+static inline int bn_threads(int n, long long hw) { return (long long)n * hw >= 32768 ? 1024 : 256; }
 #define TG_GRID_STRIDE(i, total)                                                   \
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total); \
        i += (long long)gridDim.x * blockDim.x)
@@ -26,7 +29,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-// block-wide sum (256 threads); result valid in thread 0
+// block-wide sum (blockDim.x a multiple of 64, sm holds one float per wave); result valid in thread 0
 __device__ __forceinline__ float block_sum(float v, float* sm) {
   v = wave_sum(v);
   int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -66,11 +69,15 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(BiasGradSegs dy, int n_p
   const long long lo = (long long)sl * per;
   long long hi = lo + per; if (hi > total) hi = total;
   float s = 0.f;
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-    long long b = i / hw; long long r = i - b * hw;
-    const int sg = (int)(b / n_per_seg);
-    const long long lb = b - (long long)sg * n_per_seg;
-    s += dy.seg[sg][(lb * c + ch) * hw + r];
+  // walk the slice image by image: no per-element division, block-uniform plane pointer
+  int b = (int)(lo / hw);
+  long long r0 = lo - (long long)b * hw;
+  for (long long left = hi - lo; left > 0; ++b, r0 = 0) {
+    const int sg = b / n_per_seg, lb = b - sg * n_per_seg;
+    const float* __restrict__ pl = dy.seg[sg] + ((long long)lb * c + ch) * hw;
+    const long long cnt = (hw - r0 < left) ? hw - r0 : left;
+    for (long long r = threadIdx.x; r < cnt; r += 256) s += pl[r0 + r];
+    left -= cnt;
   }
   float r = block_sum(s, sm);
   if (threadIdx.x == 0) atomicAdd(db + ch, r);
@@ -372,19 +379,19 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 
 // ---- BatchNorm2d (train) + LeakyReLU(0.2) fused ---------------------------------
 // stats: one block per channel -> mean, invstd (biased var), running stats update
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int n, int c,
+__global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict__ x, int n, int c,
                                                        int hw, float eps, float momentum,
                                                        float* __restrict__ save_mean,
                                                        float* __restrict__ save_invstd,
                                                        float* __restrict__ run_mean,
                                                        float* __restrict__ run_var) {
-  __shared__ float sm[4];
+  __shared__ float sm[16];
   __shared__ float s_mean;
   int ch = blockIdx.x;
   float s = 0.f;
   for (int b = 0; b < n; ++b) {
     const float* p = x + ((long long)b * c + ch) * hw;
-    for (int i = threadIdx.x; i < hw; i += 256) s += p[i];
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) s += p[i];
   }
   float tot = block_sum(s, sm);
   const float cnt = (float)n * (float)hw;
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   float q = 0.f;
   for (int b = 0; b < n; ++b) {
     const float* p = x + ((long long)b * c + ch) * hw;
-    for (int i = threadIdx.x; i < hw; i += 256) { float d = p[i] - mean; q += d * d; }
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) { float d = p[i] - mean; q += d * d; }
   }
   float sq = block_sum(q, sm);
   if (threadIdx.x == 0) {
@@ -423,17 +430,17 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 // backward of (BN train + lrelu): per-channel reductions then the input gradient.
 //   dz = dy * lrelu'(y);  dbeta = sum dz;  dgamma = sum dz * xhat
 //   dx = gamma*invstd * (dz - dbeta/N - xhat * dgamma/N)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
     const float* __restrict__ mean, const float* __restrict__ invstd, int n, int c, int hw,
     float slope, float* __restrict__ sum_dz, float* __restrict__ sum_dz_xhat) {
-  __shared__ float sm[4];
+  __shared__ float sm[16];
   int ch = blockIdx.x;
   float a = 0.f, bq = 0.f;
   const float mu = mean[ch], is = invstd[ch];
   for (int b = 0; b < n; ++b) {
     const long long off = ((long long)b * c + ch) * hw;
-    for (int i = threadIdx.x; i < hw; i += 256) {
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) {
       float g = dy[off + i];
       float dz = y[off + i] > 0.f ? g : g * slope;
       a += dz;
@@ -647,7 +654,7 @@ extern "C" int tg_bn_lrelu_train_fwd(const float* x, const float* gamma, const f
                                      float* save_invstd, int n, int c, int hw, tg_stream_t stream) {
   TG_REQUIRE(x && gamma && beta && y && save_mean && save_invstd, TG_E_ARG, "bn_fwd: null pointer");
   TG_REQUIRE(n > 0 && c > 0 && hw > 0 && (long long)n * hw > 1, TG_E_SHAPE, "bn_fwd: shape");
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(c), dim3(256), 0, ST, x, n, c, hw, eps, momentum, save_mean,
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(c), dim3(bn_threads(n, hw)), 0, ST, x, n, c, hw, eps, momentum, save_mean,
                      save_invstd, running_mean, running_var);
   long long total = (long long)n * c * hw;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, ST, x, save_mean,
@@ -664,7 +671,7 @@ extern "C" int tg_bn_lrelu_train_bwd(const float* x, const float* y, const float
              "bn_bwd: null pointer");
   float* s0 = scratch2c;
   float* s1 = scratch2c + c;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(c), dim3(256), 0, ST, x, y, dy, save_mean, save_invstd,
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(c), dim3(bn_threads(n, hw)), 0, ST, x, y, dy, save_mean, save_invstd,
                      n, c, hw, slope, s0, s1);
   long long total = (long long)n * c * hw;
   if (dx)
@@ -745,14 +752,14 @@ extern "C" int tg_downsample_bd(const float* x, const float* kernel2d, float* y,
 // the host can all-reduce the packed (sum, sum of squares) / (sum dz, sum dz*xhat) vectors
 // over RCCL between the two halves.  One small all-reduce per BN layer and direction.
 namespace tg {
-__global__ __launch_bounds__(256) void bn_moments_kernel(const float* __restrict__ x, int n, int c,
+__global__ __launch_bounds__(1024) void bn_moments_kernel(const float* __restrict__ x, int n, int c,
                                                          int hw, float* __restrict__ sums2c) {
-  __shared__ float sm[4];
+  __shared__ float sm[16];
   int ch = blockIdx.x;
   float s = 0.f, q = 0.f;
   for (int b = 0; b < n; ++b) {
     const float* p = x + ((long long)b * c + ch) * hw;
-    for (int i = threadIdx.x; i < hw; i += 256) { float v = p[i]; s += v; q += v * v; }
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) { float v = p[i]; s += v; q += v * v; }
   }
   float r0 = block_sum(s, sm), r1 = block_sum(q, sm);
   if (threadIdx.x == 0) { sums2c[ch] = r0; sums2c[c + ch] = r1; }
@@ -779,7 +786,7 @@ __global__ void bn_finalize_stats_kernel(const float* __restrict__ sums2c, float
 extern "C" int tg_bn_moments(const float* x, float* sums2c, int n, int c, int hw,
                              tg_stream_t stream) {
   TG_REQUIRE(x && sums2c && n > 0 && c > 0 && hw > 0, TG_E_ARG, "bn_moments: bad argument");
-  hipLaunchKernelGGL(tg::bn_moments_kernel, dim3(c), dim3(256), 0, ST, x, n, c, hw, sums2c);
+  hipLaunchKernelGGL(tg::bn_moments_kernel, dim3(c), dim3(tg::bn_threads(n, hw)), 0, ST, x, n, c, hw, sums2c);
   return tg::check_launch("bn_moments");
 }
 
@@ -806,7 +813,7 @@ extern "C" int tg_bn_lrelu_bwd_reduce(const float* x, const float* y, const floa
                                       const float* mean, const float* invstd, float slope,
                                       float* sums2c, int n, int c, int hw, tg_stream_t stream) {
   TG_REQUIRE(x && y && dy && mean && invstd && sums2c, TG_E_ARG, "bn_lrelu_bwd_reduce: null pointer");
-  hipLaunchKernelGGL(tg::bn_bwd_reduce_kernel, dim3(c), dim3(256), 0, ST, x, y, dy, mean, invstd, n, c,
+  hipLaunchKernelGGL(tg::bn_bwd_reduce_kernel, dim3(c), dim3(tg::bn_threads(n, hw)), 0, ST, x, y, dy, mean, invstd, n, c,
                      hw, slope, sums2c, sums2c + c);
   return tg::check_launch("bn_lrelu_bwd_reduce");
 }
