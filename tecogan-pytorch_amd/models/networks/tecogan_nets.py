@@ -300,8 +300,7 @@ class FRNet(nn.Module):
                 main = torch.cuda.current_stream(dev)
                 side = self._side_stream(dev)
                 side.wait_stream(main)                      # inputs / weights are ready
-                ev_f = [torch.cuda.Event() for _ in range(tot_frm)]
-                ev_s = [torch.cuda.Event() for _ in range(tot_frm)]
+                ev_f, ev_s = self._events(tot_frm)
                 for i in range(tot_frm):
                     lr_prev = zeros_lr if i == 0 else lr[i - 1:i]
                     if i >= 2:
@@ -321,14 +320,23 @@ class FRNet(nn.Module):
             return u8
         return u8.cpu().numpy()
 
+    def _events(self, n):
+        """Two event rings, created once and re-recorded by every clip."""
+        ev = getattr(self, '_ev', None)
+        if ev is None or len(ev[0]) < n:
+            ev = self._ev = ([torch.cuda.Event() for _ in range(n)],
+                             [torch.cuda.Event() for _ in range(n)])
+        return ev
+
     def _side_stream(self, dev):
         st = getattr(self, '_side', None)
         if st is None or st.device != dev:
-            # ROCm maps streams round-robin onto GPU_MAX_HW_QUEUES (default 4) hardware
-            # queues; with RCCL's own streams alive the side stream can land on the SAME
-            # queue as the main stream and the overlap silently disappears.  A stream of a
-            # different priority class is mapped separately.
-            prio = int(os.environ.get('TG_SIDE_STREAM_PRIORITY', '-1'))
+            # Default priority class.  Whether this stream really runs beside the main one is
+            # decided by the runtime's stream -> hardware-queue mapping; the package enables
+            # dynamic queue assignment for that (see tecogan_pytorch_amd/__init__.py).  A
+            # high-priority side stream (-1) was measured WORSE: FNet then pre-empts the serial
+            # SRNet chain and every 4th clip drops to 450 frames/s.
+            prio = int(os.environ.get('TG_SIDE_STREAM_PRIORITY', '0'))
             st = self._side = torch.cuda.Stream(device=dev, priority=prio)
         return st
 

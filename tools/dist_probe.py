@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("DEBUG_HIP_DYNAMIC_QUEUES", "1")   # must precede the first GPU call
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 mode = sys.argv[1]
@@ -22,7 +24,7 @@ with torch.no_grad():
     if mode in ('nccl_barrier', 'nccl_devid', 'gloo'):
         dist.barrier()
         torch.cuda.synchronize()
-    for rep in range(2):
+    for rep in range(int(os.environ.get("ITERS", "2"))):
         t0 = time.perf_counter()
         net.infer_sequence(clip, 'cuda', return_device_tensor=True)
         torch.cuda.synchronize()
