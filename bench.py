@@ -60,6 +60,9 @@ def parse():
     ap.add_argument('--no-pipeline', action='store_true',
                     help='single-stream clip inference only (for kernel-trace profiles whose per-kernel '
                          'durations are not inflated by the FNet/SRNet stream overlap)')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the secondary protocols (step protocol, 4-clip batch): counter passes then '
+                         'see only the launches of the headline workload')
     ap.add_argument('--aten-frames', type=int, default=30,
                     help='frames of the ATen/MIOpen-on-GPU context baseline (0 disables)')
     return ap.parse_args()
@@ -340,7 +343,7 @@ def main():
 
         # ---- secondary protocols (rank-local, not part of `value`) -----------------------
         sec = {}
-        if not args.no_pipeline:
+        if not args.no_pipeline and not args.no_secondary:
             net.infer_sequence(wclip, dev, pipeline=False, return_device_tensor=True)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
