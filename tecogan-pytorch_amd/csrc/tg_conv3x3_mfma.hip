@@ -27,6 +27,7 @@
 // codes/models/networks/tecogan_nets.py:23-65, 92-98, 111-113, 367-369 and the
 // torch.cat at :71 / :141 (two-source input).
 #include "tg_common.h"
+#include <cstdlib>
 
 namespace tg {
 
@@ -52,6 +53,7 @@ struct Conv3x3Args {
   long long part_ss;
   int vec_ok;   // w % 4 == 0 and 16-byte aligned y / res planes: float4 epilogue allowed
   long long* dbg;   // lab instrumentation (ABL & 16): 8 cycle stamps per workgroup
+  int nblocks;      // > 0: XCD-banded block order over nblocks tiles (grid = 8 * ceil(nblocks / 8))
 };
 
 // pack OIHW (or IOHW for transposed convs) -> [ocg][chunk][tap][half][ocb][4]
@@ -114,6 +116,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   const int wn = wave / WM;
 
   int b = blockIdx.x;
+  if (a.nblocks > 0) {
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Give XCD x the
+    // contiguous band of tiles [x*per, (x+1)*per): vertically adjacent tiles then share their
+    // halo rows through one L2 instead of each fetching them from HBM / Infinity Cache.
+    const int per = (a.nblocks + 7) >> 3;
+    b = (b & 7) * per + (b >> 3);
+    if (b >= a.nblocks) return;
+  }
   const int tx = b % a.tiles_x; b /= a.tiles_x;
   const int ty = b % a.tiles_y; b /= a.tiles_y;
   const int ocg = b % a.nocg; b /= a.nocg;
@@ -384,12 +394,17 @@ static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   if (a.ksplit < 1) a.ksplit = 1;
   long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n * a.ksplit;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "conv3x3: grid %lld", blocks);
+  // XCD banding pays when a band is many tile rows deep; TG_CONV_XCD=0/1 overrides (lab)
+  static const int xcd_env = [] { const char* e = getenv("TG_CONV_XCD"); return e ? atoi(e) : -1; }();
+  const bool xcd = xcd_env >= 0 ? xcd_env != 0 : blocks >= 512;
+  a.nblocks = xcd ? (int)blocks : 0;
+  const unsigned grid = xcd ? (unsigned)(8 * ((blocks + 7) / 8)) : (unsigned)blocks;
   if (a.x2)
     hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, true, 0, TG_CONV_OPT>),
-                       dim3((unsigned)blocks), dim3(WM * WN * 64), lds, stream, a);
+                       dim3(grid), dim3(WM * WN * 64), lds, stream, a);
   else
     hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, false, 0, TG_CONV_OPT>),
-                       dim3((unsigned)blocks), dim3(WM * WN * 64), lds, stream, a);
+                       dim3(grid), dim3(WM * WN * 64), lds, stream, a);
   return check_launch("conv3x3_mfma");
 }
 
