@@ -312,6 +312,7 @@ typedef struct tg_frnet_plan tg_frnet_plan;
 typedef struct {
   int in_nc, out_nc, nf, nb, scale, up_mode; /* FRNet ctor, tecogan_nets.py:154 */
   int n, h, w;                               /* LR batch / size */
+  int fnet_only;                             /* 1: plan and workspace for phase 1 (FNet) only */
 } tg_frnet_cfg;
 
 /* Weight table handed to the plan: device pointers to packed weights / biases
@@ -340,6 +341,17 @@ int tg_frnet_step(tg_frnet_plan* plan, const float* lr_curr, const float* lr_pre
 int tg_frnet_step_phase(tg_frnet_plan* plan, int phases, int flow_slot, const float* lr_curr,
                         const float* lr_prev, const float* hr_prev, float* hr_out,
                         uint8_t* u8_out, tg_stream_t stream);
+/* Clip inference with a BATCHED flow estimator: FNet needs only the LR frames, so an
+ * FNet-only plan (cfg.fnet_only = 1, cfg.n = frames per batch) estimates the flows of n
+ * consecutive frame pairs in one pass -- as FRNet.forward_sequence does for training
+ * (tecogan_nets.py:183-196) -- and the per-frame plan consumes them one by one:
+ *   tg_frnet_step_phase(fnet_plan, 1, slot, lr[i0..i0+n), lr[i0-1..i0+n-1), ...)
+ *   tg_frnet_step_srnet(frame_plan, tg_frnet_plan_flow(fnet_plan, slot) + j*2*fh*fw, lr[i0+j], ...)
+ * with fh = h/8*8, fw = w/8*8. */
+float* tg_frnet_plan_flow(tg_frnet_plan* plan, int flow_slot);
+int tg_frnet_step_srnet(tg_frnet_plan* plan, const float* lr_flow, const float* lr_curr,
+                        const float* hr_prev, float* hr_out, uint8_t* u8_out,
+                        tg_stream_t stream);
 /* number of kernel launches one tg_frnet_step enqueues (for reporting) */
 int tg_frnet_plan_launches(const tg_frnet_plan* plan);
 

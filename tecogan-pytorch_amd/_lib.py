@@ -18,7 +18,7 @@ P, I, I64, F, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
 class FrnetCfg(C.Structure):
     _fields_ = [(k, C.c_int) for k in
-                ('in_nc', 'out_nc', 'nf', 'nb', 'scale', 'up_mode', 'n', 'h', 'w')]
+                ('in_nc', 'out_nc', 'nf', 'nb', 'scale', 'up_mode', 'n', 'h', 'w', 'fnet_only')]
 
 
 class LayerWeights(C.Structure):
@@ -80,6 +80,8 @@ SIGNATURES = {
     'tg_frnet_step': (I, [P, P, P, P, P, P, P]),
     'tg_frnet_step_phase': (I, [P, I, I, P, P, P, P, P, P]),
     'tg_frnet_plan_launches': (I, [P]),
+    'tg_frnet_plan_flow': (P, [P, I]),
+    'tg_frnet_step_srnet': (I, [P, P, P, P, P, P, P]),
     'tg_frnet_plan_kinds': (I, []),
     'tg_frnet_kind_name': (C.c_char_p, [I]),
     'tg_frnet_plan_kind_stats': (I, [P, I, C.POINTER(C.c_int), C.POINTER(C.c_double),

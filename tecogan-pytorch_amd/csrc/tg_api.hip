@@ -35,7 +35,8 @@ struct tg_frnet_plan {
 // phase bits: 1 = FNet (lr_curr, lr_prev -> flow slot), 2 = warp + SRNet (flow slot, hr_prev -> hr_out)
 static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
                      const float* hr_prev, float* hr_out, uint8_t* u8_out, tg_stream_t st,
-                     unsigned mask, bool dry, int phases = 3, int slot = 0);
+                     unsigned mask, bool dry, int phases = 3, int slot = 0,
+                     const float* flow_ext = nullptr);
 
 static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
 
@@ -61,13 +62,14 @@ static size_t fnet_partial_floats(const tg_frnet_cfg* c) {
 static void carve(const tg_frnet_cfg* c, size_t off[12]) {
   size_t hw = (size_t)c->h * c->w, n = c->n;
   size_t o = 0;
-  off[0] = o; o += align64(n * 64 * hw);                       // A
-  off[1] = o; o += align64(n * 64 * hw);                       // B
+  const size_t sr = c->fnet_only ? 0 : 1;                      // an FNet-only plan has no SRNet regions
+  off[0] = o; o += sr * align64(n * 64 * hw);                  // A
+  off[1] = o; o += sr * align64(n * 64 * hw);                  // B
   off[2] = o; o += align64(n * 2 * hw);                        // FLOW
-  off[3] = o; o += align64(n * c->scale * c->scale * c->in_nc * hw);  // S2D
-  off[4] = o; o += align64(n * c->nf * 4 * hw);                // U1
-  off[5] = o; o += (c->scale == 4) ? align64(n * c->nf * 16 * hw) : 0;  // U2
-  off[6] = o; o += align64(fnet_partial_floats(c));            // PART (split-K partial sums, SRNet)
+  off[3] = o; o += sr * align64(n * c->scale * c->scale * c->in_nc * hw);  // S2D
+  off[4] = o; o += sr * align64(n * c->nf * 4 * hw);           // U1
+  off[5] = o; o += (c->scale == 4) ? sr * align64(n * c->nf * 16 * hw) : 0;  // U2
+  off[6] = o; o += sr * align64(fnet_partial_floats(c));       // PART (split-K partial sums, SRNet)
   off[7] = o; o += align64(n * 64 * hw);                       // FA   (FNet ping)
   off[8] = o; o += align64(n * 64 * hw);                       // FB   (FNet pong)
   off[9] = o; o += align64(fnet_partial_floats(c));            // FPART (split-K partial sums, FNet)
@@ -145,9 +147,10 @@ enum {
 
 static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
                      const float* hr_prev, float* hr_out, uint8_t* u8_out, tg_stream_t st,
-                     unsigned mask, bool dry, int phases, int slot) {
+                     unsigned mask, bool dry, int phases, int slot, const float* flow_ext) {
   const tg_frnet_cfg& c = p->cfg;
-  float* const flow_buf = slot ? p->FLOW2 : p->FLOW;
+  // phase 2 may read the flow of its frame from another plan's batched FNet pass
+  float* const flow_buf = flow_ext ? const_cast<float*>(flow_ext) : (slot ? p->FLOW2 : p->FLOW);
   bool active = (phases & 1) != 0;     // which phase the launches being issued belong to
   float* part_buf = p->FPART;
   const int n = c.n, h = c.h, w = c.w, s = c.scale;
@@ -306,7 +309,22 @@ extern "C" int tg_frnet_step_masked(tg_frnet_plan* p, const float* lr_curr, cons
                                     unsigned kind_mask, tg_stream_t st) {
   TG_REQUIRE(p && lr_curr && lr_prev && hr_prev && hr_out, TG_E_ARG, "frnet_step: null pointer");
   TG_REQUIRE(!u8_out || p->cfg.n == 1, TG_E_ARG, "frnet_step: u8 output needs n == 1");
+  TG_REQUIRE(!p->cfg.fnet_only, TG_E_ARG, "frnet_step: the plan was created FNet-only");
   return step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, u8_out, st, kind_mask, false);
+}
+
+extern "C" float* tg_frnet_plan_flow(tg_frnet_plan* p, int flow_slot) {
+  if (!p || (flow_slot != 0 && flow_slot != 1)) return nullptr;
+  return flow_slot ? p->FLOW2 : p->FLOW;
+}
+
+extern "C" int tg_frnet_step_srnet(tg_frnet_plan* p, const float* lr_flow, const float* lr_curr,
+                                   const float* hr_prev, float* hr_out, uint8_t* u8_out,
+                                   tg_stream_t st) {
+  TG_REQUIRE(p && lr_flow && lr_curr && hr_prev && hr_out, TG_E_ARG, "frnet_step_srnet: null pointer");
+  TG_REQUIRE(!p->cfg.fnet_only, TG_E_ARG, "frnet_step_srnet: the plan was created FNet-only");
+  TG_REQUIRE(!u8_out || p->cfg.n == 1, TG_E_ARG, "frnet_step_srnet: u8 output needs n == 1");
+  return step_impl(p, lr_curr, nullptr, hr_prev, hr_out, u8_out, st, 0xFFFFFFFFu, false, 2, 0, lr_flow);
 }
 
 extern "C" int tg_frnet_step_phase(tg_frnet_plan* p, int phases, int flow_slot, const float* lr_curr,
@@ -318,6 +336,7 @@ extern "C" int tg_frnet_step_phase(tg_frnet_plan* p, int phases, int flow_slot, 
   TG_REQUIRE(!(phases & 1) || lr_prev, TG_E_ARG, "frnet_step_phase: phase 1 needs lr_prev");
   TG_REQUIRE(!(phases & 2) || (hr_prev && hr_out), TG_E_ARG, "frnet_step_phase: phase 2 needs hr_prev/hr_out");
   TG_REQUIRE(!u8_out || p->cfg.n == 1, TG_E_ARG, "frnet_step_phase: u8 output needs n == 1");
+  TG_REQUIRE(!(phases & 2) || !p->cfg.fnet_only, TG_E_ARG, "frnet_step_phase: the plan was created FNet-only");
   return step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, u8_out, st, 0xFFFFFFFFu, false, phases,
                    flow_slot);
 }
@@ -327,7 +346,7 @@ extern "C" int tg_frnet_step_phase(tg_frnet_plan* p, int phases, int flow_slot, 
 extern "C" int tg_frnet_replay(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
                                const float* hr_prev, float* hr_out, unsigned kind_mask, int reps,
                                tg_stream_t st) {
-  TG_REQUIRE(p && lr_curr && lr_prev && hr_prev && hr_out && reps > 0, TG_E_ARG,
+  TG_REQUIRE(p && lr_curr && lr_prev && hr_prev && hr_out && reps > 0 && !p->cfg.fnet_only, TG_E_ARG,
              "frnet_replay: bad argument");
   for (int i = 0; i < reps; ++i) {
     int rc = step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, nullptr, st, kind_mask, false);

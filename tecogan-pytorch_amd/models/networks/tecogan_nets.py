@@ -179,10 +179,11 @@ class _StepPlan:
     """Caller-owned device state behind one tg_frnet_plan: packed weights,
     workspace, and the opaque plan handle."""
 
-    def __init__(self, net, n, h, w, device):
+    def __init__(self, net, n, h, w, device, fnet_only=False):
         lib = L.lib()
         self.cfg = L.FrnetCfg(net.in_nc, net.out_nc, net.nf, net.nb, net.scale,
-                              net.srnet.up_mode(), n, h, w)
+                              net.srnet.up_mode(), n, h, w, 1 if fnet_only else 0)
+        self.n, self.fh, self.fw = n, h // 8 * 8, w // 8 * 8
         nfl = lib.tg_frnet_workspace_floats(ctypes.byref(self.cfg))
         if nfl == 0:
             raise L.TecoganHipError(f'tg_frnet_workspace_floats: unsupported config '
@@ -223,19 +224,23 @@ class FRNet(nn.Module):
         self.upsample_func = get_upsampling_func(self.scale, degradation)
         self.fnet = FNet(in_nc)
         self.srnet = SRNet(in_nc, out_nc, nf, nb, self.upsample_func, self.scale)
-        self._plan = None
+        self._plan = {}
         self._plan_key = None
 
     # -- plan cache ---------------------------------------------------------
     def _weights_key(self):
         return tuple(ops.param_version(p) for p in self.parameters())
 
-    def _get_plan(self, n, h, w, device):
-        key = (n, h, w, str(device), self._weights_key())
-        if self._plan is None or self._plan_key != key:
-            self._plan = _StepPlan(self, n, h, w, device)
-            self._plan_key = key
-        return self._plan
+    def _get_plan(self, n, h, w, device, fnet_only=False):
+        """Plans are cached per (batch, size, device, kind); a weight update drops them all."""
+        wk = self._weights_key()
+        if self._plan_key != wk:
+            self._plan, self._plan_key = {}, wk
+        key = (n, h, w, str(device), fnet_only)
+        plan = self._plan.get(key)
+        if plan is None:
+            plan = self._plan[key] = _StepPlan(self, n, h, w, device, fnet_only)
+        return plan
 
     # -- reference API ------------------------------------------------------
     def forward(self, lr_data, device=None):
@@ -278,9 +283,10 @@ class FRNet(nn.Module):
         uploaded once, frames are quantised on the device, and there is one
         host synchronisation at the end instead of one per frame.
 
-        pipeline=True: FNet depends only on the LR frames, so FNet(t+1) runs on a
-        second HIP stream while warp+SRNet(t) runs on the first (two flow slots,
-        ordered by events); the serial part of the recurrence is SRNet alone."""
+        pipeline=True: FNet depends only on the LR frames, so the flows of the next
+        TG_FNET_BATCH (default 8) frame pairs are estimated by one batched FNet pass on a
+        second HIP stream while warp+SRNet runs frame by frame on the first (two flow
+        slots, ordered by events); the serial part of the recurrence is SRNet alone."""
         tot_frm, c, h, w = lr_data.size()
         s = self.scale
         dev = torch.device(device) if device is not None else lr_data.device
@@ -295,26 +301,40 @@ class FRNet(nn.Module):
                     lr_prev = zeros_lr if i == 0 else lr[i - 1:i]
                     self.step(lr[i:i + 1], lr_prev, hr[i & 1], out=hr[(i + 1) & 1], u8_out=u8[i])
             else:
+                # FNet needs only the LR frames: the flows of FNET_BATCH consecutive frame
+                # pairs are estimated in ONE batched pass on the side stream (large grids, no
+                # split-K) while the main stream runs warp + SRNet frame by frame on the
+                # previous batch -- the serial part of the recurrence is SRNet alone.
+                nb_ = max(1, min(int(os.environ.get('TG_FNET_BATCH', '8')), tot_frm))
                 plan = self._get_plan(1, h, w, dev)
                 lib = L.lib()
                 main = torch.cuda.current_stream(dev)
                 side = self._side_stream(dev)
+                lr_ext = torch.cat([zeros_lr, lr], 0)       # frame -1 = zeros (tecogan_nets.py:266)
                 side.wait_stream(main)                      # inputs / weights are ready
-                ev_f, ev_s = self._events(tot_frm)
-                for i in range(tot_frm):
-                    lr_prev = zeros_lr if i == 0 else lr[i - 1:i]
-                    if i >= 2:
-                        side.wait_event(ev_s[i - 2])        # flow slot i&1 consumed by frame i-2
-                    L.check(lib.tg_frnet_step_phase(plan.handle, 1, i & 1, lr[i:i + 1].data_ptr(),
-                                                    lr_prev.data_ptr(), None, None, None,
+                nbatch = (tot_frm + nb_ - 1) // nb_
+                ev_f, ev_s = self._events(nbatch)
+                fsz = 2 * plan.fh * plan.fw * 4             # bytes of one frame's LR flow
+                for k in range(nbatch):
+                    i0 = k * nb_
+                    cnt = min(nb_, tot_frm - i0)
+                    fplan = self._get_plan(cnt, h, w, dev, fnet_only=True)
+                    if k >= 2:
+                        side.wait_event(ev_s[k - 2])        # flow slot k&1 consumed by batch k-2
+                    L.check(lib.tg_frnet_step_phase(fplan.handle, 1, k & 1,
+                                                    lr_ext[i0 + 1:i0 + 1 + cnt].data_ptr(),
+                                                    lr_ext[i0:i0 + cnt].data_ptr(), None, None, None,
                                                     side.cuda_stream), 'tg_frnet_step_phase(1)')
-                    ev_f[i].record(side)
-                    main.wait_event(ev_f[i])
-                    L.check(lib.tg_frnet_step_phase(plan.handle, 2, i & 1, lr[i:i + 1].data_ptr(),
-                                                    None, hr[i & 1].data_ptr(),
-                                                    hr[(i + 1) & 1].data_ptr(), u8[i].data_ptr(),
-                                                    main.cuda_stream), 'tg_frnet_step_phase(2)')
-                    ev_s[i].record(main)
+                    ev_f[k].record(side)
+                    main.wait_event(ev_f[k])
+                    flow0 = lib.tg_frnet_plan_flow(fplan.handle, k & 1)
+                    for j in range(cnt):
+                        i = i0 + j
+                        L.check(lib.tg_frnet_step_srnet(plan.handle, flow0 + j * fsz,
+                                                        lr[i:i + 1].data_ptr(), hr[i & 1].data_ptr(),
+                                                        hr[(i + 1) & 1].data_ptr(), u8[i].data_ptr(),
+                                                        main.cuda_stream), 'tg_frnet_step_srnet')
+                    ev_s[k].record(main)
                 main.wait_stream(side)
         if return_device_tensor:
             return u8
