@@ -452,3 +452,19 @@ def test_missing_library_is_loud(monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libtecogan_hip.so')
     with pytest.raises(_lib.TecoganHipError):
         _lib.lib()
+
+
+@pytest.mark.parametrize('frames', [1, 2, 3, 9, 17])
+def test_infer_sequence_batched_flow_pipeline_matches_frame_by_frame(frames):
+    """pipeline=True estimates the flows of up to 8 frame pairs per batched FNet pass (full
+    batches plus a tail batch) and feeds them to the per-frame SRNet plan; pipeline=False runs
+    FRNet.step frame by frame.  Same arithmetic up to the split-K choices of the batched FNet
+    layers (summation order), so the uint8 frames agree to one level on at most a few pixels."""
+    net, _ = make_net('BD', 4)
+    clip = smooth_clip(frames, 3, 24, 40, seed=31)
+    a = net.infer_sequence(clip, 'cuda', pipeline=True)
+    b = net.infer_sequence(clip, 'cuda', pipeline=False)
+    assert a.shape == b.shape == (frames, 96, 160, 3) and a.dtype == np.uint8
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    assert d.max() <= 1, d.max()
+    assert (d > 0).mean() <= 2e-3, (d > 0).mean()
