@@ -444,17 +444,35 @@ __global__ void splitk_finalize_kernel(const float* __restrict__ part, int S, lo
 
 using namespace tg;
 
-// Split factor for layers whose tile count cannot fill 256 CUs (FNet's
-// low-resolution, many-channel middle).  1 = no split.
+// Split factor for layers whose tile count cannot fill 256 CUs (FNet's low-resolution,
+// many-channel middle).  1 = no split.  Cost model fitted to rocprofv3 durations (us):
+//   t(ks) = 4 + 1.15 * (nchunk / ks) * max(1, wgs * ks / 256)  [+ 4.5 for the finalize launch]
+// -- a workgroup needs 1.15 us per 8-channel chunk (36 fp32 MFMAs at 2 GHz), workgroups beyond
+// one per CU share the MFMA pipes, fixed costs are launch ramp + prologue + epilogue.  A split
+// must win by 15 %: it also costs ks x the output size in partial-sum traffic.
 extern "C" int tg_conv3x3_pick_ksplit(int n, int cin, int cout, int h, int w) {
   int ocb = tg_conv3x3_pick_ocb(cout);
   int rows = conv3x3_rows_per_wg(ocb, (long long)n * h * w);
-  long long wgs = (long long)cdiv(w, TW) * cdiv(h, rows) * cdiv(cout, ocb) * n;
-  int nchunk = cdiv(cin, CK);
-  if (wgs >= 400 || nchunk < 4) return 1;
-  int ks = 1;
-  while (ks < 8 && wgs * ks < 640 && nchunk / (ks * 2) >= 2) ks *= 2;
-  return ks;
+  const double wgs = (double)cdiv(w, TW) * cdiv(h, rows) * cdiv(cout, ocb) * n;
+  const int nchunk = cdiv(cin, CK);
+  static const int legacy = [] { const char* e = getenv("TG_KSPLIT_LEGACY"); return e ? atoi(e) : 0; }();
+  if (legacy) {   // lab: the round-1 rule (fill ~640 workgroup slots)
+    if (wgs >= 400 || nchunk < 4) return 1;
+    int ks = 1;
+    while (ks < 8 && wgs * ks < 640 && nchunk / (ks * 2) >= 2) ks *= 2;
+    return ks;
+  }
+  auto cost = [&](int ks) {
+    double share = wgs * ks / 256.0;
+    return 4.0 + 1.15 * ((double)nchunk / ks) * (share > 1.0 ? share : 1.0) + (ks > 1 ? 4.5 : 0.0);
+  };
+  int best = 1;
+  double tbest = cost(1);
+  for (int ks = 2; ks <= 8 && nchunk / ks >= 2; ks *= 2) {
+    double t = cost(ks);
+    if (t < 0.85 * tbest) { best = ks; tbest = t; }
+  }
+  return best;
 }
 
 extern "C" int tg_conv3x3_pick_ocb(int cout) { return cout <= 32 ? 32 : 64; }
