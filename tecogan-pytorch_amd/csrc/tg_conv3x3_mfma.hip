@@ -93,9 +93,14 @@ constexpr unsigned OOB = 0x80000000u;   // >= any num_records we build (tensors 
 //   4 = no epilogue stores, 8 = no LDS operand reads.
 // OPT bits (tuning switches, selected by the launcher): 1 = epilogue through LDS with
 // 16-byte stores (needs a.vec_ok), 2 = weight chunks staged by LDS-DMA (global_load_lds).
-template <int WM, int WN, int NT, bool DUAL, int ABL = 0, int OPT = 0, int STAGGER = 12>
-__global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a) {
-  constexpr int NTHREADS = WM * WN * 64;
+// KS = 2: the workgroup's waves are also split over K -- wave group wk takes every KS-th
+// channel chunk (both chunks of a pair are staged together), the partial accumulators are
+// added through LDS in a fixed order.  For problems with fewer 32x32 tiles than SIMDs
+// (training: 2 x 64 x 64 LR frames) this doubles the busy SIMDs without a second launch.
+template <int WM, int WN, int NT, bool DUAL, int ABL = 0, int OPT = 0, int STAGGER = 12, int KS = 1>
+__global__ __launch_bounds__(WM* WN* KS * 64) void conv3x3_mfma_kernel(Conv3x3Args a) {
+  static_assert(KS == 1 || (KS == 2 && (OPT & 2)), "the K-split variant stages weights by LDS-DMA");
+  constexpr int NTHREADS = WM * WN * KS * 64;
   constexpr int OCB = WN * NT * 32;
   constexpr int PH = WM + 2;
   constexpr int IN_ITEMS = PH * 2 * PW;            // 16-byte items (pixel x 4 channels) per chunk
@@ -106,14 +111,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   constexpr int I_PER_T = (IN_ITEMS + NTHREADS - 1) / NTHREADS;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_in = smem;                        // [2][IN_FLOATS]
-  float* s_w = smem + 2 * IN_FLOATS;         // [2][W_FLOATS]
+  float* s_in = smem;                        // [2][KS][IN_FLOATS]
+  float* s_w = smem + 2 * KS * IN_FLOATS;    // [2][KS][W_FLOATS]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave % WM;
-  const int wn = wave / WM;
+  const int wn = (wave / WM) % WN;
+  const int wk = wave / (WM * WN);           // K group (0 when KS == 1)
+  // double-buffer slot of the chunk (pair) that starts at channel chunk `ch`
+  auto bufof = [](int ch) { return KS == 1 ? (ch & 1) : ((ch >> 1) & 1); };
 
   int b = blockIdx.x;
   if (a.nblocks > 0) {
@@ -157,22 +165,25 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   const f32x4* wsrc =
       reinterpret_cast<const f32x4*>(a.wpk + (size_t)ocg * a.nchunk * W_FLOATS);
 
-  f32x4 rin[I_PER_T];
+  f32x4 rin[KS][I_PER_T];
   f32x4 rw[W_PER_T];
 
   auto load_chunk = [&](int ch) {
-    const unsigned cbase = (unsigned)(ch * CK) * plane;
     if (!((ABL & 32) && ch != ch_begin))      // lab: skip input re-staging
 #pragma unroll
-    for (int i = 0; i < I_PER_T; ++i) {
+    for (int k = 0; k < KS; ++k) {
+      const unsigned cbase = (unsigned)((ch + k) * CK) * plane;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // channel ch*8 + 4*hf + j.  Beyond c1 (or cin) the offset is past
-        // num_records and the load returns 0; the second source then supplies it.
-        unsigned o1 = voff[i] + cbase + (unsigned)j * plane;
-        float v = buf_load(rs1, o1);
-        if (DUAL) v += buf_load(rs2, o1 - (unsigned)a.c1 * plane);
-        rin[i][j] = v;
+      for (int i = 0; i < I_PER_T; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // channel ch*8 + 4*hf + j.  Beyond c1 (or cin) the offset is past
+          // num_records and the load returns 0; the second source then supplies it.
+          unsigned o1 = voff[i] + cbase + (unsigned)j * plane;
+          float v = buf_load(rs1, o1);
+          if (DUAL) v += buf_load(rs2, o1 - (unsigned)a.c1 * plane);
+          rin[k][i][j] = v;
+        }
       }
     }
     const f32x4* ws = wsrc + (size_t)ch * W_VEC4;
@@ -182,12 +193,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
       // straight into the other weight buffer; no VGPR round trip, no ds_write.
       constexpr int PIECES = W_FLOATS * 4 / 1024;
       constexpr int NWAVES = NTHREADS / 64;
+      // chunk ch + k lives in slot bufof(ch) * KS + k; the packed chunks of a pair are
+      // contiguous in global memory and in LDS, so the pair is one run of KS * PIECES pieces
       const char* src = reinterpret_cast<const char*>(ws) + lane * 16;
-      char* dst = reinterpret_cast<char*>(s_w + (ch & 1) * W_FLOATS);   // chunk ch lives in buffer ch & 1
+      char* dst = reinterpret_cast<char*>(s_w + bufof(ch) * KS * W_FLOATS);
+      const int valid = (ch_end - ch < KS ? ch_end - ch : KS) * PIECES;   // never read past the last chunk
 #pragma unroll
-      for (int i = 0; i < (PIECES + NWAVES - 1) / NWAVES; ++i) {
+      for (int i = 0; i < (KS * PIECES + NWAVES - 1) / NWAVES; ++i) {
         int piece = wave + i * NWAVES;
-        if (piece < PIECES)
+        if (piece < valid)
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void*)(src + piece * 1024),
               (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
@@ -201,10 +215,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
     }
   };
   auto store_chunk = [&](int buf) {
-    float* si = s_in + buf * IN_FLOATS;
 #pragma unroll
-    for (int i = 0; i < I_PER_T; ++i)
-      if (lds_item[i] >= 0) *reinterpret_cast<f32x4*>(si + lds_item[i]) = rin[i];
+    for (int k = 0; k < KS; ++k) {
+      float* si = s_in + (buf * KS + k) * IN_FLOATS;
+#pragma unroll
+      for (int i = 0; i < I_PER_T; ++i)
+        if (lds_item[i] >= 0) *reinterpret_cast<f32x4*>(si + lds_item[i]) = rin[k][i];
+    }
     if constexpr (!(OPT & 2)) {
       f32x4* sw = reinterpret_cast<f32x4*>(s_w + buf * W_FLOATS);
 #pragma unroll
@@ -236,20 +253,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
   long long tk0 = 0, tk1 = 0, t_mfma = 0, t_sync = 0, t_issue = 0;
   if constexpr (ABL & 16) tk0 = clock64();
   load_chunk(ch_begin);
-  store_chunk(ch_begin & 1);
+  store_chunk(bufof(ch_begin));
   __syncthreads();
   if constexpr (ABL & 16) tk1 = clock64();
 
-  for (int ch = ch_begin; ch < ch_end; ++ch) {
+  for (int ch = ch_begin; ch < ch_end; ch += KS) {
     long long ta = 0, tb = 0, tc = 0;
     if constexpr (ABL & 16) ta = clock64();
-    const int buf = ch & 1;
-    const bool more = (ch + 1 < ch_end) && !(ABL & 1);
-    if (more) load_chunk(ch + 1);
+    const int buf = bufof(ch);
+    const bool more = (ch + KS < ch_end) && !(ABL & 1);
+    if (more) load_chunk(ch + KS);
 
     if constexpr (ABL & 16) tb = clock64();
-    const float* si = s_in + buf * IN_FLOATS + b_off;
-    const float* sw = s_w + buf * W_FLOATS + a_off;
+    const float* si = s_in + (buf * KS + wk) * IN_FLOATS + b_off;
+    const float* sw = s_w + (buf * KS + wk) * W_FLOATS + a_off;
+    if (KS == 1 || ch + wk < ch_end) {       // odd chunk count: the last pair has one member
     f32x4 bq[2], aq[2][NT];
     bq[0] = *reinterpret_cast<const f32x4*>(si);
 #pragma unroll
@@ -271,6 +289,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][t][kk], bq[cur][kk], acc[t], 0, 0, 0);
       }
     }
+    }
     if constexpr (ABL & 16) {
       // wait for the accumulator (i.e. for the last MFMA) before stamping
       asm volatile("s_nop 0" ::"v"(acc[0][0]));
@@ -291,6 +310,28 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
     }
   }
 
+  if constexpr (KS == 2) {
+    // all staging buffers are dead (the loop ends on a barrier): K group 1 hands its
+    // partial sums to K group 0, which owns the epilogue.  acc = group0 + group1, fixed order.
+    float* red = smem;
+    if (wk == 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          red[(((wn * WM + wm) * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[t][r] += red[(((wn * WM + wm) * NT + t) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();          // the epilogue re-uses the same LDS
+  }
+  const bool do_ep = wk == 0;
   // ---- epilogue: bias, activation, residual, NCHW store --------------------
   // All loads are issued before any use (independent, one wait), and the
   // activation is a select on a wave-uniform slope: no branches per element.
@@ -317,15 +358,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
       // accumulators -> LDS [oc][32 px] (stride 36) -> each lane re-reads 4 consecutive
       // pixels of one channel and issues 16-byte stores: 4x fewer store instructions.
       constexpr int ES = 36;
-      float* ep = smem + wave * (NT * 32 * ES);
+      float* ep = smem + (wave % (WM * WN)) * (NT * 32 * ES);
+      if (do_ep) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          ep[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ES + ll] = acc[t][r];
+          for (int r = 0; r < 16; ++r)
+            ep[(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ES + ll] = acc[t][r];
+      }
       __syncthreads();
       const int ocw = ocg * OCB + wn * (NT * 32);
-      if (py < a.h) {
+      if (do_ep && py < a.h) {
 #pragma unroll
         for (int j = 0; j < NT * 4; ++j) {
           int idx4 = j * 64 + lane;
@@ -350,6 +393,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
       return;
     }
   }
+  if (!do_ep) return;        // no barrier below
   float bv[NT][16], rv[NT][16];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -380,7 +424,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv3x3_mfma_kernel(Conv3x3Args a
 #define TG_CONV_OPT 3
 #endif
 
-template <int WM, int WN, int NT>
+template <int WM, int WN, int NT, int KS = 1>
 static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   Conv3x3Args a = a0;
   a.vec_ok = (a.w % 4 == 0) && ((uintptr_t)a.y % 16 == 0) && (a.y_ns % 4 == 0) &&
@@ -390,8 +434,21 @@ static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   a.tiles_y = cdiv(a.h, WM);
   a.nocg = cdiv(a.cout, OCB);
   a.nchunk = cdiv(a.cin, CK);
-  size_t lds = 2 * (size_t)((WM + 2) * 2 * RS * 4 + 9 * CK * OCB) * sizeof(float);
+  size_t lds = 2 * KS * (size_t)((WM + 2) * 2 * RS * 4 + 9 * CK * OCB) * sizeof(float);
   if (a.ksplit < 1) a.ksplit = 1;
+  TG_REQUIRE(KS == 1 || a.ksplit == 1, TG_E_ARG, "conv3x3: in-workgroup K split excludes ksplit");
+  if (KS > 1) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(
+                              conv3x3_mfma_kernel<WM, WN, NT, true, 0, TG_CONV_OPT, 12, KS>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(
+                              conv3x3_mfma_kernel<WM, WN, NT, false, 0, TG_CONV_OPT, 12, KS>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+  }
   long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n * a.ksplit;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "conv3x3: grid %lld", blocks);
   // XCD banding pays when a band is many tile rows deep; TG_CONV_XCD=0/1 overrides (lab)
@@ -400,11 +457,11 @@ static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   a.nblocks = xcd ? (int)blocks : 0;
   const unsigned grid = xcd ? (unsigned)(8 * ((blocks + 7) / 8)) : (unsigned)blocks;
   if (a.x2)
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, true, 0, TG_CONV_OPT>),
-                       dim3(grid), dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, true, 0, TG_CONV_OPT, 12, KS>),
+                       dim3(grid), dim3(WM * WN * KS * 64), lds, stream, a);
   else
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, false, 0, TG_CONV_OPT>),
-                       dim3(grid), dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<WM, WN, NT, false, 0, TG_CONV_OPT, 12, KS>),
+                       dim3(grid), dim3(WM * WN * KS * 64), lds, stream, a);
   return check_launch("conv3x3_mfma");
 }
 
@@ -521,6 +578,11 @@ static int conv3x3_impl(const float* x, int64_t x_nstride, int c1, const float* 
   // 64 output channels per workgroup.  Small images get the 2-row tile so that
   // more workgroups exist (tile quantisation dominates there).
   if (conv3x3_rows_per_wg(ocb, (long long)n * h * w) == 4) return launch_conv<4, 1, 2>(a, n, s);
+  // At most half as many 2-row tiles as CUs (e.g. a training batch of 2 x 64 x 64): 1-row tiles
+  // with the channel chunks split over two wave groups keep every SIMD busy in ONE launch.
+  static const int ks_env = [] { const char* e = getenv("TG_CONV_WG_KSPLIT"); return e ? atoi(e) : 1; }();
+  const long long wgs2 = (long long)cdiv(w, TW) * cdiv(h, 2) * cdiv(cout, 64) * n;
+  if (ks_env && a.ksplit <= 1 && wgs2 <= 128 && cdiv(cin, CK) >= 6) return launch_conv<1, 2, 1, 2>(a, n, s);
   return launch_conv<2, 2, 1>(a, n, s);
 }
 
