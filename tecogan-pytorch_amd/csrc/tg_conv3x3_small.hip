@@ -85,7 +85,6 @@ __device__ __forceinline__ void add_upsampled(const SmallArgs& a, int n, int py,
 template <int COUT>
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmallArgs a) {
   __shared__ __attribute__((aligned(16))) float s_in[2][S_CK][S_PH][S_RS];
-  __shared__ float s_w[COUT * 9 * 64];   // [cin][tap][COUT], cin <= 64
 
   const int tid = threadIdx.x;
   const int tcx = tid % S_TWT, tcy = tid / S_TWT;
@@ -97,11 +96,9 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmallArgs a) {
   const long long hw = (long long)a.h * a.w;
   const float* xb = a.x + (long long)n * a.x_ns;
 
-  // weights -> LDS as [cin][tap][COUT]
-  for (int i = tid; i < a.cin * 9 * COUT; i += 256) {
-    int o = i % COUT, t = (i / COUT) % 9, c = i / (COUT * 9);
-    s_w[i] = a.wt[((size_t)o * a.cin + c) * 9 + t];
-  }
+  // wave-uniform weights through the constant address space = scalar loads (see the v2 kernel)
+  const __attribute__((address_space(4))) float* wk =
+      (const __attribute__((address_space(4))) float*)a.wt;           // OIHW
 
   constexpr int PATCH = S_PH * S_PW;                       // 1188 per channel
   constexpr int PER_T = (S_CK * PATCH + 255) / 256;        // 19
@@ -147,7 +144,11 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmallArgs a) {
     for (int c = 0; c < S_CK; ++c) {
       const int cg = ch * S_CK + c;
       if (cg < a.cin) {
-        const float* wc = s_w + cg * 9 * COUT;
+        float wreg[COUT][9];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+#pragma unroll
+          for (int t = 0; t < 9; ++t) wreg[o][t] = wk[(o * a.cin + cg) * 9 + t];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const float* row = &s_in[buf][c][tcy + ky][tcx * S_PXT];
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(SmallArgs a) {
           for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
             for (int o = 0; o < COUT; ++o) {
-              float wv = wc[(ky * 3 + kx) * COUT + o];
+              float wv = wreg[o][ky * 3 + kx];
 #pragma unroll
               for (int p = 0; p < S_PXT; ++p) acc[o][p] += wv * in6[p + kx];
             }
@@ -204,7 +205,12 @@ constexpr unsigned V_OOB = 0x80000000u;
 template <int COUT>
 __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
   __shared__ __attribute__((aligned(16))) float s_in[2][V_CK][S_PH][V_RS];
-  __shared__ float s_w[COUT * 9 * 64];   // [cin][tap][COUT]
+  // The weights are wave-uniform: read through the constant address space they become scalar
+  // loads (s_load_dwordx*) and feed the FMAs as SGPR operands.  Staging them in LDS cost 27
+  // broadcast ds_reads per input channel and made the kernel LDS-issue-bound (PMC:
+  // SQ_WAIT_INST_LDS 37 % of the wave cycles, 32 % of the LDS cycles bank conflicts).
+  const __attribute__((address_space(4))) float* wk =
+      (const __attribute__((address_space(4))) float*)a.wt;           // OIHW
 
   const int tid = threadIdx.x;
   const int tcx = tid % S_TWT, tcy = tid / S_TWT;
@@ -216,11 +222,6 @@ __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
   const int hw = a.h * a.w;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x + (long long)n * a.x_ns), 0, a.cin * hw * 4, 0x00020000);
-
-  for (int i = tid; i < a.cin * 9 * COUT; i += 256) {
-    int o = i % COUT, t = (i / COUT) % 9, c = i / (COUT * 9);
-    s_w[i] = a.wt[((size_t)o * a.cin + c) * 9 + t];
-  }
 
   // per-thread staging slots (fixed for the whole kernel)
   unsigned voff[V_PER_T];
@@ -270,7 +271,11 @@ __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
     for (int c = 0; c < V_CK; ++c) {
       const int cg = ch * V_CK + c;
       if (cg < a.cin) {
-        const float* wc = s_w + cg * 9 * COUT;
+        float wreg[COUT][9];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+#pragma unroll
+          for (int t = 0; t < 9; ++t) wreg[o][t] = wk[(o * a.cin + cg) * 9 + t];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           const float* row = &s_in[buf][c][tcy + ky][tcx * S_PXT];
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
           for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
             for (int o = 0; o < COUT; ++o) {
-              float wv = wc[(ky * 3 + kx) * COUT + o];
+              float wv = wreg[o][ky * 3 + kx];
 #pragma unroll
               for (int p = 0; p < S_PXT; ++p) acc[o][p] += wv * in6[p + kx];
             }
