@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """Training-step timing (BASELINE configs[2]/[3]; not the headline metric).
   python tools/bench_train.py [--crop 256] [--steps 10] [--model TecoGAN]
-One JSON line: steps/s, HR frames/s (= n * 19 / step), per-step ms."""
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      tools/bench_train.py --crop 128          # BASELINE config 4: DDP over RCCL, one rank per GPU
+One JSON line (rank 0): steps/s, HR frames/s (= world * n * 19 / step), per-step ms (MAX over ranks).
+Under torch.distributed.run the gradients of G (and of D when it updates) are averaged over the
+ranks through one flat-bucket all-reduce each, BatchNorm statistics are global (SyncBatchNorm
+halves) and the adaptive-D decision uses one fused 2-float all-reduce; seeds are 0 + rank."""
 import argparse
 import json
 import os
@@ -28,6 +33,8 @@ def main():
     ap.add_argument('--fm-crit', action='store_true', help='add the discriminator feature-matching loss (CB)')
     a = ap.parse_args()
     from tecogan_pytorch_amd.models import define_model
+    from tecogan_pytorch_amd.utils import dist_utils
+    world = int(os.environ.get('WORLD_SIZE', '1'))
     opt = {
         'scale': 4, 'dist': False, 'device': 'cuda', 'rank': 0, 'world_size': 1, 'is_train': True,
         'dataset': {'degradation': {'type': 'BD', 'sigma': 1.5}, 'train': {'crop_size': a.crop}},
@@ -51,9 +58,20 @@ def main():
                                         'feature_layers': [8, 17, 26, 35], 'init': 'default'}
     if a.fm_crit:
         opt['train']['feature_matching_crit'] = {'type': 'CB', 'weight': 1.0, 'reduction': 'mean'}
-    torch.manual_seed(0)
+    if world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ):
+        dist_utils.init_dist(opt, int(os.environ.get('LOCAL_RANK', '0')))
+    rank = opt['rank']
+    torch.manual_seed(0 + rank)                   # base_utils.py:46
     m = define_model(opt)
-    gen = torch.Generator().manual_seed(1)
+    if opt['dist']:                               # identical initial weights on every rank
+        import torch.distributed as dist
+        for net in (m.net_G, getattr(m, 'net_D', None)):
+            if net is not None:
+                for p in net.parameters():
+                    dist.broadcast(p.data, 0)
+                    from tecogan_pytorch_amd import ops as _ops
+                    _ops.bump_version(p)
+    gen = torch.Generator().manual_seed(1 + rank)
     data = [{'gt': torch.rand(a.batch, a.tempo, 3, a.crop + 8, a.crop + 8, generator=gen)}
             for _ in range(2)]
     for i in range(a.warmup):
@@ -66,10 +84,13 @@ def main():
         nupd += 1 if m.log_dict.get('l_gan_D', 0) != 0 else 0
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    dt = dist_utils.max_over_ranks(dt, device='cuda') if opt['dist'] else dt
     tt = 2 * a.tempo - 1 if a.model != 'FRVSR' else a.tempo
-    print(json.dumps({'model': a.model, 'crop': a.crop, 'batch': a.batch, 'tempo_extent': a.tempo,
+    if rank != 0:
+        return
+    print(json.dumps({'model': a.model, 'world_size': opt['world_size'], 'crop': a.crop, 'batch': a.batch, 'tempo_extent': a.tempo,
                       'feature_crit': a.feature_crit, 'fm_crit': a.fm_crit, 'ms_per_step': 1e3 * dt, 'steps_per_s': 1 / dt,
-                      'hr_frames_per_s': a.batch * tt / dt, 'd_updates': nupd, 'steps': a.steps,
+                      'hr_frames_per_s': opt['world_size'] * a.batch * tt / dt, 'd_updates': nupd, 'steps': a.steps,
                       'last_log': {k: float(v) for k, v in m.log_dict.items()},
                       'peak_mem_gb': torch.cuda.max_memory_allocated() / 2**30}))
 
