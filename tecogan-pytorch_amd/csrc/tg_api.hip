@@ -142,7 +142,8 @@ enum {
   K_UPSAMPLE = 7,
   K_QUANT = 8,
   K_FINAL = 9,      // splitk_finalize_kernel
-  K_COUNT = 10
+  K_CONV64_KS = 10, // conv3x3_mfma_kernel<1,2,1,...,2>: in-workgroup K split (few tiles)
+  K_COUNT = 11
 };
 
 static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
@@ -180,6 +181,8 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     double fl = 2.0 * cin * 9 * cout * px;
     double by = 4.0 * px * (cin + cout + (res ? cout : 0)) + 4.0 * 9 * cin * cout;
     int ks = res ? 1 : tg_conv3x3_pick_ksplit(n, cin, cout, hh, ww);
+    if (ks == 1 && kind == K_CONV64_R2 && tg::conv3x3_uses_wg_ksplit(n, cin, cout, hh, ww))
+      kind = K_CONV64_KS;          // same rule as the launcher (tg_conv3x3_mfma.hip)
     if (ks > 1) {
       go(kind, fl, by, [&] {
         return tg::conv3x3_splitk_conv(x, xns, c1, x2, x2ns, lw.w, ocb, n, cin, cout, hh, ww, ks,
@@ -362,7 +365,7 @@ extern "C" const char* tg_frnet_kind_name(int kind) {
       "conv3x3_mfma_kernel<2,2,1>", "conv3x3_mfma_kernel<4,1,2>", "conv3x3_mfma_kernel<4,1,1>",
       "convt3x3s2_mfma_kernel<4,2>", "conv3x3_small_kernel",       "flowup_warp_s2d_kernel",
       "maxpool2_kernel",             "upsample_kernel",            "quantize_u8_hwc_kernel",
-      "splitk_finalize_kernel"};
+      "splitk_finalize_kernel",      "conv3x3_mfma_kernel<1,2,1,KS=2>"};
   return (kind >= 0 && kind < K_COUNT) ? names[kind] : "?";
 }
 

@@ -499,6 +499,16 @@ __global__ void splitk_finalize_kernel(const float* __restrict__ part, int S, lo
 
 }  // namespace tg
 
+namespace tg {
+bool conv3x3_uses_wg_ksplit(int n, int cin, int cout, int h, int w) {
+  static const int ks_env = [] { const char* e = getenv("TG_CONV_WG_KSPLIT"); return e ? atoi(e) : 1; }();
+  if (!ks_env || tg_conv3x3_pick_ocb(cout) != 64 || conv3x3_rows_per_wg(64, (long long)n * h * w) != 2)
+    return false;
+  const long long wgs2 = (long long)cdiv(w, TW) * cdiv(h, 2) * cdiv(cout, 64) * n;
+  return wgs2 <= 128 && cdiv(cin, CK) >= 6;
+}
+}  // namespace tg
+
 using namespace tg;
 
 // Split factor for layers whose tile count cannot fill 256 CUs (FNet's low-resolution,
@@ -580,9 +590,7 @@ static int conv3x3_impl(const float* x, int64_t x_nstride, int c1, const float* 
   if (conv3x3_rows_per_wg(ocb, (long long)n * h * w) == 4) return launch_conv<4, 1, 2>(a, n, s);
   // At most half as many 2-row tiles as CUs (e.g. a training batch of 2 x 64 x 64): 1-row tiles
   // with the channel chunks split over two wave groups keep every SIMD busy in ONE launch.
-  static const int ks_env = [] { const char* e = getenv("TG_CONV_WG_KSPLIT"); return e ? atoi(e) : 1; }();
-  const long long wgs2 = (long long)cdiv(w, TW) * cdiv(h, 2) * cdiv(cout, 64) * n;
-  if (ks_env && a.ksplit <= 1 && wgs2 <= 128 && cdiv(cin, CK) >= 6) return launch_conv<1, 2, 1, 2>(a, n, s);
+  if (a.ksplit <= 1 && conv3x3_uses_wg_ksplit(n, cin, cout, h, w)) return launch_conv<1, 2, 1, 2>(a, n, s);
   return launch_conv<2, 2, 1>(a, n, s);
 }
 
