@@ -87,6 +87,18 @@ int tg_conv3x3_fwd(
     float* y, int64_t y_nstride,
     int n, int cin, int cout, int h, int w, int act, tg_stream_t stream);
 
+/* tg_conv3x3_fwd followed by a ReLU-backward mask in the same epilogue:
+ *   y = relu_mask > 0 ? y : 0      (relu_mask: (n,cout,h,w) fp32, e.g. a ReLU layer's output)
+ * Used by the training tape: the data-gradient conv of a layer (weights packed with
+ * transposed = 2) then delivers dZ of the PRECEDING ReLU layer directly, without a separate
+ * activation-backward pass (torch.autograd's threshold_backward). */
+int tg_conv3x3_fwd_masked(const float* x, int64_t x_nstride, int c1, const float* x2,
+                          int64_t x2_nstride, const float* w_packed, int ocb,
+                          const float* bias, const float* res, int64_t res_nstride,
+                          const float* relu_mask, int64_t mask_nstride, float* y,
+                          int64_t y_nstride, int n, int cin, int cout, int h, int w, int act,
+                          tg_stream_t stream);
+
 /* Split-K variant for layers whose output tile count cannot fill the GPU (FNet's
  * low-resolution many-channel middle, tecogan_nets.py:37-60): `ksplit` groups of
  * input channels are reduced by different workgroups into `partials`

@@ -54,6 +54,10 @@ struct Conv3x3Args {
   int vec_ok;   // w % 4 == 0 and 16-byte aligned y / res planes: float4 epilogue allowed
   long long* dbg;   // lab instrumentation (ABL & 16): 8 cycle stamps per workgroup
   int nblocks;      // > 0: XCD-banded block order over nblocks tiles (grid = 8 * ceil(nblocks / 8))
+  // optional ReLU-backward mask applied last: y = mask > 0 ? y : 0  (same layout as y).  Lets the
+  // data-gradient conv of a layer deliver dZ of the PREVIOUS layer directly (no act_bwd pass).
+  const float* mask;
+  long long mask_ns;
 };
 
 // pack OIHW (or IOHW for transposed convs) -> [ocg][chunk][tap][half][ocb][4]
@@ -381,10 +385,13 @@ __global__ __launch_bounds__(WM* WN* KS * 64) void conv3x3_mfma_kernel(Conv3x3Ar
             long long off = (long long)oc * hw + (long long)py * a.w + gx;
             f32x4 rr = {0.f, 0.f, 0.f, 0.f};
             if (a.res) rr = *reinterpret_cast<const f32x4*>(a.res + (long long)n * a.res_ns + off);
+            f32x4 mm = {1.f, 1.f, 1.f, 1.f};
+            if (a.mask) mm = *reinterpret_cast<const f32x4*>(a.mask + (long long)n * a.mask_ns + off);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float q = v[e] + bb;
-              v[e] = (q >= 0.f ? q : q * slope + 0.f) + rr[e];
+              q = (q >= 0.f ? q : q * slope + 0.f) + rr[e];
+              v[e] = mm[e] > 0.f ? q : 0.f;
             }
             *reinterpret_cast<f32x4*>(a.y + (long long)n * a.y_ns + off) = v;
           }
@@ -395,6 +402,9 @@ __global__ __launch_bounds__(WM* WN* KS * 64) void conv3x3_mfma_kernel(Conv3x3Ar
   }
   if (!do_ep) return;        // no barrier below
   float bv[NT][16], rv[NT][16];
+  unsigned dead[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) dead[t] = 0u;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -403,6 +413,8 @@ __global__ __launch_bounds__(WM* WN* KS * 64) void conv3x3_mfma_kernel(Conv3x3Ar
       int occ = oc < a.cout ? oc : a.cout - 1;
       bv[t][r] = a.bias ? a.bias[occ] : 0.f;
       rv[t][r] = (a.res && inimg) ? a.res[(long long)n * a.res_ns + opix + (long long)occ * hw] : 0.f;
+      if (a.mask && inimg && a.mask[(long long)n * a.mask_ns + opix + (long long)occ * hw] <= 0.f)
+        dead[t] |= 1u << r;
     }
   if (inimg) {
     float* yb = a.y + (long long)n * a.y_ns + opix;
@@ -413,6 +425,7 @@ __global__ __launch_bounds__(WM* WN* KS * 64) void conv3x3_mfma_kernel(Conv3x3Ar
         int oc = ocb0 + t * 32 + (r & 3) + 8 * (r >> 2);
         float v = acc[t][r] + bv[t][r];
         v = (v >= 0.f ? v : v * slope + 0.f) + rv[t][r];
+        if (dead[t] & (1u << r)) v = 0.f;
         if (oc < a.cout && (!(ABL & 4) || v == 12345.678f)) yb[(long long)oc * hw] = v;
       }
   }
@@ -428,7 +441,8 @@ template <int WM, int WN, int NT, int KS = 1>
 static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   Conv3x3Args a = a0;
   a.vec_ok = (a.w % 4 == 0) && ((uintptr_t)a.y % 16 == 0) && (a.y_ns % 4 == 0) &&
-             (!a.res || (((uintptr_t)a.res % 16 == 0) && (a.res_ns % 4 == 0)));
+             (!a.res || (((uintptr_t)a.res % 16 == 0) && (a.res_ns % 4 == 0))) &&
+             (!a.mask || (((uintptr_t)a.mask % 16 == 0) && (a.mask_ns % 4 == 0)));
   constexpr int OCB = WN * NT * 32;
   a.tiles_x = cdiv(a.w, TW);
   a.tiles_y = cdiv(a.h, WM);
@@ -567,8 +581,9 @@ static int conv3x3_impl(const float* x, int64_t x_nstride, int c1, const float* 
                         int64_t x2_nstride, const float* w_packed, int ocb, const float* bias,
                         const float* res, int64_t res_nstride, float* y, int64_t y_nstride, int n,
                         int cin, int cout, int h, int w, int act, int ksplit, float* partials,
-                        tg_stream_t stream) {
+                        tg_stream_t stream, const float* mask = nullptr, int64_t mask_nstride = 0) {
   TG_REQUIRE(x && w_packed && y, TG_E_ARG, "conv3x3_fwd: null pointer");
+  TG_REQUIRE(!mask || ksplit <= 1, TG_E_ARG, "conv3x3_fwd: the ReLU mask is applied in the epilogue (no split-K)");
   TG_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, TG_E_SHAPE,
              "conv3x3_fwd: n=%d cin=%d cout=%d h=%d w=%d", n, cin, cout, h, w);
   TG_REQUIRE(c1 > 0 && c1 <= cin && (c1 == cin || x2), TG_E_ARG,
@@ -583,6 +598,7 @@ static int conv3x3_impl(const float* x, int64_t x_nstride, int c1, const float* 
   a.y = y; a.x_ns = x_nstride; a.x2_ns = x2_nstride; a.res_ns = res_nstride; a.y_ns = y_nstride;
   a.c1 = c1; a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
   a.ksplit = ksplit; a.part = partials; a.part_ss = (long long)n * cout * h * w;
+  a.mask = mask; a.mask_ns = mask_nstride;
   hipStream_t s = (hipStream_t)stream;
   if (ocb == 32) return launch_conv<4, 1, 1>(a, n, s);
   // 64 output channels per workgroup.  Small images get the 2-row tile so that
@@ -601,6 +617,16 @@ extern "C" int tg_conv3x3_fwd(const float* x, int64_t x_nstride, int c1, const f
                               int w, int act, tg_stream_t stream) {
   return conv3x3_impl(x, x_nstride, c1, x2, x2_nstride, w_packed, ocb, bias, res, res_nstride, y,
                       y_nstride, n, cin, cout, h, w, act, 1, nullptr, stream);
+}
+
+extern "C" int tg_conv3x3_fwd_masked(const float* x, int64_t x_nstride, int c1, const float* x2,
+                                     int64_t x2_nstride, const float* w_packed, int ocb,
+                                     const float* bias, const float* res, int64_t res_nstride,
+                                     const float* relu_mask, int64_t mask_nstride, float* y,
+                                     int64_t y_nstride, int n, int cin, int cout, int h, int w,
+                                     int act, tg_stream_t stream) {
+  return conv3x3_impl(x, x_nstride, c1, x2, x2_nstride, w_packed, ocb, bias, res, res_nstride, y,
+                      y_nstride, n, cin, cout, h, w, act, 1, nullptr, stream, relu_mask, mask_nstride);
 }
 
 namespace tg {

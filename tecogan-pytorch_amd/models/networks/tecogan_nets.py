@@ -157,9 +157,13 @@ class SRNet(nn.Module):
         if tape is not None:
             out = TG.conv3x3(tape, self.conv_in['0'], lr_curr, TG.RELU, x2=hr_prev_tran,
                              need_dx=False, need_dx2=True)
+            fused = os.environ.get('TG_FUSED_RESBLOCK', '1') != '0'       # lab switch
             for rb in self.resblocks:
-                t = TG.conv3x3(tape, rb.conv['0'], out, TG.RELU)
-                out = TG.conv3x3(tape, rb.conv['2'], t, TG.NONE, res=out)
+                if fused:
+                    out = TG.resblock(tape, rb.conv['0'], rb.conv['2'], out)
+                else:
+                    t = TG.conv3x3(tape, rb.conv['0'], out, TG.RELU)
+                    out = TG.conv3x3(tape, rb.conv['2'], t, TG.NONE, res=out)
             for k in self.conv_up:
                 out = TG.convt3x3s2(tape, self.conv_up[k], out, TG.RELU)
             return TG.conv3x3_small(tape, self.conv_out, out, TG.NONE, up_src=lr_curr,

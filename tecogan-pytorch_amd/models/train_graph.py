@@ -172,6 +172,37 @@ def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=
     return y
 
 
+def resblock(tape, conv1, conv2, x):
+    """ResidualBlock (tecogan_nets.py:85-100): out = x + conv2(relu(conv1(x))) with a hand-fused
+    backward -- two data-gradient launches per block instead of five:
+      dZ1 = relu'(y1) * dgrad2(dOut)      ReLU mask applied in the conv epilogue
+      dX  = dgrad1(dZ1) + dOut            the skip connection's gradient rides the residual input
+    (the generic tape would run: clone for the skip, dgrad2, act_bwd, dgrad1, axpy)."""
+    y1 = conv3x3(None, conv1, x, RELU)
+    out = conv3x3(None, conv2, y1, NONE, res=x)
+    if tape is None:
+        return out
+    w1, b1, w2, b2 = conv1.weight, conv1.bias, conv2.weight, conv2.bias
+    c = w1.shape[0]
+
+    def bwd():
+        g = tape.pop_grad(out)
+        if g is None:
+            return
+        if w2.requires_grad:
+            tape.defer_wgrad(('w', id(conv2), 0), g, y1, _grad_buf(w2), 0)
+            tape.defer_bias(_grad_buf(b2), g)
+        pk2 = _CACHE.get(conv2, ('dg', 0), _ver(w2), lambda: ops.pack_conv3x3_dgrad(w2.detach().contiguous()))
+        dz1 = ops.conv3x3(g, pk2[0], None, c, c, pk2[3], relu_mask=y1)
+        if w1.requires_grad:
+            tape.defer_wgrad(('w', id(conv1), 0), dz1, x, _grad_buf(w1), 0)
+            tape.defer_bias(_grad_buf(b1), dz1)
+        pk1 = _CACHE.get(conv1, ('dg', 0), _ver(w1), lambda: ops.pack_conv3x3_dgrad(w1.detach().contiguous()))
+        tape.add_grad(x, ops.conv3x3(dz1, pk1[0], None, c, w1.shape[1], pk1[3], res=g))
+    tape.record(bwd)
+    return out
+
+
 def conv3x3_small(tape, layer, x, act=NONE, up_src=None, up_mode=ops.UP_NONE, up_scale=1):
     """cout <= 4 head (flow[2] / conv_out).  `up_src` is data (no gradient)."""
     w, b = layer.weight, layer.bias

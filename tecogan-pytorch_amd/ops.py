@@ -62,17 +62,20 @@ def pack_conv3x3(weight, transposed=False, ocb=None):
 
 
 def conv3x3(x, wpk, bias, cin, cout, ocb, act=ACT_NONE, x2=None, res=None, out=None,
-            pool=False, ksplit=None):
+            pool=False, ksplit=None, relu_mask=None):
     """y = act(conv3x3(cat[x, x2]) + bias) (+ res) [-> maxpool2 when pool].
     x: (n,c1,h,w), x2: (n,cin-c1,h,w).  Small, deep layers go through the
-    deterministic split-K path (ksplit=None: library heuristic)."""
+    deterministic split-K path (ksplit=None: library heuristic).
+    relu_mask (shape of y): y is zeroed where relu_mask <= 0 in the same epilogue (the
+    ReLU backward of the layer that produced relu_mask)."""
     _chk(x, 'x')
     n, c1, h, w = x.shape
     if ksplit is None:
-        ksplit = 1 if res is not None else L.lib().tg_conv3x3_pick_ksplit(n, cin, cout, h, w)
+        ksplit = 1 if (res is not None or relu_mask is not None) else \
+            L.lib().tg_conv3x3_pick_ksplit(n, cin, cout, h, w)
     if ksplit > 1:
-        if res is not None:
-            raise L.TecoganHipError('conv3x3: split-K path has no residual epilogue')
+        if res is not None or relu_mask is not None:
+            raise L.TecoganHipError('conv3x3: split-K path has no residual / mask epilogue')
         if x2 is not None:
             _chk(x2, 'x2')
         part = torch.empty(ksplit * n * cout * h * w, dtype=torch.float32, device=x.device)
@@ -100,6 +103,15 @@ def conv3x3(x, wpk, bias, cin, cout, ocb, act=ACT_NONE, x2=None, res=None, out=N
         if res.shape != out.shape:
             raise L.TecoganHipError('conv3x3: residual shape mismatch')
     hw = h * w
+    if relu_mask is not None:
+        _chk(relu_mask, 'relu_mask')
+        if relu_mask.shape != out.shape:
+            raise L.TecoganHipError('conv3x3: relu_mask shape mismatch')
+        L.check(L.lib().tg_conv3x3_fwd_masked(
+            x.data_ptr(), c1 * hw, c1, _ptr(x2), 0 if x2 is None else x2.shape[1] * hw,
+            wpk.data_ptr(), ocb, _ptr(bias), _ptr(res), cout * hw, relu_mask.data_ptr(), cout * hw,
+            out.data_ptr(), cout * hw, n, cin, cout, h, w, act, _stream()), 'tg_conv3x3_fwd_masked')
+        return out
     L.check(L.lib().tg_conv3x3_fwd(
         x.data_ptr(), c1 * hw, c1, _ptr(x2), 0 if x2 is None else x2.shape[1] * hw,
         wpk.data_ptr(), ocb, _ptr(bias), _ptr(res), cout * hw, out.data_ptr(), cout * hw,

@@ -238,3 +238,41 @@ def test_wgrad_and_bias_grad_over_segments_match_concatenation(ops):
         ops.wgrad3x3_multi(P, Q[:-1], out)
     with pytest.raises(Exception):
         ops.wgrad3x3_multi(P[:2] + [P[2][:, :, :-1].contiguous()], Q[:3], out)
+
+
+def test_conv_relu_mask_epilogue_and_fused_resblock_backward(ops):
+    """tg_conv3x3_fwd_masked == act_bwd(conv(...)) bit for bit, for aligned and odd widths; the
+    hand-fused ResidualBlock backward (2 launches) reproduces the generic tape (5 launches)
+    bit for bit in dX and in both weight / bias gradients."""
+    from tecogan_pytorch_amd.models import train_graph as TG
+    from tecogan_pytorch_amd.models.networks.tecogan_nets import _Conv
+    g = torch.Generator().manual_seed(5)
+    for (n, h, w) in [(2, 12, 16), (1, 9, 13)]:
+        x = torch.randn(n, 64, h, w, generator=g).cuda()
+        wt = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).cuda()
+        ymask = torch.randn(n, 64, h, w, generator=g).cuda()
+        pk, _, _, ocb = ops.pack_conv3x3(wt)
+        ref = ops.conv3x3(x, pk, None, 64, 64, ocb, ksplit=1)
+        ref = ops.act_bwd(ref, ymask.clamp_min(0).contiguous(), ops.ACT_RELU)
+        out = ops.conv3x3(x, pk, None, 64, 64, ocb, relu_mask=ymask)
+        assert torch.equal(out, ref)
+    torch.manual_seed(3)
+    c1, c2 = _Conv(64, 64).cuda(), _Conv(64, 64).cuda()
+    x = torch.randn(2, 64, 16, 24, generator=g).cuda()
+    gout = torch.randn(2, 64, 16, 24, generator=g).cuda()
+    res = []
+    for fused in (True, False):
+        for p in list(c1.parameters()) + list(c2.parameters()):
+            p.grad = None
+        tape = TG.Tape()
+        if fused:
+            out = TG.resblock(tape, c1, c2, x)
+        else:
+            t = TG.conv3x3(tape, c1, x, TG.RELU)
+            out = TG.conv3x3(tape, c2, t, TG.NONE, res=x)
+        tape.add_grad(out, gout.clone())
+        tape.backward()
+        res.append((out.clone(), tape.grad(x).clone(), c1.weight.grad.clone(), c1.bias.grad.clone(),
+                    c2.weight.grad.clone(), c2.bias.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
