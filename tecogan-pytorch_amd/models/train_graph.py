@@ -231,17 +231,46 @@ def conv3x3_small(tape, layer, x, act=NONE, up_src=None, up_mode=ops.UP_NONE, up
 # the space-to-depth embedding (oy = 2*iy - 1 + ky  <=>  ky -> (phase, tap)).
 # ---------------------------------------------------------------------------
 _KT = {0: (1, 0), 1: (0, 1), 2: (1, 1)}          # convT: ky -> (py, ty)
+_IDX = {}
+
+
+def _embed_index(kind, a, b, device):
+    """Flat gather indices of the space-to-depth embeddings, built once per shape:
+    `fwd` maps every element of the embedded 3x3 weight to its source element (or to a
+    trailing zero slot), `inv` maps every element of the original weight to its slot in the
+    embedded tensor.  One index_select then replaces 9 / 16 strided slice copies."""
+    key = (kind, a, b, str(device))
+    ent = _IDX.get(key)
+    if ent is None:
+        table = _KT if kind == 'convt' else _K4
+        k = len(table)
+        src = torch.arange(a * b * k * k, dtype=torch.int64).view(a, b, k, k)
+        if kind == 'convt':          # (ci, co, 3, 3) -> (ci, 4co, 3, 3)
+            emb = torch.full((a, 4 * b, 3, 3), a * b * k * k, dtype=torch.int64)
+            for ky, (py, ty) in table.items():
+                for kx, (px, tx) in table.items():
+                    ph = py * 2 + px
+                    emb[:, ph * b:(ph + 1) * b, ty, tx] = src[:, :, ky, kx]
+        else:                        # (co, ci, 4, 4) -> (co, 4ci, 3, 3)
+            emb = torch.full((a, 4 * b, 3, 3), a * b * k * k, dtype=torch.int64)
+            for ky, (py, ty) in table.items():
+                for kx, (px, tx) in table.items():
+                    ph = py * 2 + px
+                    emb[:, ph * b:(ph + 1) * b, ty, tx] = src[:, :, ky, kx]
+        fwd = emb.reshape(-1)
+        inv = torch.empty(a * b * k * k, dtype=torch.int64)
+        valid = fwd < a * b * k * k
+        inv[fwd[valid]] = torch.nonzero(valid).reshape(-1)
+        ent = _IDX[key] = (fwd.to(device), inv.to(device))
+    return ent
 
 
 def _convt_embed(wt):
     """(ci, co, 3, 3) -> conv weight (cout_op = ci, cin_op = 4*co, 3, 3) acting on s2d(dY)."""
     ci, co = wt.shape[:2]
-    we = torch.zeros(ci, 4 * co, 3, 3, dtype=wt.dtype, device=wt.device)
-    for ky, (py, ty) in _KT.items():
-        for kx, (px, tx) in _KT.items():
-            ph = py * 2 + px
-            we[:, ph * co:(ph + 1) * co, ty, tx] = wt[:, :, ky, kx]
-    return we
+    fwd, _ = _embed_index('convt', ci, co, wt.device)
+    flat = torch.cat([wt.reshape(-1), wt.new_zeros(1)])          # trailing slot = 0
+    return flat.index_select(0, fwd).view(ci, 4 * co, 3, 3)
 
 
 def convt3x3s2(tape, layer, x, act=RELU):
@@ -262,12 +291,8 @@ def convt3x3s2(tape, layer, x, act=RELU):
         tape.add_grad(x, ops.conv3x3(s, we[0], None, 4 * co, ci, we[3], ksplit=1))
         if w.requires_grad:
             def post(ge):                                          # G[ci][(ph,co)][ty][tx]
-                sel = torch.empty(ci, co, 3, 3, dtype=torch.float32, device=ge.device)
-                for ky, (py, ty) in _KT.items():
-                    for kx, (px, tx) in _KT.items():
-                        ph = py * 2 + px
-                        sel[:, :, ky, kx] = ge[:, ph * co:(ph + 1) * co, ty, tx]   # gather (copy)
-                ops.axpy_(_grad_buf(w), sel, 1.0)
+                _, inv = _embed_index('convt', ci, co, ge.device)
+                ops.axpy_(_grad_buf(w), ge.reshape(-1).index_select(0, inv).view(ci, co, 3, 3), 1.0)
             tape.defer_wgrad(('ct', id(layer)), x, s, None, 0, post)
             tape.defer_bias(_grad_buf(b), dz)
     tape.record(bwd)
@@ -284,12 +309,9 @@ _K4 = {0: (1, 0), 1: (0, 1), 2: (1, 1), 3: (0, 2)}   # ky -> (py, ty)
 def _conv4_embed(w4):
     """(co, ci, 4, 4) -> (co, 4*ci, 3, 3) acting on s2d(x, 2)."""
     co, ci = w4.shape[:2]
-    we = torch.zeros(co, 4 * ci, 3, 3, dtype=w4.dtype, device=w4.device)
-    for ky, (py, ty) in _K4.items():
-        for kx, (px, tx) in _K4.items():
-            ph = py * 2 + px
-            we[:, ph * ci:(ph + 1) * ci, ty, tx] = w4[:, :, ky, kx]
-    return we
+    fwd, _ = _embed_index('conv4', co, ci, w4.device)
+    flat = torch.cat([w4.reshape(-1), w4.new_zeros(1)])
+    return flat.index_select(0, fwd).view(co, 4 * ci, 3, 3)
 
 
 def conv4x4s2(tape, holder, x, need_dx=True):
@@ -308,12 +330,8 @@ def conv4x4s2(tape, holder, x, need_dx=True):
             return
         if w.requires_grad:
             def post(ge):
-                sel = torch.empty(co, ci, 4, 4, dtype=torch.float32, device=ge.device)
-                for ky, (py, ty) in _K4.items():
-                    for kx, (px, tx) in _K4.items():
-                        ph = py * 2 + px
-                        sel[:, :, ky, kx] = ge[:, ph * ci:(ph + 1) * ci, ty, tx]   # gather (copy)
-                ops.axpy_(_grad_buf(w), sel, 1.0)
+                _, inv = _embed_index('conv4', co, ci, ge.device)
+                ops.axpy_(_grad_buf(w), ge.reshape(-1).index_select(0, inv).view(co, ci, 4, 4), 1.0)
             tape.defer_wgrad(('c4', id(holder)), g, s, None, 0, post)
         if need_dx:
             pkd = _CACHE.get(holder, ('c4d',), _ver(w),
