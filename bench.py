@@ -393,6 +393,8 @@ def main():
     if rank == 0:
         gf, _ = net.profile((c, h, w))
         plan = net._get_plan(1, h, w, dev)
+        cfg_name = ('configs[1]' if (s, deg, (c, h, w)) == (4, 'BD', (3, 134, 320)) else
+                    'configs[4]' if (s, deg, (c, h, w)) == (2, 'BI', (3, 268, 640)) else 'shape, not a named config')
         result = {
             'metric': 'HR frames/sec/GPU at 4xSR 3x134x320 LR; Vid4 PSNR vs reference',
             'value': world * args.steps / elapsed,
@@ -404,7 +406,7 @@ def main():
             'config': {'workload': f'TecoGAN {s}xSR {deg} generator-only inference '
                                    f'(FRNet.infer_sequence) of a synthetic {args.steps}-frame '
                                    f'{c}x{h}x{w} LR clip -> {c}x{s*h}x{s*w} HR uint8, 1 clip/GPU, '
-                                   f'random-init weights (BASELINE configs[1]); a step = one '
+                                   f'random-init weights (BASELINE {cfg_name}); a step = one '
                                    f'recurrent frame',
                        'parallelism': f'clip-sharded x{world}, no data-path collective',
                        'algorithmic_gflop_per_frame': gf['FNet'] + gf['SRNet'],
