@@ -107,6 +107,7 @@ def train(opt, batches):
         if ck and it % ck == 0:
             os.makedirs(opt['train']['ckpt_dir'], exist_ok=True)
             model.save(it)
+            model.save_training_state(it)      # optimiser moments etc.: restartable run
     return model
 
 

@@ -127,6 +127,33 @@ class BaseModel:
     def save_network(self, net, net_label, current_iter):
         torch.save(net.state_dict(), osp.join(self.ckpt_dir, f'{net_label}_iter{current_iter}.pth'))
 
+    @dist_utils.master_only
+    def save_training_state(self, current_iter):
+        """Optimiser moments, schedule position and the adaptive-D counter next to the weight
+        files of `save()`: everything `resume_training_state` needs to continue the run."""
+        st = {'iter': int(current_iter)}
+        for name in ('optim_G', 'optim_D'):
+            if hasattr(self, name):
+                st[name] = getattr(self, name).state_dict()
+        for name in ('sched_G', 'sched_D'):
+            if getattr(self, name, None) is not None:
+                st[name] = getattr(self, name).last_epoch
+        if hasattr(self, 'cnt_upd_D'):
+            st['cnt_upd_D'] = self.cnt_upd_D
+        torch.save(st, osp.join(self.ckpt_dir, f'state_iter{current_iter}.pth'))
+
+    def resume_training_state(self, path):
+        st = torch.load(path, map_location='cpu')
+        for name in ('optim_G', 'optim_D'):
+            if name in st and hasattr(self, name):
+                getattr(self, name).load_state_dict(st[name])
+        for name in ('sched_G', 'sched_D'):
+            if name in st and getattr(self, name, None) is not None:
+                getattr(self, name).last_epoch = st[name]
+        if 'cnt_upd_D' in st:
+            self.cnt_upd_D = st['cnt_upd_D']
+        return st['iter']
+
     def load_network(self, net, load_path):
         net.load_state_dict(torch.load(load_path, map_location='cpu'))
 

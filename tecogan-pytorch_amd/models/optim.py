@@ -38,6 +38,35 @@ class Adam:
             ops.bump_version(p)
 
 
+def _adam_state_dict(self):
+    """Moments in parameter order (the reference saves weights only -- its resume path is a
+    TODO at base_model.py:220-222; this is the missing half of a restartable run)."""
+    st = []
+    for p in self.params:
+        e = self.state.get(id(p))
+        st.append(None if e is None else (e[0].detach().cpu(), e[1].detach().cpu()))
+    return {'steps': self.steps, 'param_groups': [dict(g) for g in self.param_groups], 'state': st}
+
+
+def _adam_load_state_dict(self, sd):
+    if len(sd['state']) != len(self.params):
+        raise ValueError(f"optimizer state has {len(sd['state'])} entries, the network has "
+                         f"{len(self.params)} parameters")
+    self.steps = int(sd['steps'])
+    for g, src in zip(self.param_groups, sd['param_groups']):
+        g.update(src)
+    self.state = {}
+    for p, e in zip(self.params, sd['state']):
+        if e is not None:
+            if e[0].shape != p.shape:
+                raise ValueError(f'optimizer state shape {tuple(e[0].shape)} vs parameter {tuple(p.shape)}')
+            self.state[id(p)] = (e[0].to(p.device).contiguous(), e[1].to(p.device).contiguous())
+
+
+Adam.state_dict = _adam_state_dict
+Adam.load_state_dict = _adam_load_state_dict
+
+
 def define_criterion(criterion_opt):
     """codes/models/optim/__init__.py:5-35: (type, reduction) descriptors; the arithmetic is in
     the HIP loss kernels."""

@@ -140,3 +140,37 @@ def test_vsr_infer_wrapper_matches_generator():
     padded = torch.cat([clip[1:4].flip(0), clip], 0)
     ref = m.net_G.infer_sequence(padded, 'cuda')[3:]
     assert np.array_equal(out, ref)
+
+
+def test_resume_from_weights_and_optimizer_state(tmp_path):
+    """save() + save_training_state() after 2 iterations, a fresh model resumed from them and
+    stepped once == 3 uninterrupted iterations (up to the atomics in the scalar reductions)."""
+    from tecogan_pytorch_amd.models import define_model
+
+    def fresh():
+        opt = make_opt('FRVSR')
+        opt['train']['ckpt_dir'] = str(tmp_path)
+        m = define_model(opt)
+        m.net_G.load_state_dict(generator_state_dict(scale=SCALE, degradation='BD'), strict=True)
+        return m
+    a = fresh()
+    for it in range(3):
+        a.prepare_training_data({'gt': batch(500 + it)})
+        a.train()
+    b = fresh()
+    for it in range(2):
+        b.prepare_training_data({'gt': batch(500 + it)})
+        b.train()
+    b.save(2)
+    b.save_training_state(2)
+    c = fresh()
+    c.load_network(c.net_G, str(tmp_path / 'G_iter2.pth'))
+    assert c.resume_training_state(str(tmp_path / 'state_iter2.pth')) == 2
+    assert c.optim_G.steps == 2
+    c.prepare_training_data({'gt': batch(502)})
+    c.train()
+    pa, pc = dict(a.net_G.named_parameters()), dict(c.net_G.named_parameters())
+    for k in WATCH_G:
+        d = (pa[k] - pc[k]).abs().max().item()
+        assert d <= 2.5e-4, (k, d)          # a few Adam sign flips of 1e-4 at most
+    assert abs(a.log_dict['l_pix_G'] - c.log_dict['l_pix_G']) <= 1e-5

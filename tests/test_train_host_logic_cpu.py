@@ -59,3 +59,27 @@ def test_tape_accumulates_and_orders():
     assert tape.pop_grad(a) is g and tape.grad(a) is None
     tape.backward()
     assert order == ['second', 'first'] and tape.nodes == []
+
+
+def test_adam_state_dict_round_trip():
+    """Optimiser-state checkpoint (the resume half the reference leaves as a TODO): moments,
+    step count and hyper-parameters survive a save / load; mismatched networks are refused."""
+    import pytest
+    from tecogan_pytorch_amd.models.optim import Adam
+    ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5))]
+    a = Adam(ps, lr=1e-4, betas=(0.9, 0.99))
+    a.steps = 7
+    a.state[id(ps[0])] = (torch.full((3, 4), 0.5), torch.full((3, 4), 0.25))
+    sd = a.state_dict()
+    assert sd['steps'] == 7 and sd['state'][1] is None
+    qs = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5))]
+    b = Adam(qs, lr=1.0)
+    b.load_state_dict(sd)
+    assert b.steps == 7 and b.param_groups[0]['lr'] == 1e-4 and b.param_groups[0]['betas'] == (0.9, 0.99)
+    m, v = b.state[id(qs[0])]
+    assert torch.equal(m, torch.full((3, 4), 0.5)) and torch.equal(v, torch.full((3, 4), 0.25))
+    assert id(qs[1]) not in b.state
+    with pytest.raises(ValueError):
+        Adam(qs[:1], lr=1.0).load_state_dict(sd)
+    with pytest.raises(ValueError):
+        Adam([torch.nn.Parameter(torch.zeros(4, 3)), qs[1]], lr=1.0).load_state_dict(sd)
