@@ -285,12 +285,18 @@ int tg_bn_lrelu_train_bwd(const float* x, const float* y, const float* dy,
                           float* dgamma, float* dbeta, int accumulate, float* scratch2c,
                           int n, int c, int hw, tg_stream_t stream);
 /* SyncBatchNorm halves (base_model.py:133): per-channel reductions exposed so the host can
- * all-reduce the packed vectors over RCCL in between.  sums2c = [sum x | sum x^2] (fwd) or
- * [sum dz | sum dz*xhat] (bwd), 2*c floats; count / inv_count refer to the GLOBAL batch. */
-int tg_bn_moments(const float* x, float* sums2c, int n, int c, int hw, tg_stream_t stream);
-int tg_bn_finalize_stats(const float* sums2c, float count, float eps, float momentum,
-                         float* mean, float* invstd, float* running_mean,
-                         float* running_var, int c, tg_stream_t stream);
+ * exchange the packed vectors over RCCL in between.
+ *   forward : tg_bn_local_stats -> stats2c = [mean | centred sum of squares] of THIS rank's
+ *             slice; all-gather (world x 2c floats); tg_bn_merge_stats merges equally sized
+ *             partitions with Chan's formula (no E[x^2]-mean^2 cancellation; world = 1
+ *             reproduces tg_bn_lrelu_train_fwd's statistics exactly) and updates the
+ *             running stats with the unbiased global variance;
+ *   backward: tg_bn_lrelu_bwd_reduce -> sums2c = [sum dz | sum dz*xhat]; all-reduce(sum);
+ *             tg_bn_lrelu_bwd_apply with inv_count = 1 / GLOBAL element count. */
+int tg_bn_local_stats(const float* x, float* stats2c, int n, int c, int hw, tg_stream_t stream);
+int tg_bn_merge_stats(const float* gathered, int world, float count_per_rank, float eps,
+                      float momentum, float* mean, float* invstd, float* running_mean,
+                      float* running_var, int c, tg_stream_t stream);
 int tg_bn_lrelu_apply(const float* x, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, float slope, float* y,
                       int n, int c, int hw, tg_stream_t stream);
@@ -313,6 +319,35 @@ int tg_linear1_bwd(const float* x, const float* w, const float* dy, float* dx, f
  * y is (nc, oh, ow) with oh = pad ? (h-1)/scale+1 : (h-ksize)/scale+1. */
 int tg_downsample_bd(const float* x, const float* kernel2d, float* y, int nc, int h,
                      int w, int ksize, int scale, int pad, tg_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * RCCL exchange of the data-parallel training step (one process per GPU, xGMI).
+ * Replaces DistributedDataParallel's gradient all-reduce (base_model.py:130-136), the
+ * SyncBatchNorm statistics exchange (:133) and dist.all_reduce of the adaptive-D scalars
+ * (vsrgan_model.py:166-173) for a host WITHOUT torch.distributed: rank 0 calls
+ * tg_comm_get_unique_id and ships the 128 bytes to the other ranks over any channel it has
+ * (the reference's launcher: env:// TCP, utils/dist_utils.py:8-24); every rank then calls
+ * tg_comm_init_rank (collective, current HIP device).  Collectives only enqueue on `stream`.
+ * RCCL is bound with dlopen at the first tg_comm_* call (the copy already mapped in the
+ * process wins); a missing RCCL is TG_E_HIP, never a silent single-rank run.
+ * The Python host mirror keeps the reference's own transport by default -- torch.distributed,
+ * whose "nccl" backend IS this same RCCL -- because the process group's lifetime and
+ * rendezvous belong to the host application (utils/dist_utils.py:init_dist); it switches to
+ * these entry points with TECOGAN_COMM=c_abi.
+ * ---------------------------------------------------------------------- */
+#define TG_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+typedef struct tg_comm tg_comm;
+int tg_comm_get_unique_id(uint8_t id[TG_COMM_ID_BYTES]);
+int tg_comm_init_rank(const uint8_t id[TG_COMM_ID_BYTES], int world, int rank, tg_comm** out);
+int tg_comm_destroy(tg_comm* comm);
+int tg_comm_world(const tg_comm* comm);
+int tg_comm_rank(const tg_comm* comm);
+const char* tg_comm_library_origin(void); /* which librccl was bound ("" = none yet) */
+/* in-place SUM over ranks (flat gradient bucket: 10.4 MB G / 3.3 MB D; BN backward sums) */
+int tg_allreduce_sum_f32(tg_comm* comm, float* buf, int64_t count, tg_stream_t stream);
+/* recv = [rank 0 | rank 1 | ...], count_per_rank floats each (SyncBN forward statistics) */
+int tg_allgather_f32(tg_comm* comm, const float* send, float* recv, int64_t count_per_rank,
+                     tg_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Whole-frame plan: one call = FRNet.step (tecogan_nets.py:227-252).  The plan

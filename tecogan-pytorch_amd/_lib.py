@@ -66,14 +66,22 @@ SIGNATURES = {
     'tg_axpy': (I, [P, P, F, I64, P]),
     'tg_bn_lrelu_train_fwd': (I, [P, P, P, P, P, F, F, F, P, P, P, I, I, I, P]),
     'tg_bn_lrelu_train_bwd': (I, [P, P, P, P, P, P, F, P, P, P, I, P, I, I, I, P]),
-    'tg_bn_moments': (I, [P, P, I, I, I, P]),
-    'tg_bn_finalize_stats': (I, [P, F, F, F, P, P, P, P, I, P]),
+    'tg_bn_local_stats': (I, [P, P, I, I, I, P]),
+    'tg_bn_merge_stats': (I, [P, I, F, F, F, P, P, P, P, I, P]),
     'tg_bn_lrelu_apply': (I, [P, P, P, P, P, F, P, I, I, I, P]),
     'tg_bn_lrelu_bwd_reduce': (I, [P, P, P, P, P, F, P, I, I, I, P]),
     'tg_bn_lrelu_bwd_apply': (I, [P, P, P, P, P, P, P, F, F, P, I, I, I, P]),
     'tg_linear1_fwd': (I, [P, P, P, P, I, I, P]),
     'tg_linear1_bwd': (I, [P, P, P, P, P, P, I, I, I, P]),
     'tg_downsample_bd': (I, [P, P, P, I, I, I, I, I, I, P]),
+    'tg_comm_get_unique_id': (I, [P]),
+    'tg_comm_init_rank': (I, [P, I, I, C.POINTER(C.c_void_p)]),
+    'tg_comm_destroy': (I, [P]),
+    'tg_comm_world': (I, [P]),
+    'tg_comm_rank': (I, [P]),
+    'tg_comm_library_origin': (C.c_char_p, []),
+    'tg_allreduce_sum_f32': (I, [P, P, I64, P]),
+    'tg_allgather_f32': (I, [P, P, P, I64, P]),
     'tg_frnet_workspace_floats': (SZ, [C.POINTER(FrnetCfg)]),
     'tg_frnet_plan_create': (I, [C.POINTER(FrnetCfg), C.POINTER(LayerWeights), I, P,
                                  C.POINTER(C.c_void_p)]),

@@ -5,14 +5,19 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=on -Wall -Wno-unused-function"
 OBJS=()
+PIDS=()
 for f in tg_*.hip; do
   o="${f%.hip}.o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ tg_common.h -nt "$o" ] || [ ../../include/tecogan_hip.h -nt "$o" ]; then
     echo "hipcc $f"
+    rm -f "$o"                       # a failed compile must not leave a stale object to link
     $HIPCC $FLAGS ${EXTRA_FLAGS:-} -c "$f" -o "$o" &
+    PIDS+=($!)
   fi
   OBJS+=("$o")
 done
-wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libtecogan_hip.so "${OBJS[@]}"
+for pid in "${PIDS[@]:-}"; do      # bare `wait` returns 0 even when a job failed
+  [ -z "$pid" ] || wait "$pid" || { echo "build.sh: a compile job failed" >&2; exit 1; }
+done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libtecogan_hip.so "${OBJS[@]}" -ldl
 echo "built $(cd .. && pwd)/libtecogan_hip.so"

@@ -749,54 +749,79 @@ extern "C" int tg_downsample_bd(const float* x, const float* kernel2d, float* y,
 
 // ---- SyncBatchNorm building blocks (nn.SyncBatchNorm.convert_sync_batchnorm,
 // codes/models/base_model.py:133): the per-channel reductions are exposed separately so
-// the host can all-reduce the packed (sum, sum of squares) / (sum dz, sum dz*xhat) vectors
-// over RCCL between the two halves.  One small all-reduce per BN layer and direction.
+// the host can exchange them over RCCL between the two halves: forward = all-gather of the
+// per-rank (mean, centred M2) pairs merged with Chan's formula (what torch's SyncBatchNorm
+// does with mean / invstd / count), backward = all-reduce of (sum dz, sum dz*xhat).
+// One small collective per BN layer and direction.
 namespace tg {
-__global__ __launch_bounds__(1024) void bn_moments_kernel(const float* __restrict__ x, int n, int c,
-                                                         int hw, float* __restrict__ sums2c) {
+// local statistics of this rank's slice of the batch: mean and CENTRED sum of squares
+// (two passes over the plane, like bn_stats_kernel) -> stats2c = [mean | M2]
+__global__ __launch_bounds__(1024) void bn_local_stats_kernel(const float* __restrict__ x, int n, int c,
+                                                             int hw, float* __restrict__ stats2c) {
   __shared__ float sm[16];
+  __shared__ float s_mean;
   int ch = blockIdx.x;
-  float s = 0.f, q = 0.f;
+  float s = 0.f;
   for (int b = 0; b < n; ++b) {
     const float* p = x + ((long long)b * c + ch) * hw;
-    for (int i = threadIdx.x; i < hw; i += blockDim.x) { float v = p[i]; s += v; q += v * v; }
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) s += p[i];
   }
-  float r0 = block_sum(s, sm), r1 = block_sum(q, sm);
-  if (threadIdx.x == 0) { sums2c[ch] = r0; sums2c[c + ch] = r1; }
+  float tot = block_sum(s, sm);
+  if (threadIdx.x == 0) s_mean = tot / ((float)n * (float)hw);
+  __syncthreads();
+  const float mean = s_mean;
+  float q = 0.f;
+  for (int b = 0; b < n; ++b) {
+    const float* p = x + ((long long)b * c + ch) * hw;
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) { float d = p[i] - mean; q += d * d; }
+  }
+  float sq = block_sum(q, sm);
+  if (threadIdx.x == 0) { stats2c[ch] = mean; stats2c[c + ch] = sq; }
 }
-// sums2c = global (sum x, sum x^2), count = global element count per channel
-__global__ void bn_finalize_stats_kernel(const float* __restrict__ sums2c, float count, float eps,
-                                         float momentum, float* __restrict__ mean,
-                                         float* __restrict__ invstd, float* __restrict__ run_mean,
-                                         float* __restrict__ run_var, int c) {
+// Chan et al. merge of `world` equally sized partitions (DistributedSampler: equal per-rank
+// batches): mean = avg(mean_r); M2 = sum M2_r + cnt_r * sum (mean_r - mean)^2, ranks in
+// index order on every rank (bit-identical statistics everywhere).  No E[x^2]-mean^2
+// cancellation, no clamp: with world = 1 this is exactly bn_stats_kernel's result.
+__global__ void bn_merge_stats_kernel(const float* __restrict__ gathered, int world, float cnt_r,
+                                      float eps, float momentum, float* __restrict__ mean,
+                                      float* __restrict__ invstd, float* __restrict__ run_mean,
+                                      float* __restrict__ run_var, int c) {
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
-  float m = sums2c[ch] / count;
-  float var = sums2c[c + ch] / count - m * m;
-  var = var < 0.f ? 0.f : var;
+  float m = 0.f;
+  for (int r = 0; r < world; ++r) m += gathered[(long long)r * 2 * c + ch];
+  m = world == 1 ? m : m / (float)world;
+  float m2 = 0.f;
+  for (int r = 0; r < world; ++r) {
+    float d = gathered[(long long)r * 2 * c + ch] - m;
+    m2 += gathered[(long long)r * 2 * c + c + ch] + cnt_r * d * d;
+  }
+  const float cnt = cnt_r * (float)world;
+  float var = m2 / cnt;
   mean[ch] = m;
   invstd[ch] = 1.0f / sqrtf(var + eps);
   if (run_mean) {
     run_mean[ch] = (1.f - momentum) * run_mean[ch] + momentum * m;
-    run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * (var * count / (count - 1.f));
+    run_var[ch] = (1.f - momentum) * run_var[ch] + momentum * (var * cnt / (cnt - 1.f));
   }
 }
 }  // namespace tg
 
-extern "C" int tg_bn_moments(const float* x, float* sums2c, int n, int c, int hw,
-                             tg_stream_t stream) {
-  TG_REQUIRE(x && sums2c && n > 0 && c > 0 && hw > 0, TG_E_ARG, "bn_moments: bad argument");
-  hipLaunchKernelGGL(tg::bn_moments_kernel, dim3(c), dim3(tg::bn_threads(n, hw)), 0, ST, x, n, c, hw, sums2c);
-  return tg::check_launch("bn_moments");
+extern "C" int tg_bn_local_stats(const float* x, float* stats2c, int n, int c, int hw,
+                                 tg_stream_t stream) {
+  TG_REQUIRE(x && stats2c && n > 0 && c > 0 && hw > 0, TG_E_ARG, "bn_local_stats: bad argument");
+  hipLaunchKernelGGL(tg::bn_local_stats_kernel, dim3(c), dim3(tg::bn_threads(n, hw)), 0, ST, x, n, c, hw, stats2c);
+  return tg::check_launch("bn_local_stats");
 }
 
-extern "C" int tg_bn_finalize_stats(const float* sums2c, float count, float eps, float momentum,
-                                    float* mean, float* invstd, float* running_mean,
-                                    float* running_var, int c, tg_stream_t stream) {
-  TG_REQUIRE(sums2c && mean && invstd && c > 0 && count > 1.f, TG_E_ARG, "bn_finalize_stats: bad argument");
-  hipLaunchKernelGGL(tg::bn_finalize_stats_kernel, dim3(tg::cdiv(c, 256)), dim3(256), 0, ST, sums2c,
-                     count, eps, momentum, mean, invstd, running_mean, running_var, c);
-  return tg::check_launch("bn_finalize_stats");
+extern "C" int tg_bn_merge_stats(const float* gathered, int world, float count_per_rank, float eps,
+                                 float momentum, float* mean, float* invstd, float* running_mean,
+                                 float* running_var, int c, tg_stream_t stream) {
+  TG_REQUIRE(gathered && mean && invstd && c > 0 && world >= 1 && count_per_rank * world > 1.f, TG_E_ARG,
+             "bn_merge_stats: bad argument");
+  hipLaunchKernelGGL(tg::bn_merge_stats_kernel, dim3(tg::cdiv(c, 256)), dim3(256), 0, ST, gathered, world,
+                     count_per_rank, eps, momentum, mean, invstd, running_mean, running_var, c);
+  return tg::check_launch("bn_merge_stats");
 }
 
 extern "C" int tg_bn_lrelu_apply(const float* x, const float* mean, const float* invstd,

@@ -34,6 +34,10 @@ def parse_args(argv=None):
     p.add_argument('--test_speed', action='store_true')
     p.add_argument('--local_rank', default=-1, type=int)
     p.add_argument('--iters', type=int, default=20, help='synthetic train iterations')
+    p.add_argument('--resume', type=int, default=0,
+                   help='iteration to resume from: loads {G,D}_iter<k>.pth and state_iter<k>.pth from '
+                        'train.ckpt_dir and continues at k + 1 (the reference leaves this as a TODO, '
+                        'base_model.py:220-222)')
     return p.parse_args(argv)
 
 
@@ -78,7 +82,8 @@ def setup(args):
     seed = opt.get('manual_seed', 2021) + opt['rank']          # base_utils.py:46
     torch.manual_seed(seed)
     np.random.seed(seed)
-    opt['train'].setdefault('ckpt_dir', os.path.join(args.exp_dir, 'train', 'ckpt'))
+    if opt['is_train']:      # the reference's test.yml files have no `train` section
+        opt['train'].setdefault('ckpt_dir', os.path.join(args.exp_dir, 'train', 'ckpt'))
     return opt
 
 
@@ -93,10 +98,28 @@ def synthetic_train_batches(opt, n_iter, seed):
         yield {'gt': torch.rand(n, t, 3, s + 2 * b, s + 2 * b, generator=g)}
 
 
-def train(opt, batches):
-    """codes/main.py:14-129 call sequence (logging to stdout on rank 0)."""
+def resume(model, opt, it):
+    """Weights of iteration `it` + optimiser moments, schedule position and adaptive-D counter.
+    The learning rate comes from the restored schedule position; every other hyper-parameter
+    from the CURRENT yml."""
+    ck = opt['train']['ckpt_dir']
+    model.load_network(model.net_G, os.path.join(ck, f'G_iter{it}.pth'))
+    if hasattr(model, 'net_D'):
+        model.load_network(model.net_D, os.path.join(ck, f'D_iter{it}.pth'))
+    got = model.resume_training_state(os.path.join(ck, f'state_iter{it}.pth'))
+    if got != it:
+        raise ValueError(f'state_iter{it}.pth was written at iteration {got}')
+    return it
+
+
+def train(opt, batches, start_iter=0):
+    """codes/main.py:14-129 call sequence (logging to stdout on rank 0).  start_iter > 0:
+    continue a checkpointed run (iterations are numbered from start_iter + 1, so checkpoints
+    are not overwritten and the schedules continue where they stopped)."""
     model = define_model(opt)
-    for it, data in enumerate(batches, 1):
+    if start_iter:
+        resume(model, opt, start_iter)
+    for it, data in enumerate(batches, start_iter + 1):
         model.prepare_training_data(data)
         model.train()
         model.update_running_log()
@@ -162,7 +185,8 @@ def main(argv=None):
     args = parse_args(argv)
     opt = setup(args)
     if args.mode == 'train':
-        train(opt, synthetic_train_batches(opt, args.iters, 100 + opt['rank']))
+        train(opt, synthetic_train_batches(opt, args.iters, 100 + opt['rank'] + 7919 * args.resume),
+              start_iter=args.resume)
     elif args.mode == 'test':
         g = torch.Generator().manual_seed(7)
         seqs = []

@@ -75,7 +75,21 @@ class BaseModel:
 
     # -- bookkeeping --------------------------------------------------------
     def model_to_device(self, net):
-        return net.to(self.device)
+        """base_model.py:124-136.  Under DDP the reference's wrapper broadcasts rank 0's
+        parameters and buffers at construction; main.setup seeds every rank differently
+        (base_utils.py:46), so without this the replicas would start from different weights
+        and never converge to one model."""
+        net = net.to(self.device)
+        if self.dist:
+            self.sync_module_states(net)
+        return net
+
+    def sync_module_states(self, net):
+        for prm in net.parameters():
+            dist_utils.broadcast_(prm.data, 0)
+            ops.bump_version(prm)
+        for buf in net.buffers():
+            dist_utils.broadcast_(buf, 0)
 
     def update_learning_rate(self):
         """base_model.py:138-143."""
@@ -125,7 +139,10 @@ class BaseModel:
 
     @dist_utils.master_only
     def save_network(self, net, net_label, current_iter):
-        torch.save(net.state_dict(), osp.join(self.ckpt_dir, f'{net_label}_iter{current_iter}.pth'))
+        # parameters are views of the optimiser's flat buffer: clone so that each entry is
+        # serialised as its own storage, exactly like a reference checkpoint (base_model.py:213-218)
+        sd = OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items())
+        torch.save(sd, osp.join(self.ckpt_dir, f'{net_label}_iter{current_iter}.pth'))
 
     @dist_utils.master_only
     def save_training_state(self, current_iter):
@@ -143,13 +160,18 @@ class BaseModel:
         torch.save(st, osp.join(self.ckpt_dir, f'state_iter{current_iter}.pth'))
 
     def resume_training_state(self, path):
+        """Optimiser moments + step counts, schedule positions (and the learning rate they imply),
+        the adaptive-D counter.  Weights are loaded separately (load_network); betas / eps /
+        weight decay follow the current configuration.  main.train(start_iter=...) wires both."""
         st = torch.load(path, map_location='cpu')
         for name in ('optim_G', 'optim_D'):
             if name in st and hasattr(self, name):
                 getattr(self, name).load_state_dict(st[name])
         for name in ('sched_G', 'sched_D'):
             if name in st and getattr(self, name, None) is not None:
-                getattr(self, name).last_epoch = st[name]
+                sched = getattr(self, name)
+                sched.last_epoch = st[name]
+                sched.optimizer.param_groups[0]['lr'] = sched.lr_at(sched.last_epoch) if st[name] else sched.base_lr
         if 'cnt_upd_D' in st:
             self.cnt_upd_D = st['cnt_upd_D']
         return st['iter']
@@ -171,14 +193,40 @@ class BaseModel:
         return lr_data, n_pad
 
     # -- gradient exchange (clip-level data parallel) ------------------------
-    def allreduce_grads(self, net):
-        """Mean of the gradients over ranks through ONE flat fp32 bucket (RCCL all-reduce
-        over xGMI when the backend is nccl); payload 10.4 MB (G) / 3.3 MB (D)."""
+    def _optim_of(self, net):
+        for name_n, name_o in (('net_G', 'optim_G'), ('net_D', 'optim_D')):
+            if getattr(self, name_n, None) is net:
+                return getattr(self, name_o, None)
+        return None
+
+    def start_grad_exchange(self, net):
+        """Launch the mean-over-ranks of one network's gradients: ONE flat fp32 all-reduce
+        (RCCL over xGMI when the backend is nccl; 10.4 MB G / 3.3 MB D -- latency bound, so a
+        single collective replaces DDP's many buckets), asynchronous on RCCL's own stream.
+        Returns a handle for finish_grad_exchange, or None outside data-parallel runs.  The
+        optimiser's flat gradient buffer is reduced in place (no concatenation / copy back)."""
         if not self.dist:
+            return None
+        optim = self._optim_of(net)
+        if optim is not None and optim._is_flat():
+            bucket = dist_utils.GradBucket([optim.flat_grad], flat=optim.flat_grad)
+        else:
+            bucket = dist_utils.GradBucket(
+                [p.grad for p in net.parameters() if p.requires_grad and p.grad is not None])
+        return bucket.start()
+
+    def finish_grad_exchange(self, bucket):
+        if bucket is None:
             return
-        grads = [p.grad for p in net.parameters() if p.requires_grad and p.grad is not None]
 
         def scale(dst, src, a):
-            dst.zero_()
-            ops.axpy_(dst.view(-1), src.contiguous(), a)
-        dist_utils.allreduce_mean_(grads, scale_fn=scale)
+            if src is None:                       # in place: dst += (a - 1) * dst
+                ops.axpy_(dst, dst, a - 1.0)
+            else:
+                dst.zero_()
+                ops.axpy_(dst.view(-1), src.contiguous(), a)
+        bucket.finish(scale_fn=scale)
+
+    def allreduce_grads(self, net):
+        """Blocking form (reference: DDP's backward hook, base_model.py:130-136)."""
+        self.finish_grad_exchange(self.start_grad_exchange(net))

@@ -283,27 +283,39 @@ class FRNet(nn.Module):
 
     def infer_sequence(self, lr_data, device, pipeline=True, return_device_tensor=False):
         """lr_data: (t,c,h,w) fp32 (host or device) -> (t, s*h, s*w, c) uint8
-        numpy, zero initial state (tecogan_nets.py:254-281).  The whole clip is
-        uploaded once, frames are quantised on the device, and there is one
-        host synchronisation at the end instead of one per frame.
+        numpy, zero initial state (tecogan_nets.py:254-281).  Frames are quantised on the
+        device and there is ONE host synchronisation at the end instead of one per frame.
 
         pipeline=True: FNet depends only on the LR frames, so the flows of the next
         TG_FNET_BATCH (default 8) frame pairs are estimated by one batched FNet pass on a
         second HIP stream while warp+SRNet runs frame by frame on the first (two flow
-        slots, ordered by events); the serial part of the recurrence is SRNet alone."""
+        slots, ordered by events); the serial part of the recurrence is SRNet alone.
+
+        Host I/O (the reference moves every frame H2D and back D2H inside its loop, :273-279):
+        a host clip is uploaded batch by batch and the uint8 frames of a finished batch are
+        copied to pinned host memory on a third (copy) stream while the next batch computes;
+        the returned array is backed by that pinned buffer."""
         tot_frm, c, h, w = lr_data.size()
         s = self.scale
         dev = torch.device(device) if device is not None else lr_data.device
-        lr = lr_data.to(dev, dtype=torch.float32, non_blocking=True).contiguous()
+        host_in = not lr_data.is_cuda
+        stream_io = pipeline and tot_frm >= 2 and not return_device_tensor
         zeros_lr = torch.zeros(1, c, h, w, dtype=torch.float32, device=dev)
+        if host_in and stream_io:
+            lr_ext = torch.empty(tot_frm + 1, c, h, w, dtype=torch.float32, device=dev)
+            lr_ext[0].zero_()                               # frame -1 = zeros (tecogan_nets.py:266)
+            lr_host = lr_data.to(dtype=torch.float32).contiguous()
+        else:
+            lr_ext = torch.cat([zeros_lr, lr_data.to(dev, dtype=torch.float32, non_blocking=True)], 0)
+        lr = lr_ext[1:]
         hr = [torch.zeros(1, c, s * h, s * w, dtype=torch.float32, device=dev),
               torch.empty(1, c, s * h, s * w, dtype=torch.float32, device=dev)]
         u8 = torch.empty(tot_frm, s * h, s * w, c, dtype=torch.uint8, device=dev)
+        host_out = None
         with torch.no_grad():
             if not pipeline or tot_frm < 2:
                 for i in range(tot_frm):
-                    lr_prev = zeros_lr if i == 0 else lr[i - 1:i]
-                    self.step(lr[i:i + 1], lr_prev, hr[i & 1], out=hr[(i + 1) & 1], u8_out=u8[i])
+                    self.step(lr[i:i + 1], lr_ext[i:i + 1], hr[i & 1], out=hr[(i + 1) & 1], u8_out=u8[i])
             else:
                 # FNet needs only the LR frames: the flows of FNET_BATCH consecutive frame
                 # pairs are estimated in ONE batched pass on the side stream (large grids, no
@@ -314,15 +326,29 @@ class FRNet(nn.Module):
                 lib = L.lib()
                 main = torch.cuda.current_stream(dev)
                 side = self._side_stream(dev)
-                lr_ext = torch.cat([zeros_lr, lr], 0)       # frame -1 = zeros (tecogan_nets.py:266)
                 side.wait_stream(main)                      # inputs / weights are ready
                 nbatch = (tot_frm + nb_ - 1) // nb_
                 ev_f, ev_s = self._events(nbatch)
+                copy = self._copy_stream(dev) if stream_io else None
+                ev_in = [torch.cuda.Event() for _ in range(nbatch)] if (stream_io and host_in) else None
+                if stream_io:
+                    host_out = torch.empty(tot_frm, s * h, s * w, c, dtype=torch.uint8, pin_memory=True)
+                    copy.wait_stream(main)                  # lr_ext / u8 allocations are visible
+                if ev_in is not None:                       # uploads run ahead on the copy stream
+                    for k in range(nbatch):
+                        i0 = k * nb_
+                        cnt = min(nb_, tot_frm - i0)
+                        with torch.cuda.stream(copy):
+                            lr_ext[i0 + 1:i0 + 1 + cnt].copy_(lr_host[i0:i0 + cnt], non_blocking=True)
+                            ev_in[k].record(copy)
                 fsz = 2 * plan.fh * plan.fw * 4             # bytes of one frame's LR flow
                 for k in range(nbatch):
                     i0 = k * nb_
                     cnt = min(nb_, tot_frm - i0)
                     fplan = self._get_plan(cnt, h, w, dev, fnet_only=True)
+                    if ev_in is not None:
+                        side.wait_event(ev_in[k])
+                        main.wait_event(ev_in[k])
                     if k >= 2:
                         side.wait_event(ev_s[k - 2])        # flow slot k&1 consumed by batch k-2
                     L.check(lib.tg_frnet_step_phase(fplan.handle, 1, k & 1,
@@ -339,10 +365,25 @@ class FRNet(nn.Module):
                                                         hr[(i + 1) & 1].data_ptr(), u8[i].data_ptr(),
                                                         main.cuda_stream), 'tg_frnet_step_srnet')
                     ev_s[k].record(main)
+                    if stream_io:                           # download batch k while batch k+1 computes
+                        copy.wait_event(ev_s[k])
+                        with torch.cuda.stream(copy):
+                            host_out[i0:i0 + cnt].copy_(u8[i0:i0 + cnt], non_blocking=True)
                 main.wait_stream(side)
+                if stream_io:
+                    main.wait_stream(copy)
         if return_device_tensor:
             return u8
+        if host_out is not None:
+            torch.cuda.current_stream(dev).synchronize()
+            return host_out.numpy()
         return u8.cpu().numpy()
+
+    def _copy_stream(self, dev):
+        st = getattr(self, '_copy', None)
+        if st is None or st.device != dev:
+            st = self._copy = torch.cuda.Stream(device=dev)
+        return st
 
     def _events(self, n):
         """Two event rings, created once and re-recorded by every clip."""
@@ -362,6 +403,15 @@ class FRNet(nn.Module):
             # SRNet chain and every 4th clip drops to 450 frames/s.
             prio = int(os.environ.get('TG_SIDE_STREAM_PRIORITY', '0'))
             st = self._side = torch.cuda.Stream(device=dev, priority=prio)
+            from ... import dynamic_queues_active
+            if not dynamic_queues_active():
+                import warnings
+                warnings.warn(
+                    'tecogan_pytorch_amd: DEBUG_HIP_DYNAMIC_QUEUES=1 is not in effect (the HIP runtime '
+                    'was initialised before the package was imported, or the variable is set to another '
+                    'value).  The FNet/SRNet two-stream overlap of infer_sequence then shares a hardware '
+                    'queue on some clips and silently loses ~15 % throughput on those; export '
+                    'DEBUG_HIP_DYNAMIC_QUEUES=1 before the first GPU call.', RuntimeWarning, stacklevel=3)
         return st
 
     def forward_sequence(self, lr_data):

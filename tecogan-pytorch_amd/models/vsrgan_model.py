@@ -72,9 +72,9 @@ class VSRGANModel(VSRModel):
         all-reduce (the reference issues two all-reduces and a barrier, :166-173)."""
         v = torch.stack([real_stats[2], fake_stats[2]])
         if self.dist:
-            import torch.distributed as dist
-            dist.all_reduce(v)
-            v = v / self.opt['world_size']
+            from ..utils import dist_utils
+            dist_utils.all_reduce_sum_(v)
+            return [x / self.opt['world_size'] for x in v.tolist()]
         return v.tolist()
 
     def train(self):
@@ -126,18 +126,18 @@ class VSRGANModel(VSRModel):
             upd_D = distance < opt_tr['discriminator']['update_threshold']
         else:
             upd_D = True
+        bucket_D = None
         if upd_D:
             self.cnt_upd_D += 1.0
             tape_D.add_grad(real_pred, g_real)
             tape_D.add_grad(fake_pred, g_fake)
             tape_D.backward()
-            self.allreduce_grads(self.net_D)
-            self.optim_D.step()
+            # D's gradient all-reduce runs on RCCL's stream while the D-independent generator
+            # losses below are evaluated on the compute stream
+            bucket_D = self.start_grad_exchange(self.net_D)
         tape_D.nodes, tape_D.grads = [], {}
 
-        # === generator === (D frozen, already updated: :201-202 after :188)
-        for p in self.net_D.parameters():
-            p.requires_grad = False
+        # === generator ===
         losses = torch.zeros(5, dtype=torch.float32, device=self.device)   # pix warp pp feat fm
         if self.pix_crit is not None:
             w_ = opt_tr['pixel_crit'].get('weight', 1)
@@ -168,6 +168,13 @@ class VSRGANModel(VSRModel):
             full2 = torch.zeros_like(hr_data)
             full2[:, te:] = g.flip(1)
             tape_G.add_grad(hr_data, self._neg(full2))
+        # D's update lands here: the third D pass sees the UPDATED, frozen critic
+        # (:201-202 after :188)
+        if upd_D:
+            self.finish_grad_exchange(bucket_D)
+            self.optim_D.step()
+        for p in self.net_D.parameters():
+            p.requires_grad = False
         d_in['tape'] = tape_G
         d_in['need_input_grad'] = True
         (fake_pred_G, fake_feats), _ = self.net_D(hr_data, d_in)

@@ -536,32 +536,30 @@ def downsample_bd(x, kernel2d, scale, pad):
     return y
 
 
-# ---- SyncBatchNorm (+LeakyReLU): reductions all-reduced over ranks between the halves ----
-def _allreduce_sum_(t):
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t)
-        return dist.get_world_size()
-    return 1
-
-
+# ---- SyncBatchNorm (+LeakyReLU): statistics exchanged over ranks between the halves ----
 def sync_bn_lrelu_train_fwd(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5,
                             slope=0.2):
-    """Same contract as bn_lrelu_train_fwd with statistics over the GLOBAL batch: one
-    all-reduce of the packed (sum, sum^2) vector per layer (equal per-rank batch sizes, as
-    DistributedSampler guarantees)."""
+    """Same contract as bn_lrelu_train_fwd with statistics over the GLOBAL batch: every rank
+    computes (mean, centred M2) of its slice, ONE all-gather of 2c floats per layer, merged
+    with Chan's formula in rank order (equal per-rank batch sizes, as DistributedSampler
+    guarantees) -- the formulation torch's SyncBatchNorm uses, with no E[x^2] - mean^2
+    cancellation.  With one rank the result is bit-identical to bn_lrelu_train_fwd."""
+    from .utils import dist_utils
     _chk(x, 'x')
     n, c, h, w = x.shape
     lib = L.lib()
-    sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
-    L.check(lib.tg_bn_moments(x.data_ptr(), sums.data_ptr(), n, c, h * w, _stream()), 'tg_bn_moments')
-    world = _allreduce_sum_(sums)
+    local = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    L.check(lib.tg_bn_local_stats(x.data_ptr(), local.data_ptr(), n, c, h * w, _stream()),
+            'tg_bn_local_stats')
+    gathered = dist_utils.all_gather_flat(local).contiguous()
+    world = gathered.shape[0]
     count = float(n * h * w * world)
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     invstd = torch.empty(c, dtype=torch.float32, device=x.device)
-    L.check(lib.tg_bn_finalize_stats(sums.data_ptr(), count, float(eps), float(momentum),
-                                     mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean),
-                                     _ptr(running_var), c, _stream()), 'tg_bn_finalize_stats')
+    L.check(lib.tg_bn_merge_stats(gathered.data_ptr(), world, float(n * h * w), float(eps),
+                                  float(momentum), mean.data_ptr(), invstd.data_ptr(),
+                                  _ptr(running_mean), _ptr(running_var), c, _stream()),
+            'tg_bn_merge_stats')
     y = torch.empty_like(x)
     L.check(lib.tg_bn_lrelu_apply(x.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
                                   beta.data_ptr(), float(slope), y.data_ptr(), n, c, h * w,
@@ -580,9 +578,10 @@ def sync_bn_lrelu_train_bwd(x, y, dy, gamma, mean, invstd, count, dgamma=None, d
                                        invstd.data_ptr(), float(slope), sums.data_ptr(), n, c, h * w,
                                        _stream()), 'tg_bn_lrelu_bwd_reduce')
     if dgamma is not None:
-        axpy_(dgamma, sums[c:].contiguous(), 1.0)
-        axpy_(dbeta, sums[:c].contiguous(), 1.0)
-    _allreduce_sum_(sums)
+        axpy_(dgamma, sums[c:], 1.0)           # contiguous slices of the packed vector
+        axpy_(dbeta, sums[:c], 1.0)
+    from .utils import dist_utils
+    dist_utils.all_reduce_sum_(sums)
     dx = None
     if need_dx:
         dx = torch.empty_like(x)

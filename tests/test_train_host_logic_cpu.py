@@ -63,7 +63,7 @@ def test_tape_accumulates_and_orders():
 
 def test_adam_state_dict_round_trip():
     """Optimiser-state checkpoint (the resume half the reference leaves as a TODO): moments,
-    step count and hyper-parameters survive a save / load; mismatched networks are refused."""
+    step count and the learning rate survive a save / load; mismatched networks are refused."""
     import pytest
     from tecogan_pytorch_amd.models.optim import Adam
     ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5))]
@@ -75,7 +75,9 @@ def test_adam_state_dict_round_trip():
     qs = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5))]
     b = Adam(qs, lr=1.0)
     b.load_state_dict(sd)
-    assert b.steps == 7 and b.param_groups[0]['lr'] == 1e-4 and b.param_groups[0]['betas'] == (0.9, 0.99)
+    # the learning rate in force at the checkpoint is restored; the other hyper-parameters are
+    # the CURRENT configuration's (a resumed run follows its yml)
+    assert b.steps == 7 and b.param_groups[0]['lr'] == 1e-4 and b.param_groups[0]['betas'] == (0.9, 0.999)
     m, v = b.state[id(qs[0])]
     assert torch.equal(m, torch.full((3, 4), 0.5)) and torch.equal(v, torch.full((3, 4), 0.25))
     assert id(qs[1]) not in b.state
