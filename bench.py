@@ -318,7 +318,7 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
                       'discriminator': {'name': 'STNet', 'in_nc': 3, 'tempo_range': 3}},
             'train': {'tempo_extent': 10, 'ckpt_dir': '/tmp',
                       'generator': {'lr': 5e-5, 'betas': [0.9, 0.999]},
-                      'discriminator': {'update_policy': 'adaptive', 'update_threshold': 0.4,
+                      'discriminator': {'update_policy': 'adaptive', 'update_threshold': 1e9,
                                         'crop_border_ratio': 0.75, 'lr': 5e-5, 'betas': [0.9, 0.999]},
                       'pixel_crit': {'type': 'CB', 'weight': 1, 'reduction': 'mean'},
                       'warping_crit': {'type': 'CB', 'weight': 1, 'reduction': 'mean'},
@@ -355,7 +355,8 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
     out.update({
         'workload': 'BASELINE configs[3]: TecoGAN 4xSR BD GAN training step, per-GPU batch 2 x 10 -> 19 '
                     'frames, crop 128 (REDS yml shape), synthetic U[0,1) GT, random-init weights, fp32; '
-                    'prepare_training_data + train()',
+                    'prepare_training_data + train() with the discriminator updated EVERY step '
+                    '(adaptive policy with threshold +inf: the full G + D step incl. both gradient exchanges)',
         'n_gpus': world, 'ms_per_step': 1e3 * dt, 'clips_per_s': world * 2 / dt,
         'hr_frames_per_s': world * 2 * 19 / dt, 'd_updates': nupd, 'steps': args.train_steps,
         'scaling': 'weak'})

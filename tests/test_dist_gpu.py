@@ -4,7 +4,7 @@ Two ranks run VSRGANModel.train() with per-rank seeds and per-rank batch shards 
 (a) start from rank 0's weights (DDP's construction-time broadcast), (b) stay bit-identical
 to each other after two iterations (flat-bucket gradient mean, SyncBatchNorm statistics,
 fused adaptive-D decision), and (c) reproduce the single-process run on the concatenated
-batch: running BatchNorm statistics to 1e-4 relative, weights to a few Adam sign flips,
+batch: running BatchNorm statistics to 1e-3 relative (+2e-5 abs), weights to a few Adam sign flips,
 rank-0-reduced log values to 1e-3 relative.
 
 `gloo` variant: both ranks share the ONE GPU of the test box (RCCL refuses two ranks on one
@@ -69,7 +69,7 @@ def _check_two_ranks(res2, res1):
         if k.endswith('num_batches_tracked'):
             assert int(v) == int(w) == 6, k
         elif 'running_' in k:
-            assert torch.allclose(v, w, rtol=1e-4, atol=1e-6), (k, (v - w).abs().max())
+            assert torch.allclose(v, w, rtol=1e-3, atol=2e-5), (k, (v - w).abs().max())
         elif v.dtype.is_floating_point:
             d = (v - w).abs().max().item()
             assert d <= 2.5e-4, (k, d)            # 2 Adam steps of 5e-5: a few sign flips at most
