@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtecogan_hip.so')
+# TECOGAN_HIP_LIB: measurement builds of the same sources (tools/build_lab_libs.sh); never a fallback
+LIB_PATH = os.environ.get('TECOGAN_HIP_LIB') or os.path.join(_HERE, 'libtecogan_hip.so')
 
 TG_OK = 0
 ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_TANH24 = 0, 1, 2, 3

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Ablation builds of libtecogan_hip.so for measurements (selected with TECOGAN_HIP_LIB):
+#   warp_abl1 = fused warp kernel without its stores, warp_abl2 = one tap row instead of two,
+#   warp_abl4 = no flow loads.   Usage: bash tools/build_lab_libs.sh
+set -euo pipefail
+cd "$(dirname "$0")/../tecogan-pytorch_amd/csrc"
+OUT=../../tools/_lab_libs
+mkdir -p $OUT
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=on -Wno-unused-value"
+for abl in 1 2 4 3; do
+  /opt/rocm/bin/hipcc $FLAGS -DTG_WARP_ABL=$abl -c tg_warp.hip -o $OUT/tg_warp_abl$abl.o &
+done
+wait
+OBJS=$(ls tg_*.o | grep -v tg_warp.o)
+for abl in 1 2 4 3; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libtecogan_warp_abl$abl.so $OBJS $OUT/tg_warp_abl$abl.o -ldl
+done
+ls -la $OUT/*.so
