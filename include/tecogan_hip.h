@@ -321,6 +321,21 @@ int tg_downsample_bd(const float* x, const float* kernel2d, float* y, int nc, in
                      int w, int ksize, int scale, int pad, tg_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Training-batch assembly from an HBM-resident uint8 training set (the decoded LMDB of
+ * scripts/create_lmdb.py:57: raw RGB HWC frames).  Replaces the per-sample CPU work of
+ * UnpairedLMDBDataset.__getitem__ (codes/data/unpaired_lmdb_dataset.py:55-89: frame windows
+ * incl. "moving first frame", crop_sequence :95-109, augment_sequence :112-129, /255) and the
+ * H2D copy of the fp32 batch.  Geometry is the caller's (drawn with the reference's random
+ * streams):
+ *   geo (n, t, 4) int64: byte offset of the stored frame in `store`, frame width, window
+ *                        row0, col0;   aug (n, 3) int32: flip axis (0 | 2 rows | 3 columns,
+ *                        numpy axes of the tchw stack), temporal flip (0|1), np.rot90 count;
+ *   out (n, t, c, size, size) fp32 = rot90(flip_t(flip_s(windows))) / 255.
+ * ---------------------------------------------------------------------- */
+int tg_gather_clips_u8(const uint8_t* store, const int64_t* geo, const int32_t* aug,
+                       float* out, int n, int t, int c, int size, tg_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * RCCL exchange of the data-parallel training step (one process per GPU, xGMI).
  * Replaces DistributedDataParallel's gradient all-reduce (base_model.py:130-136), the
  * SyncBatchNorm statistics exchange (:133) and dist.all_reduce of the adaptive-D scalars

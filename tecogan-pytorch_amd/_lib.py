@@ -75,6 +75,7 @@ SIGNATURES = {
     'tg_linear1_fwd': (I, [P, P, P, P, I, I, P]),
     'tg_linear1_bwd': (I, [P, P, P, P, P, P, I, I, I, P]),
     'tg_downsample_bd': (I, [P, P, P, I, I, I, I, I, I, P]),
+    'tg_gather_clips_u8': (I, [P, P, P, P, I, I, I, I, P]),
     'tg_comm_get_unique_id': (I, [P]),
     'tg_comm_init_rank': (I, [P, I, I, C.POINTER(C.c_void_p)]),
     'tg_comm_destroy': (I, [P]),

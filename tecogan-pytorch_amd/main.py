@@ -1,10 +1,12 @@
 """Driver with the reference's three modes and CLI flags (codes/main.py,
 codes/utils/base_utils.py:14-30): train | test | profile.
 
-Datasets (LMDB / PNG folders) are out of scope, so `train` and `test` draw clips
-from a synthetic source that honours the loader's output contract
-(unpaired_lmdb_dataset.py:89-93, paired_folder_dataset.py:57-63); a user plugs a
-real DataLoader in by passing any iterable of such dicts to `train()` / `test()`.
+`train` reads the reference's LMDB training sets when `dataset.train.seq_dir` names one
+(tecogan_pytorch_amd/data: the decoded frames live in HBM, batches are cut out by a HIP
+kernel with the reference's augmentation); without it, and for `test` (PNG folders are out of
+scope), clips come from a synthetic source that honours the loader's output contract
+(unpaired_lmdb_dataset.py:89-93, paired_folder_dataset.py:57-63); any iterable of such dicts
+can be passed to `train()` / `test()`.
 
   python -m tecogan_pytorch_amd.main --mode profile --lr_size 3x134x320 --test_speed
   python -m tecogan_pytorch_amd.main --mode train --opt my_train.yml --gpu_ids 0
@@ -184,7 +186,22 @@ def profile(opt, lr_size, test_speed=False):
 def main(argv=None):
     args = parse_args(argv)
     opt = setup(args)
-    if args.mode == 'train':
+    if args.mode == 'train' and opt['dataset'].get('train', {}).get('seq_dir') and \
+            os.path.exists(opt['dataset']['train']['seq_dir']):
+        from .data import TrainSource
+        src = TrainSource(opt)
+
+        def epochs():
+            ep, left = 0, args.iters
+            while left > 0:
+                for b in src.epoch(ep):
+                    if left <= 0:
+                        return
+                    left -= 1
+                    yield b
+                ep += 1
+        train(opt, epochs(), start_iter=args.resume)
+    elif args.mode == 'train':
         train(opt, synthetic_train_batches(opt, args.iters, 100 + opt['rank'] + 7919 * args.resume),
               start_iter=args.resume)
     elif args.mode == 'test':

@@ -1,0 +1,108 @@
+"""CPU: the training-data front end -- LMDB file format reader /
+writer, the reference's key format, and the augmentation geometry + host execution against
+golden vectors produced by the REFERENCE UnpairedLMDBDataset (tests/golden/make_golden_data.py;
+same Python / numpy seeds => identical samples, bit for bit)."""
+import os
+import pickle
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import data_fixture as F
+from tecogan_pytorch_amd.data import (LMDBReader, LMDBWriter, UnpairedLMDBDataset, make_key,
+                                      parse_lmdb_key)
+
+
+def test_key_format_round_trip():
+    k = make_key('my_seq_01', 100, 720, 1280, 7)
+    assert k == 'my_seq_01_100x720x1280_0007'                 # scripts/create_lmdb.py:57
+    assert parse_lmdb_key(k) == ('my_seq_01', (100, 720, 1280), 7)
+
+
+def test_lmdb_round_trip_inline_overflow_and_multi_level(tmp_path):
+    rs = np.random.RandomState(5)
+    items = {}
+    for s in range(50):                                        # 1500 small (inline) values
+        for i in range(30):
+            items[make_key(f'small_{s:02d}', 30, 10, 12, i)] = rs.randint(0, 256, 360, dtype=np.uint8).tobytes()
+    for i in range(20):                                        # overflow runs of 4 pages each
+        items[make_key('big', 20, 64, 64, i)] = rs.randint(0, 256, 64 * 64 * 3, dtype=np.uint8).tobytes()
+    items['edge_exact'] = bytes(2038 - 8 - len('edge_exact'))  # largest inline node
+    items['edge_over'] = bytes(2038 - 8 - len('edge_over') + 1)  # first size that must overflow
+    items['empty'] = b''
+    n = LMDBWriter(str(tmp_path)).write(items)
+    r = LMDBReader(str(tmp_path))
+    assert n == len(items) == len(r)
+    assert r.meta['depth'] >= 3 and r.psize == 4096
+    assert r.keys() == sorted(k.encode() for k in items)
+    for k, v in items.items():
+        assert bytes(r.get(k)) == v, k
+    assert r.get('absent') is None and r.get('big_20x64x64_9999') is None and r.get('') is None
+    # file-level invariants of the format: meta magic, page numbers stored in every header
+    raw = open(os.path.join(str(tmp_path), 'data.mdb'), 'rb').read()
+    assert struct.unpack_from('<I', raw, 16)[0] == 0xBEEFC0DE
+    assert struct.unpack_from('<I', raw, 4096 + 16)[0] == 0xBEEFC0DE
+    assert struct.unpack_from('<Q', raw, 2 * 4096)[0] == 2
+    assert len(raw) % 4096 == 0 and len(raw) // 4096 == r.meta['last_pg'] + 1
+    r.close()
+
+
+def test_reader_rejects_garbage(tmp_path):
+    p = tmp_path / 'data.mdb'
+    p.write_bytes(b'\0' * 8192)
+    with pytest.raises(ValueError):
+        LMDBReader(str(tmp_path))
+
+
+def _make_env(tmp_path, with_meta=True):
+    frames = F.all_frames()
+    LMDBWriter(str(tmp_path)).write({k: v.tobytes() for k, v in frames.items()})
+    if with_meta:
+        with open(os.path.join(str(tmp_path), 'meta_info.pkl'), 'wb') as f:
+            pickle.dump({'name': 'fixture', 'color': 'RGB', 'keys': list(frames.keys())}, f)
+    return frames
+
+
+@pytest.mark.parametrize('tag', list(F.CONFIGS))
+@pytest.mark.parametrize('with_meta', [True, False])
+def test_dataset_samples_equal_the_reference(tmp_path, golden, tag, with_meta):
+    """Frames served from an LMDB file written here; random geometry drawn with the same
+    seeds as the reference run => the same samples (incl. reflect temporal padding at the end
+    of a sequence and the "moving first frame" windows)."""
+    _make_env(tmp_path, with_meta)
+    moving, factor, pseed, nseed = F.CONFIGS[tag]
+    ds = UnpairedLMDBDataset({'seq_dir': str(tmp_path), 'filter_file': None, 'data_type': 'rgb'},
+                             crop_size=F.CROP, tempo_extent=F.TEMPO, moving_first_frame=moving,
+                             moving_factor=factor)
+    g = golden('data_aug')
+    assert len(ds) == sum(n for _, n, _, _ in F.SEQS)
+    random.seed(pseed)
+    np.random.seed(nseed)
+    for it, ref in zip(g[tag + '_items'], g[tag + '_u8']):
+        x = ds[int(it)]['gt']
+        assert x.dtype.is_floating_point and tuple(x.shape) == (F.TEMPO, 3, F.CROP, F.CROP)
+        assert np.array_equal(x.numpy(), ref.astype(np.float32) / np.float32(255.0)), (tag, int(it))
+
+
+def test_filter_file_and_plan_geometry(tmp_path):
+    _make_env(tmp_path)
+    flt = tmp_path / 'sel.txt'
+    flt.write_text('000_ride\n')
+    ds = UnpairedLMDBDataset({'seq_dir': str(tmp_path), 'filter_file': str(flt), 'data_type': 'rgb'},
+                             crop_size=F.CROP, tempo_extent=F.TEMPO, moving_first_frame=True,
+                             moving_factor=0.0)
+    assert len(ds) == 6 and all(k.startswith('000_ride') for k in ds.keys)
+    random.seed(1)
+    np.random.seed(2)
+    for it in range(len(ds)):
+        p = ds.draw_plan(it)
+        assert len(set(p.keys)) == 1                        # moving first frame: one stored frame
+        _, (_, h, w), _ = parse_lmdb_key(p.keys[0])
+        assert all(0 <= r and r + F.CROP <= h for r in p.row0)
+        assert all(0 <= c and c + F.CROP <= w for c in p.col0)
+        assert p.flip_axis in (0, 2, 3) and p.rot_k in (0, 1, 2, 3)
+    with pytest.raises(AssertionError):                    # crop larger than the frame
+        UnpairedLMDBDataset({'seq_dir': str(tmp_path), 'filter_file': None, 'data_type': 'rgb'},
+                            crop_size=64, tempo_extent=F.TEMPO).draw_plan(0)
