@@ -64,24 +64,25 @@ def test_train_source_feeds_the_training_step(tmp_path):
     """TrainSource = create_dataloader(opt, 'train') for BD: enlarged crop (S + 2*int(3 sigma)),
     drop_last batches, DistributedSampler sharding; its batches go straight into
     prepare_training_data + train()."""
-    from test_hip_train import make_opt
+    from tests.test_hip_train import make_opt
     from tecogan_pytorch_amd.models import define_model
     _env(tmp_path)
     opt = make_opt('FRVSR')
     opt['manual_seed'] = 3
-    opt['dataset']['train'].update({'seq_dir': str(tmp_path), 'filter_file': None, 'data_type': 'rgb',
-                                    'crop_size': 16, 'batch_size_per_gpu': 2})
+    flt = tmp_path / 'sel.txt'
+    flt.write_text('walk_000\n')                               # 8 frames of 40 x 48
+    opt['dataset']['train'].update({'seq_dir': str(tmp_path), 'filter_file': str(flt), 'data_type': 'rgb',
+                                    'crop_size': 32, 'batch_size_per_gpu': 2})
     opt['train']['tempo_extent'] = 4
-    opt['train']['moving_first_frame'] = True
-    opt['train']['moving_factor'] = 0.7
     src = TrainSource(opt)
-    assert len(src) == 14 // 2 and src.store.nbytes() >= 8 * 40 * 48 * 3 + 6 * 36 * 52 * 3
+    assert len(src) == 8 // 2 and src.store.nbytes() >= 8 * 40 * 48 * 3
     batches = list(src.epoch(0))
-    assert len(batches) == 7
-    assert all(tuple(b['gt'].shape) == (2, 4, 3, 24, 24) and b['gt'].is_cuda for b in batches)
+    assert len(batches) == 4
+    assert all(tuple(b['gt'].shape) == (2, 4, 3, 40, 40) and b['gt'].is_cuda for b in batches)
+    assert float(batches[0]['gt'].min()) >= 0.0 and float(batches[0]['gt'].max()) <= 1.0
     m = define_model(opt)
     m.prepare_training_data(batches[0])
-    assert tuple(m.lr_data.shape) == (2, 4, 3, 4, 4) and tuple(m.gt_data.shape) == (2, 4, 3, 16, 16)
+    assert tuple(m.lr_data.shape) == (2, 4, 3, 8, 8) and tuple(m.gt_data.shape) == (2, 4, 3, 32, 32)
     m.train()
     assert np.isfinite(m.log_dict['l_pix_G'])
     # two ranks see disjoint halves of the same permutation
@@ -95,4 +96,4 @@ def test_train_source_feeds_the_training_step(tmp_path):
         order = torch.randperm(n, generator=g).tolist()
         halves.append(order[rank:n:2])
         assert len(s) == (n // 2) // 2
-    assert set(halves[0]).isdisjoint(halves[1]) and len(halves[0]) + len(halves[1]) == 14
+    assert set(halves[0]).isdisjoint(halves[1]) and len(halves[0]) + len(halves[1]) == 8
