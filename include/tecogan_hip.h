@@ -137,6 +137,18 @@ int tg_conv3x3_small_fwd(const float* x, int64_t x_nstride, const float* w_oihw,
                          int up_scale, float* y, int64_t y_nstride, int n,
                          int cin, int cout, int h, int w, int act,
                          tg_stream_t stream);
+/* The same launch additionally writing the result as an (h, w, cout) uint8 frame --
+ * float32_to_uint8 (codes/utils/data_utils.py:80-87: round-half-even, clip) of the fp32 value
+ * it stores in y -- so FRNet.infer_sequence's per-frame quantise pass and its re-read of the
+ * HR frame disappear.  Needs n == 1, w % 4 == 0 and 16-byte aligned planes:
+ * tg_conv3x3_small_can_fuse_u8 tells; otherwise call tg_quantize_u8_hwc on y. */
+int tg_conv3x3_small_fwd_u8(const float* x, int64_t x_nstride, const float* w_oihw,
+                            const float* bias, const float* up_src, int up_mode,
+                            int up_scale, float* y, int64_t y_nstride, uint8_t* u8_out,
+                            int n, int cin, int cout, int h, int w, int act,
+                            tg_stream_t stream);
+int tg_conv3x3_small_can_fuse_u8(const float* x, int64_t x_nstride, const float* y,
+                                 int64_t y_nstride, int n, int cin, int h, int w);
 
 /* ------------------------------------------------------------------------
  * Fused: reflect-pad(bottom/right) -> scale * upsample -> backward_warp ->

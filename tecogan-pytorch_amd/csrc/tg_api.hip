@@ -285,16 +285,21 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     });
     top = p->U2;
   }
+  bool u8_fused = false;
   {
     const tg_layer_weights lw = p->L[li++];
     double hpx = (double)n * s * s * hw;
+    u8_fused = !dry && u8_out &&
+               tg_conv3x3_small_can_fuse_u8(top, (int64_t)nf * s * s * hw, hr_out,
+                                            (int64_t)c.out_nc * s * s * hw, n, nf, s * h, s * w);
     go(K_SMALL, 2.0 * nf * 9 * c.out_nc * hpx, 4.0 * hpx * (nf + c.out_nc), [&] {
-      return tg_conv3x3_small_fwd(top, (int64_t)nf * s * s * hw, lw.w, lw.b, lr_curr, c.up_mode, s,
-                                  hr_out, (int64_t)c.out_nc * s * s * hw, n, nf, c.out_nc, s * h,
-                                  s * w, TG_ACT_NONE, st);
+      return tg_conv3x3_small_fwd_u8(top, (int64_t)nf * s * s * hw, lw.w, lw.b, lr_curr, c.up_mode, s,
+                                     hr_out, (int64_t)c.out_nc * s * s * hw, u8_fused ? u8_out : nullptr,
+                                     n, nf, c.out_nc, s * h, s * w, TG_ACT_NONE, st);
     });
   }
-  if (u8_out || dry) {
+  if ((u8_out && !u8_fused) || dry) {
+    // only when the output conv cannot emit the uint8 frame itself (w % 4 != 0, unaligned planes)
     go(K_QUANT, 0, 5.0 * c.out_nc * s * s * hw,
        [&] { return tg_quantize_u8_hwc(hr_out, u8_out, c.out_nc, s * h, s * w, st); });
   }

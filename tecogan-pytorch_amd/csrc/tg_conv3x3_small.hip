@@ -35,6 +35,8 @@ struct SmallArgs {
   long long x_ns, y_ns;
   int cin, cout, h, w, act, up_mode, up_scale;
   int tiles_x, tiles_y;
+  uint8_t* u8;         // optional (n == 1): the same result as HWC uint8, float32_to_uint8
+                       // (codes/utils/data_utils.py:80-87) fused into the epilogue
 };
 
 template <int COUT>
@@ -204,7 +206,10 @@ constexpr unsigned V_OOB = 0x80000000u;
 
 template <int COUT>
 __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_in[2][V_CK][S_PH][V_RS];
+  // ONE LDS buffer (21.9 KB => 7 workgroups per CU instead of 3): the two chunks in flight live
+  // in registers, and with 28 waves per CU the second barrier per chunk costs less than the
+  // occupancy the double buffer took.
+  __shared__ __attribute__((aligned(16))) float s_in[1][V_CK][S_PH][V_RS];
   // The weights are wave-uniform: read through the constant address space they become scalar
   // loads (s_load_dwordx*) and feed the FMAs as SGPR operands.  Staging them in LDS cost 27
   // broadcast ds_reads per input channel and made the kernel LDS-issue-bound (PMC:
@@ -237,8 +242,11 @@ __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
     lds_off[i] = idx < V_ITEMS ? (c * S_PH + r) * V_RS + 4 * q : -1;
   }
   const unsigned plane = (unsigned)hw * 4u;
-  f32x4 rin[V_PER_T];
-  auto load_chunk = [&](int c0) {
+  // Two chunks are in flight: the loop is bound by the latency of the global loads (4
+  // channels = 0.4 us of FMAs per chunk against ~2 us to fetch the next one), so chunk
+  // ch + 2 is requested before chunk ch is consumed; rinA / rinB alternate (loop unrolled x2).
+  f32x4 rinA[V_PER_T], rinB[V_PER_T];
+  auto load_chunk = [&](f32x4 (&rin)[V_PER_T], int c0) {
 #pragma unroll
     for (int i = 0; i < V_PER_T; ++i) {
       // channels past cin fall beyond num_records and read as 0
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
                                              rsrc, (int)(voff[i] + (unsigned)c0 * plane), 0, 0));
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](const f32x4 (&rin)[V_PER_T], int buf) {
     float* base = &s_in[buf][0][0][0];
 #pragma unroll
     for (int i = 0; i < V_PER_T; ++i)
@@ -259,14 +267,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
 #pragma unroll
     for (int p = 0; p < S_PXT; ++p) acc[o][p] = 0.f;
 
-  const int nchunk = cdiv(a.cin, V_CK);
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const int buf = ch & 1;
-    const bool more = ch + 1 < nchunk;
-    if (more) load_chunk((ch + 1) * V_CK);
+  auto compute = [&](int ch, int buf) {
 #pragma unroll
     for (int c = 0; c < V_CK; ++c) {
       const int cg = ch * V_CK + c;
@@ -295,8 +296,29 @@ __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
         }
       }
     }
-    if (more) store_chunk(buf ^ 1);
-    __syncthreads();
+  };
+
+  const int nchunk = cdiv(a.cin, V_CK);
+  load_chunk(rinA, 0);
+  store_chunk(rinA, 0);
+  __syncthreads();
+  if (nchunk > 1) load_chunk(rinB, V_CK);            // chunk 1 -> B
+  // invariant at the top of an even iteration ch: LDS = chunk ch, B = chunk ch + 1 (in flight)
+  for (int ch = 0; ch < nchunk; ch += 2) {
+    if (ch + 2 < nchunk) load_chunk(rinA, (ch + 2) * V_CK);
+    compute(ch, 0);
+    __syncthreads();                                 // everyone has consumed chunk ch
+    if (ch + 1 < nchunk) {
+      store_chunk(rinB, 0);
+      __syncthreads();
+      if (ch + 3 < nchunk) load_chunk(rinB, (ch + 3) * V_CK);
+      compute(ch + 1, 0);
+      __syncthreads();
+      if (ch + 2 < nchunk) {
+        store_chunk(rinA, 0);
+        __syncthreads();
+      }
+    }
   }
 
   const int py = y0 + tcy;
@@ -316,6 +338,24 @@ __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
       *reinterpret_cast<f32x4*>(a.y + (long long)n * a.y_ns + (long long)o * hw +
                                 (long long)py * a.w + px0) = ov;
     }
+    if (a.u8) {
+      // uint8(clip(round_half_even(x * 255), 0, 255)), HWC: the thread's 4 pixels x COUT channels
+      // are 4 * COUT consecutive bytes (px0 % 4 == 0 => 4-byte aligned)
+      uint8_t q[S_PXT * COUT];
+#pragma unroll
+      for (int p = 0; p < S_PXT; ++p)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+          float r = rintf(v[p][o] * 255.0f);
+          r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
+          q[p * COUT + o] = (uint8_t)r;
+        }
+      uint32_t* dst = reinterpret_cast<uint32_t*>(a.u8 + ((long long)py * a.w + px0) * COUT);
+#pragma unroll
+      for (int k = 0; k < COUT; ++k)
+        dst[k] = (uint32_t)q[4 * k] | ((uint32_t)q[4 * k + 1] << 8) | ((uint32_t)q[4 * k + 2] << 16) |
+                 ((uint32_t)q[4 * k + 3] << 24);
+    }
   }
 }
 
@@ -323,10 +363,26 @@ __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
 
 using namespace tg;
 
+// whether tg_conv3x3_small_fwd_u8 can emit the uint8 frame for this launch (else: tg_quantize_u8_hwc)
+extern "C" int tg_conv3x3_small_can_fuse_u8(const float* x, int64_t x_nstride, const float* y,
+                                            int64_t y_nstride, int n, int cin, int h, int w) {
+  return n == 1 && (w % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
+         (x_nstride % 4 == 0) && (y_nstride % 4 == 0) && ((long long)(cin + 4) * h * w * 4 < (1ll << 31));
+}
+
 extern "C" int tg_conv3x3_small_fwd(const float* x, int64_t x_nstride, const float* w_oihw,
                                     const float* bias, const float* up_src, int up_mode,
                                     int up_scale, float* y, int64_t y_nstride, int n, int cin,
                                     int cout, int h, int w, int act, tg_stream_t stream) {
+  return tg_conv3x3_small_fwd_u8(x, x_nstride, w_oihw, bias, up_src, up_mode, up_scale, y, y_nstride,
+                                 nullptr, n, cin, cout, h, w, act, stream);
+}
+
+extern "C" int tg_conv3x3_small_fwd_u8(const float* x, int64_t x_nstride, const float* w_oihw,
+                                       const float* bias, const float* up_src, int up_mode,
+                                       int up_scale, float* y, int64_t y_nstride, uint8_t* u8_out,
+                                       int n, int cin, int cout, int h, int w, int act,
+                                       tg_stream_t stream) {
   TG_REQUIRE(x && w_oihw && y, TG_E_ARG, "conv3x3_small_fwd: null pointer");
   TG_REQUIRE(n > 0 && cin > 0 && cin <= 64 && cout >= 1 && cout <= 4 && h > 0 && w > 0,
              TG_E_SHAPE, "conv3x3_small_fwd: n=%d cin=%d (<=64) cout=%d (<=4) h=%d w=%d", n, cin,
@@ -341,6 +397,7 @@ extern "C" int tg_conv3x3_small_fwd(const float* x, int64_t x_nstride, const flo
   a.x = x; a.wt = w_oihw; a.bias = bias; a.up = up_src; a.y = y; a.x_ns = x_nstride;
   a.y_ns = y_nstride; a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
   a.up_mode = up_mode; a.up_scale = up_scale;
+  a.u8 = u8_out;
   a.tiles_x = cdiv(w, S_TW); a.tiles_y = cdiv(h, S_TH);
   long long blocks = (long long)a.tiles_x * a.tiles_y * n;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "conv3x3_small: grid %lld", blocks);
@@ -349,6 +406,9 @@ extern "C" int tg_conv3x3_small_fwd(const float* x, int64_t x_nstride, const flo
   const bool vec_ok = (w % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) &&
                       (x_nstride % 4 == 0) && (y_nstride % 4 == 0) &&
                       ((long long)(cin + 4) * h * w * 4 < (1ll << 31));
+  TG_REQUIRE(!u8_out || (n == 1 && vec_ok && ((uintptr_t)u8_out % 4 == 0)), TG_E_ARG,
+             "conv3x3_small_fwd_u8: the fused uint8 output needs n == 1, w %% 4 == 0 and aligned planes "
+             "(tg_conv3x3_small_can_fuse_u8)");
   if (vec_ok) {
     switch (cout) {
       case 1: hipLaunchKernelGGL(conv3x3_small_v2_kernel<1>, g, t, 0, s, a); break;
