@@ -87,6 +87,21 @@ int tg_conv3x3_fwd(
     float* y, int64_t y_nstride,
     int n, int cin, int cout, int h, int w, int act, tg_stream_t stream);
 
+/* conv3x3 with PHASE-RESTRICTED TAPS: the strided layers run through their space-to-depth
+ * embeddings -- Conv2d(k4, s2, p1) of the discriminator blocks (tecogan_nets.py:322-340) is a 3x3
+ * conv on space_to_depth(x, 2) with 4*ci input channels, its data gradient a 3x3 conv onto
+ * 4*ci output channels, and the data gradient of ConvTranspose2d(k3, s2, p1, op1) (:119-126) a
+ * 3x3 conv on space_to_depth(dY, 2).  In those embedded weights every sub-pixel phase
+ * (py, px) owns only some tap rows / columns; the others are zeros.  This entry skips them:
+ *   tapsel 1: the phase of the INPUT channel chunk ((channel / cphase): py = phase >> 1,
+ *             px = phase & 1) selects the taps; tapsel 2: the phase of the OUTPUT block does;
+ *   taps_phase0 / taps_phase1: tap set used by phase coordinate 0 / 1 along each axis,
+ *             0 = {0,1,2}, 1 = {0,1}, 2 = {1,2}, 3 = {1}.
+ * Results equal tg_conv3x3_fwd on the same (zero-padded) weights up to summation order. */
+int tg_conv3x3_fwd_phased(const float* x, int64_t x_nstride, const float* w_packed, int ocb,
+                          const float* bias, float* y, int64_t y_nstride, int n, int cin,
+                          int cout, int h, int w, int act, int tapsel, int cphase,
+                          int taps_phase0, int taps_phase1, tg_stream_t stream);
 /* tg_conv3x3_fwd followed by a ReLU-backward mask in the same epilogue:
  *   y = relu_mask > 0 ? y : 0      (relu_mask: (n,cout,h,w) fp32, e.g. a ReLU layer's output)
  * Used by the training tape: the data-gradient conv of a layer (weights packed with
@@ -231,6 +246,14 @@ int tg_wgrad3x3_multi(const float* const* p_list, const float* const* q_list, in
                       int64_t p_nstride, int64_t q_nstride, float* grad, float* workspace,
                       int n_per_seg, int ca, int cb, int cb_total, int cb_off, int h, int w,
                       int accumulate, tg_stream_t stream);
+/* tg_wgrad3x3_multi for a space-to-depth embedded strided conv (see tg_conv3x3_fwd_phased): the
+ * q channels come in 4 sub-pixel phases of `cphase` (multiple of 64) channels and only the taps
+ * the phase owns are computed; the other entries of grad are written as 0. */
+int tg_wgrad3x3_multi_phased(const float* const* p_list, const float* const* q_list, int nseg,
+                             int64_t p_nstride, int64_t q_nstride, float* grad,
+                             float* workspace, int n_per_seg, int ca, int cb, int h, int w,
+                             int accumulate, int cphase, int taps_phase0, int taps_phase1,
+                             tg_stream_t stream);
 int tg_bias_grad_multi(const float* const* dy_list, int nseg, float* db, int n_per_seg, int c,
                        int hw, int accumulate, tg_stream_t stream);
 /* dx = dy * act'(.), expressed through the activation OUTPUT y (ReLU, LeakyReLU(0.2),

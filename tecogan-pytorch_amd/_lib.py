@@ -34,6 +34,7 @@ SIGNATURES = {
     'tg_conv3x3_packed_floats': (SZ, [I, I, I]),
     'tg_conv3x3_pack': (I, [P, P, I, I, I, I, P]),
     'tg_conv3x3_fwd': (I, [P, I64, I, P, I64, P, I, P, P, I64, P, I64, I, I, I, I, I, I, P]),
+    'tg_conv3x3_fwd_phased': (I, [P, I64, P, I, P, P, I64, I, I, I, I, I, I, I, I, I, I, P]),
     'tg_conv3x3_fwd_masked': (I, [P, I64, I, P, I64, P, I, P, P, I64, P, I64, P, I64, I, I, I, I, I, I, P]),
     'tg_conv3x3_pick_ksplit': (I, [I, I, I, I, I]),
     'tg_conv3x3_splitk_fwd': (I, [P, I64, I, P, I64, P, I, P, P, I, I, I, I, I, I, I, P, I, P]),
@@ -53,6 +54,7 @@ SIGNATURES = {
     'tg_wgrad3x3_workspace_floats': (SZ, [I, I, I, I, I]),
     'tg_wgrad3x3': (I, [P, I64, P, I64, P, P, I, I, I, I, I, I, I, I, P]),
     'tg_wgrad3x3_multi': (I, [P, P, I, I64, I64, P, P, I, I, I, I, I, I, I, I, P]),
+    'tg_wgrad3x3_multi_phased': (I, [P, P, I, I64, I64, P, P, I, I, I, I, I, I, I, I, I, P]),
     'tg_bias_grad_multi': (I, [P, I, P, I, I, I, I, P]),
     'tg_act_bwd': (I, [P, P, P, I64, I, P]),
     'tg_bias_grad': (I, [P, P, I, I, I, I, P]),

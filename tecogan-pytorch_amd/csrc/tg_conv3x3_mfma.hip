@@ -58,6 +58,12 @@ struct Conv3x3Args {
   // data-gradient conv of a layer deliver dZ of the PREVIOUS layer directly (no act_bwd pass).
   const float* mask;
   long long mask_ns;
+  // Phase-restricted taps (strided convs through their space-to-depth embedding, see
+  // tap_rows()): tapsel 0 = all nine taps; 1 = the phase of an INPUT channel chunk selects the
+  // taps (cphase channels per phase); 2 = the phase of the OUTPUT channel block does.
+  // rowsets[py] / colsets[px] name the tap rows / columns in use (TAPS_* below).
+  int tapsel, cphase;
+  unsigned char rowsets[2];
 };
 
 // pack OIHW (or IOHW for transposed convs) -> [ocg][chunk][tap][half][ocb][4]
@@ -91,6 +97,63 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned vof
 }
 
 constexpr unsigned OOB = 0x80000000u;   // >= any num_records we build (tensors < 2 GiB per item)
+
+// Tap subsets of the embedded strided convolutions.  A Conv2d(k4, s2, p1) on x equals a 3x3
+// conv on space_to_depth(x, 2) whose sub-pixel phase (py, px) only owns the kernel rows
+// {ky : 2*oy - 1 + ky = 2*(oy + ty - 1) + py}: py = 1 -> ty in {0, 1}, py = 0 -> ty in {1, 2}
+// (same along x); the transposed conv's data gradient on space_to_depth(dY, 2) owns
+// py = 1 -> {0, 1}, py = 0 -> {1}.  The embedded 3x3 weights are zero elsewhere: 4/9 (resp.
+// 9/36) of the MFMAs of the dense kernel are useful, the rest multiplied zeros.  A set is
+// named by a code: 0 = {0,1,2}, 1 = {0,1}, 2 = {1,2}, 3 = {1}.
+enum { TAPS_ALL = 0, TAPS_01 = 1, TAPS_12 = 2, TAPS_1 = 3 };
+__host__ __device__ constexpr int taps_first(int code) { return (code == TAPS_12 || code == TAPS_1) ? 1 : 0; }
+__host__ __device__ constexpr int taps_count(int code) { return code == TAPS_ALL ? 3 : (code == TAPS_1 ? 1 : 2); }
+
+// The MFMAs of one channel chunk over the tap rows RY x tap columns RX (all static): operands
+// of the next tap are fetched into the other register set while this tap's MFMAs issue.
+template <int NT, int OCB, int RY, int RX>
+__device__ __forceinline__ void chunk_taps(const float* si, const float* sw, f32x16 (&acc)[NT]) {
+  constexpr int Y0 = taps_first(RY), NY = taps_count(RY), X0 = taps_first(RX), NX = taps_count(RX);
+  constexpr int N = NY * NX;
+  f32x4 bq[2], aq[2][NT];
+  auto fetch = [&](int i, int slot) {
+    const int ky = Y0 + i / NX, kx = X0 + i % NX;
+    bq[slot] = *reinterpret_cast<const f32x4*>(si + (ky * 2 * 34 + kx) * 4);      // RS = 34
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      aq[slot][t] = *reinterpret_cast<const f32x4*>(sw + (ky * 3 + kx) * (2 * OCB * 4) + t * 128);
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int cur = i & 1;
+    if (i + 1 < N) fetch(i + 1, cur ^ 1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][t][kk], bq[cur][kk], acc[t], 0, 0, 0);
+    }
+  }
+}
+
+template <int NT, int OCB>
+__device__ __forceinline__ void chunk_taps_sel(int ry, int rx, const float* si, const float* sw,
+                                               f32x16 (&acc)[NT]) {
+  // wave-uniform dispatch to the statically unrolled variant
+  switch (ry * 4 + rx) {
+    case TAPS_01 * 4 + TAPS_01: chunk_taps<NT, OCB, TAPS_01, TAPS_01>(si, sw, acc); break;
+    case TAPS_01 * 4 + TAPS_12: chunk_taps<NT, OCB, TAPS_01, TAPS_12>(si, sw, acc); break;
+    case TAPS_12 * 4 + TAPS_01: chunk_taps<NT, OCB, TAPS_12, TAPS_01>(si, sw, acc); break;
+    case TAPS_12 * 4 + TAPS_12: chunk_taps<NT, OCB, TAPS_12, TAPS_12>(si, sw, acc); break;
+    case TAPS_01 * 4 + TAPS_1: chunk_taps<NT, OCB, TAPS_01, TAPS_1>(si, sw, acc); break;
+    case TAPS_1 * 4 + TAPS_01: chunk_taps<NT, OCB, TAPS_1, TAPS_01>(si, sw, acc); break;
+    case TAPS_1 * 4 + TAPS_1: chunk_taps<NT, OCB, TAPS_1, TAPS_1>(si, sw, acc); break;
+    case TAPS_12 * 4 + TAPS_1: chunk_taps<NT, OCB, TAPS_12, TAPS_1>(si, sw, acc); break;
+    case TAPS_1 * 4 + TAPS_12: chunk_taps<NT, OCB, TAPS_1, TAPS_12>(si, sw, acc); break;
+    default: chunk_taps<NT, OCB, TAPS_ALL, TAPS_ALL>(si, sw, acc); break;
+  }
+}
 
 // ABL: ablation bits for tools/conv_lab.hip only (0 in the product):
 //   1 = no re-staging inside the chunk loop, 2 = no barrier in the loop,
@@ -272,6 +335,11 @@ __global__ __launch_bounds__(WM* WN* KS * 64) void conv3x3_mfma_kernel(Conv3x3Ar
     const float* si = s_in + (buf * KS + wk) * IN_FLOATS + b_off;
     const float* sw = s_w + (buf * KS + wk) * W_FLOATS + a_off;
     if (KS == 1 || ch + wk < ch_end) {       // odd chunk count: the last pair has one member
+    if (a.tapsel) {
+      // phase of this chunk's input channels (1) or of this block's output channels (2)
+      const int ph = a.tapsel == 1 ? ((ch + wk) * CK) / a.cphase : (ocg * OCB) / a.cphase;
+      chunk_taps_sel<NT, OCB>(a.rowsets[(ph >> 1) & 1], a.rowsets[ph & 1], si, sw, acc);
+    } else {
     f32x4 bq[2], aq[2][NT];
     bq[0] = *reinterpret_cast<const f32x4*>(si);
 #pragma unroll
@@ -292,6 +360,7 @@ __global__ __launch_bounds__(WM* WN* KS * 64) void conv3x3_mfma_kernel(Conv3x3Ar
         for (int t = 0; t < NT; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[cur][t][kk], bq[cur][kk], acc[t], 0, 0, 0);
       }
+    }
     }
     }
     if constexpr (ABL & 16) {
@@ -581,7 +650,8 @@ static int conv3x3_impl(const float* x, int64_t x_nstride, int c1, const float* 
                         int64_t x2_nstride, const float* w_packed, int ocb, const float* bias,
                         const float* res, int64_t res_nstride, float* y, int64_t y_nstride, int n,
                         int cin, int cout, int h, int w, int act, int ksplit, float* partials,
-                        tg_stream_t stream, const float* mask = nullptr, int64_t mask_nstride = 0) {
+                        tg_stream_t stream, const float* mask = nullptr, int64_t mask_nstride = 0,
+                        int tapsel = 0, int cphase = 0, int set_p0 = 0, int set_p1 = 0) {
   TG_REQUIRE(x && w_packed && y, TG_E_ARG, "conv3x3_fwd: null pointer");
   TG_REQUIRE(!mask || ksplit <= 1, TG_E_ARG, "conv3x3_fwd: the ReLU mask is applied in the epilogue (no split-K)");
   TG_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, TG_E_SHAPE,
@@ -599,6 +669,14 @@ static int conv3x3_impl(const float* x, int64_t x_nstride, int c1, const float* 
   a.c1 = c1; a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
   a.ksplit = ksplit; a.part = partials; a.part_ss = (long long)n * cout * h * w;
   a.mask = mask; a.mask_ns = mask_nstride;
+  a.tapsel = tapsel; a.cphase = cphase; a.rowsets[0] = (unsigned char)set_p0; a.rowsets[1] = (unsigned char)set_p1;
+  if (tapsel) {
+    TG_REQUIRE((tapsel == 1 || tapsel == 2) && cphase > 0 && cphase % CK == 0 && set_p0 >= 0 && set_p0 <= 3 &&
+                   set_p1 >= 0 && set_p1 <= 3, TG_E_ARG, "conv3x3: tapsel=%d cphase=%d sets %d/%d", tapsel,
+               cphase, set_p0, set_p1);
+    TG_REQUIRE(tapsel == 1 ? cin == 4 * cphase : (cout == 4 * cphase && cphase % 64 == 0), TG_E_SHAPE,
+               "conv3x3: phased taps need 4 phases of %d channels (cin=%d cout=%d)", cphase, cin, cout);
+  }
   hipStream_t s = (hipStream_t)stream;
   if (ocb == 32) return launch_conv<4, 1, 1>(a, n, s);
   // 64 output channels per workgroup.  Small images get the 2-row tile so that
@@ -617,6 +695,16 @@ extern "C" int tg_conv3x3_fwd(const float* x, int64_t x_nstride, int c1, const f
                               int w, int act, tg_stream_t stream) {
   return conv3x3_impl(x, x_nstride, c1, x2, x2_nstride, w_packed, ocb, bias, res, res_nstride, y,
                       y_nstride, n, cin, cout, h, w, act, 1, nullptr, stream);
+}
+
+extern "C" int tg_conv3x3_fwd_phased(const float* x, int64_t x_nstride, const float* w_packed, int ocb,
+                                     const float* bias, float* y, int64_t y_nstride, int n, int cin,
+                                     int cout, int h, int w, int act, int tapsel, int cphase,
+                                     int taps_phase0, int taps_phase1, tg_stream_t stream) {
+  TG_REQUIRE(tapsel == 1 || tapsel == 2, TG_E_ARG, "conv3x3_fwd_phased: tapsel=%d (1 input | 2 output phases)", tapsel);
+  return conv3x3_impl(x, x_nstride, cin, nullptr, 0, w_packed, ocb, bias, nullptr, 0, y, y_nstride, n, cin,
+                      cout, h, w, act, 1, nullptr, stream, nullptr, 0, tapsel, cphase, taps_phase0,
+                      taps_phase1);
 }
 
 extern "C" int tg_conv3x3_fwd_masked(const float* x, int64_t x_nstride, int c1, const float* x2,

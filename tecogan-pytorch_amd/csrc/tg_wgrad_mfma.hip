@@ -44,9 +44,21 @@ struct WgradArgs {
   int ca, cb, cb_total, cb_off;   // G is written at columns [cb_off, cb_off+cb) of a cb_total-wide matrix
   int n, h, w;
   int tiles_x, tiles_y, ntiles, nsplit, nab, nbb;
+  // phase-restricted taps (see tg_conv3x3_mfma.hip): the b channels come in 4 sub-pixel phases
+  // of cphase channels; phase coordinate v along an axis uses tap set rowsets[v].  Taps outside
+  // the set are not computed (their gradient entries are written as 0; the embedding drops them).
+  int cphase;
+  unsigned char rowsets[2];
 };
 
-__global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) {
+enum { WTAPS_ALL = 0, WTAPS_01 = 1, WTAPS_12 = 2, WTAPS_1 = 3 };
+__host__ __device__ constexpr bool wtap_on(int code, int k) {
+  return code == WTAPS_ALL || (code == WTAPS_01 && k <= 1) || (code == WTAPS_12 && k >= 1) ||
+         (code == WTAPS_1 && k == 1);
+}
+
+template <int RY, int RX>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                          // [2][WG_A_FLOATS]
   float* sB = smem + 2 * WG_A_FLOATS;        // [2][WG_B_FLOATS]
@@ -154,10 +166,12 @@ __global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx)
+            if (wtap_on(RY, ky) && wtap_on(RX, kx)) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-              acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[ky][kk + kx],
-                                                                      acc[ky * 3 + kx], 0, 0, 0);
+              for (int kk = 0; kk < 4; ++kk)
+                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[ky][kk + kx],
+                                                                        acc[ky * 3 + kx], 0, 0, 0);
+            }
       }
     }
     if (more) store_tile(buf ^ 1);
@@ -177,6 +191,24 @@ __global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) {
         for (int t = 0; t < 9; ++t) o[t] = acc[t][r];
       }
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) {
+  if (a.cphase == 0) { wgrad_body<WTAPS_ALL, WTAPS_ALL>(a); return; }
+  // block-uniform: the 64 b channels of this block belong to one sub-pixel phase
+  const int bb = ((int)blockIdx.x / a.nsplit) % a.nbb;
+  const int ph = (bb * 64) / a.cphase;
+  const int ry = a.rowsets[(ph >> 1) & 1], rx = a.rowsets[ph & 1];
+  switch (ry * 4 + rx) {
+    case WTAPS_01 * 4 + WTAPS_01: wgrad_body<WTAPS_01, WTAPS_01>(a); break;
+    case WTAPS_01 * 4 + WTAPS_12: wgrad_body<WTAPS_01, WTAPS_12>(a); break;
+    case WTAPS_12 * 4 + WTAPS_01: wgrad_body<WTAPS_12, WTAPS_01>(a); break;
+    case WTAPS_12 * 4 + WTAPS_12: wgrad_body<WTAPS_12, WTAPS_12>(a); break;
+    case WTAPS_01 * 4 + WTAPS_1: wgrad_body<WTAPS_01, WTAPS_1>(a); break;
+    case WTAPS_1 * 4 + WTAPS_01: wgrad_body<WTAPS_1, WTAPS_01>(a); break;
+    case WTAPS_1 * 4 + WTAPS_1: wgrad_body<WTAPS_1, WTAPS_1>(a); break;
+    default: wgrad_body<WTAPS_ALL, WTAPS_ALL>(a); break;
   }
 }
 
@@ -239,7 +271,8 @@ extern "C" size_t tg_wgrad3x3_workspace_floats(int n, int ca, int cb_total, int 
 static int wgrad_launch(const float* const* p_list, const float* const* q_list, int nseg,
                         int64_t p_nstride, int64_t q_nstride, float* grad, float* workspace,
                         int n_per_seg, int ca, int cb, int cb_total, int cb_off, int h, int w,
-                        int accumulate, tg_stream_t stream) {
+                        int accumulate, tg_stream_t stream, int cphase = 0, int set_p0 = 0,
+                        int set_p1 = 0) {
   TG_REQUIRE(p_list && q_list && grad && workspace, TG_E_ARG, "wgrad3x3: null pointer");
   TG_REQUIRE(nseg >= 1 && nseg <= WG_MAXSEG, TG_E_ARG, "wgrad3x3: %d segments (1..%d)", nseg, WG_MAXSEG);
   TG_REQUIRE(n_per_seg > 0 && ca > 0 && cb > 0 && h > 0 && w > 0 && cb_off >= 0 &&
@@ -261,6 +294,13 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
   a.ntiles = n * a.tiles_x * a.tiles_y;
   a.nab = cdiv(ca, 64); a.nbb = cdiv(cb, 64);
   a.nsplit = wgrad_nsplit(n, h, w, ca, cb_total);   // same value the workspace was sized with
+  a.cphase = cphase; a.rowsets[0] = (unsigned char)set_p0; a.rowsets[1] = (unsigned char)set_p1;
+  if (cphase) {
+    TG_REQUIRE(cphase % 64 == 0 && cb == 4 * cphase && cb_off == 0 && set_p0 >= 0 && set_p0 <= 3 &&
+                   set_p1 >= 0 && set_p1 <= 3, TG_E_ARG,
+               "wgrad3x3: phased taps need cb = 4 phases of a multiple of 64 channels (cb=%d cphase=%d)", cb,
+               cphase);
+  }
   size_t lds = 2 * (size_t)(WG_A_FLOATS + WG_B_FLOATS) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -285,6 +325,16 @@ extern "C" int tg_wgrad3x3(const float* p, int64_t p_nstride, const float* q, in
   TG_REQUIRE(p && q, TG_E_ARG, "wgrad3x3: null pointer");
   return wgrad_launch(&p, &q, 1, p_nstride, q_nstride, grad, workspace, n, ca, cb, cb_total, cb_off, h,
                       w, accumulate, stream);
+}
+
+extern "C" int tg_wgrad3x3_multi_phased(const float* const* p_list, const float* const* q_list, int nseg,
+                                        int64_t p_nstride, int64_t q_nstride, float* grad,
+                                        float* workspace, int n_per_seg, int ca, int cb, int h, int w,
+                                        int accumulate, int cphase, int taps_phase0, int taps_phase1,
+                                        tg_stream_t stream) {
+  TG_REQUIRE(cphase > 0, TG_E_ARG, "wgrad3x3_multi_phased: cphase=%d", cphase);
+  return wgrad_launch(p_list, q_list, nseg, p_nstride, q_nstride, grad, workspace, n_per_seg, ca, cb,
+                      cb, 0, h, w, accumulate, stream, cphase, taps_phase0, taps_phase1);
 }
 
 extern "C" int tg_wgrad3x3_multi(const float* const* p_list, const float* const* q_list, int nseg,

@@ -58,9 +58,9 @@ class Tape:
     # are collected during the reverse sweep and reduced by ONE wgrad launch per layer
     # over the concatenated batch: 19x fewer launches / split-K reductions, and enough
     # pixel tiles per launch to fill the GPU.
-    def defer_wgrad(self, key, p, q, target, cb_off=0, post=None):
+    def defer_wgrad(self, key, p, q, target, cb_off=0, post=None, phased=None):
         ent = self.deferred.setdefault(key, {'p': [], 'q': [], 'target': target, 'cb_off': cb_off,
-                                             'post': post})
+                                             'post': post, 'phased': phased})
         ent['p'].append(p)
         ent['q'].append(q)
 
@@ -83,7 +83,12 @@ class Tape:
             else:
                 p0, q0 = ent['p'][0], ent['q'][0]
                 ge = torch.zeros(p0.shape[1], q0.shape[1], 3, 3, dtype=torch.float32, device=p0.device)
-                if multi:
+                phased = ent.get('phased')
+                if phased is not None and (phased[0] % 64 != 0 or not (same(ent['p']) and same(ent['q']))):
+                    phased = None                 # the kernel dispatches on 64-channel blocks
+                if phased is not None:            # skips the taps a sub-pixel phase does not own
+                    ops.wgrad3x3_multi(ent['p'], ent['q'], ge, accumulate=False, phased=phased)
+                elif multi:
                     ops.wgrad3x3_multi(ent['p'], ent['q'], ge, accumulate=False)
                 else:
                     P = p0 if len(ent['p']) == 1 else torch.cat(ent['p'], 0)
@@ -288,12 +293,15 @@ def convt3x3s2(tape, layer, x, act=RELU):
         dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
         s = ops.space_to_depth(dz, 2)                              # (n, 4co, h, w)
         we = _CACHE.get(layer, ('cte',), _ver(w), lambda: ops.pack_conv3x3(_convt_embed(w.detach())))
-        tape.add_grad(x, ops.conv3x3(s, we[0], None, 4 * co, ci, we[3], ksplit=1))
+        if co % 8 == 0:      # phase py = 1 owns tap rows {0, 1}, py = 0 only {1}: 9 of 36 taps are non-zero
+            tape.add_grad(x, ops.conv3x3_phased(s, we[0], 4 * co, ci, we[3], 1, co, ops.TAPS_1, ops.TAPS_01))
+        else:
+            tape.add_grad(x, ops.conv3x3(s, we[0], None, 4 * co, ci, we[3], ksplit=1))
         if w.requires_grad:
             def post(ge):                                          # G[ci][(ph,co)][ty][tx]
                 _, inv = _embed_index('convt', ci, co, ge.device)
                 ops.axpy_(_grad_buf(w), ge.reshape(-1).index_select(0, inv).view(ci, co, 3, 3), 1.0)
-            tape.defer_wgrad(('ct', id(layer)), x, s, None, 0, post)
+            tape.defer_wgrad(('ct', id(layer)), x, s, None, 0, post, phased=(co, ops.TAPS_1, ops.TAPS_01))
             tape.defer_bias(_grad_buf(b), dz)
     tape.record(bwd)
     return y
@@ -320,7 +328,12 @@ def conv4x4s2(tape, holder, x, need_dx=True):
     co, ci = w.shape[:2]
     s = ops.space_to_depth(x, 2)
     pk = _CACHE.get(holder, ('c4f',), _ver(w), lambda: ops.pack_conv3x3(_conv4_embed(w.detach())))
-    y = ops.conv3x3(s, pk[0], None, 4 * ci, co, pk[3])
+    # phase coordinate 1 owns tap rows {0, 1}, coordinate 0 rows {1, 2}: 4 of 9 taps per channel
+    sparse = ci % 8 == 0 and co > 32
+    if sparse:
+        y = ops.conv3x3_phased(s, pk[0], 4 * ci, co, pk[3], 1, ci, ops.TAPS_12, ops.TAPS_01)
+    else:
+        y = ops.conv3x3(s, pk[0], None, 4 * ci, co, pk[3])
     if tape is None:
         return y
 
@@ -332,11 +345,14 @@ def conv4x4s2(tape, holder, x, need_dx=True):
             def post(ge):
                 _, inv = _embed_index('conv4', co, ci, ge.device)
                 ops.axpy_(_grad_buf(w), ge.reshape(-1).index_select(0, inv).view(co, ci, 4, 4), 1.0)
-            tape.defer_wgrad(('c4', id(holder)), g, s, None, 0, post)
+            tape.defer_wgrad(('c4', id(holder)), g, s, None, 0, post, phased=(ci, ops.TAPS_12, ops.TAPS_01))
         if need_dx:
             pkd = _CACHE.get(holder, ('c4d',), _ver(w),
                              lambda: ops.pack_conv3x3_dgrad(_conv4_embed(w.detach())))
-            ds = ops.conv3x3(g, pkd[0], None, co, 4 * ci, pkd[3], ksplit=1)
+            if ci % 64 == 0:    # rot180 taps: coordinate 1 owns rows {1, 2}, coordinate 0 rows {0, 1}
+                ds = ops.conv3x3_phased(g, pkd[0], co, 4 * ci, pkd[3], 2, ci, ops.TAPS_01, ops.TAPS_12)
+            else:
+                ds = ops.conv3x3(g, pkd[0], None, co, 4 * ci, pkd[3], ksplit=1)
             tape.add_grad(x, ops.depth_to_space(ds, 2))
     tape.record(bwd)
     return y

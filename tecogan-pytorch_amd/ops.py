@@ -119,6 +119,25 @@ def conv3x3(x, wpk, bias, cin, cout, ocb, act=ACT_NONE, x2=None, res=None, out=N
     return out
 
 
+TAPS_ALL, TAPS_01, TAPS_12, TAPS_1 = 0, 1, 2, 3
+
+
+def conv3x3_phased(x, wpk, cin, cout, ocb, tapsel, cphase, taps_phase0, taps_phase1, out=None):
+    """conv3x3 (no bias / activation) of a space-to-depth embedded strided conv, skipping the
+    taps a sub-pixel phase does not own (include/tecogan_hip.h: tg_conv3x3_fwd_phased)."""
+    _chk(x, 'x')
+    n, c1, h, w = x.shape
+    if c1 != cin:
+        raise L.TecoganHipError(f'conv3x3_phased: x has {c1} channels, weights expect {cin}')
+    if out is None:
+        out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_conv3x3_fwd_phased(x.data_ptr(), cin * h * w, wpk.data_ptr(), ocb, None,
+                                          out.data_ptr(), cout * h * w, n, cin, cout, h, w, ACT_NONE,
+                                          int(tapsel), int(cphase), int(taps_phase0), int(taps_phase1),
+                                          _stream()), 'tg_conv3x3_fwd_phased')
+    return out
+
+
 def convt3x3s2(x, wpk, bias, cout, act=ACT_NONE, out=None):
     _chk(x, 'x')
     n, cin, h, w = x.shape
@@ -300,9 +319,11 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def wgrad3x3_multi(p_list, q_list, grad, cb_off=0, accumulate=True):
+def wgrad3x3_multi(p_list, q_list, grad, cb_off=0, accumulate=True, phased=None):
     """wgrad3x3 over the concatenation of equally shaped (p_i, q_i) pairs without concatenating
-    them: one launch reads up to MAX_SEGS separately allocated segments."""
+    them: one launch reads up to MAX_SEGS separately allocated segments.
+    phased = (cphase, taps_phase0, taps_phase1): q is a space-to-depth embedded tensor; only the
+    taps each sub-pixel phase owns are computed (tg_wgrad3x3_multi_phased)."""
     if len(p_list) != len(q_list) or not p_list:
         raise L.TecoganHipError('wgrad3x3_multi: empty or mismatched lists')
     for t in list(p_list) + list(q_list):
@@ -322,6 +343,15 @@ def wgrad3x3_multi(p_list, q_list, grad, cb_off=0, accumulate=True):
         ps, qs = p_list[i:i + MAX_SEGS], q_list[i:i + MAX_SEGS]
         nfl = lib.tg_wgrad3x3_workspace_floats(n * len(ps), ca, cb_total, h, w)
         ws = _wgrad_workspace(grad.device, nfl)
+        if phased is not None:
+            if cb_off or cb != cb_total:
+                raise L.TecoganHipError('wgrad3x3_multi: phased taps take the whole q tensor')
+            L.check(lib.tg_wgrad3x3_multi_phased(_ptr_array(ps), _ptr_array(qs), len(ps), ca * h * w,
+                                                 cb * h * w, grad.data_ptr(), ws.data_ptr(), n, ca, cb, h, w,
+                                                 1 if (accumulate or i > 0) else 0, int(phased[0]),
+                                                 int(phased[1]), int(phased[2]), _stream()),
+                    'tg_wgrad3x3_multi_phased')
+            continue
         L.check(lib.tg_wgrad3x3_multi(_ptr_array(ps), _ptr_array(qs), len(ps), ca * h * w, cb * h * w,
                                       grad.data_ptr(), ws.data_ptr(), n, ca, cb, cb_total, cb_off, h, w,
                                       1 if (accumulate or i > 0) else 0, _stream()), 'tg_wgrad3x3_multi')
