@@ -276,3 +276,61 @@ def test_conv_relu_mask_epilogue_and_fused_resblock_backward(ops):
                     c2.weight.grad.clone(), c2.bias.grad.clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('ci,co,hw', [(64, 64, 32), (64, 128, 16), (128, 256, 8)])
+def test_strided_conv_embeddings_with_phase_restricted_taps(ops, ci, co, hw):
+    """Conv2d(k4, s2, p1) forward / data gradient / weight gradient and the ConvTranspose2d
+    (k3, s2, p1, op1) data / weight gradients through their space-to-depth embeddings: the
+    phase-restricted-tap entry points (4/9 and 9/36 of the MFMAs) against torch autograd on the
+    strided ops themselves."""
+    import torch.nn.functional as F
+    from tecogan_pytorch_amd.models import train_graph as TG
+
+    class Holder(torch.nn.Module):
+        def __init__(self, w):
+            super().__init__()
+            self.weight = torch.nn.Parameter(w)
+
+    g = torch.Generator().manual_seed(ci + co)
+    x = torch.randn(3, ci, hw, hw, generator=g)
+    w4 = torch.randn(co, ci, 4, 4, generator=g) / (4 * ci ** 0.5)
+    xr = x.clone().requires_grad_(True)
+    wr = w4.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride=2, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    hold = Holder(w4.cuda())
+    tape = TG.Tape()
+    xd = x.cuda()
+    y = TG.conv4x4s2(tape, hold, xd)
+    def err(a, b):
+        return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+    assert err(y, yr) <= 2e-4 * max(1.0, yr.abs().max().item())
+    hold.weight.grad = torch.zeros_like(hold.weight)
+    tape.add_grad(y, gy.cuda())
+    tape.backward()
+    assert err(tape.grad(xd), xr.grad) <= 2e-4 * max(1.0, xr.grad.abs().max().item())
+    assert err(hold.weight.grad, wr.grad) <= 3e-4 * max(1.0, wr.grad.abs().max().item())
+
+    # transposed conv (SRNet.conv_up): forward is the sub-pixel kernel, backward the embedding
+    from tecogan_pytorch_amd.models.networks.tecogan_nets import _Conv
+    layer = _Conv(ci, 64, transposed=True).cuda()
+    xt = torch.randn(2, ci, hw, hw, generator=g)
+    xtr = xt.clone().requires_grad_(True)
+    wtr = layer.weight.detach().cpu().clone().requires_grad_(True)
+    btr = layer.bias.detach().cpu().clone().requires_grad_(True)
+    ytr = F.relu(F.conv_transpose2d(xtr, wtr, btr, stride=2, padding=1, output_padding=1))
+    gyt = torch.randn(ytr.shape, generator=g)
+    ytr.backward(gyt)
+    tape = TG.Tape()
+    xtd = xt.cuda()
+    yt = TG.convt3x3s2(tape, layer, xtd, TG.RELU)
+    assert err(yt, ytr) <= 2e-4
+    layer.weight.grad = torch.zeros_like(layer.weight)
+    layer.bias.grad = torch.zeros_like(layer.bias)
+    tape.add_grad(yt, gyt.cuda())
+    tape.backward()
+    assert err(tape.grad(xtd), xtr.grad) <= 2e-4 * max(1.0, xtr.grad.abs().max().item())
+    assert err(layer.weight.grad, wtr.grad) <= 3e-4 * max(1.0, wtr.grad.abs().max().item())
+    assert err(layer.bias.grad, btr.grad) <= 3e-4 * max(1.0, btr.grad.abs().max().item())
