@@ -14,6 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01b'
 rnd = sys.argv[2] if len(sys.argv) > 2 else 'r01'
+outdir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'profiles')     # the GPU box writes to gpurun_out/
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for i in (1, 2, 3, 4):
     path = os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}_{i}', 'pmc_counter_collection.csv')
@@ -25,7 +26,7 @@ for i in (1, 2, 3, 4):
         key = (r['Kernel_Name'].split('(')[0].replace('void ', ''), r['Grid_Size'])
         agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
 names = sorted({c for d in agg.values() for c in d})
-out = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_summary.csv')
+out = os.path.join(outdir, f'{rnd}_pmc_summary.csv')
 with open(out, 'w', newline='') as f:
     w = csv.writer(f)
     w.writerow(['kernel', 'grid', 'dispatches'] + names)
@@ -41,5 +42,5 @@ for (k, g), d in agg.items():
         t[0] += (sum(d['FETCH_SIZE']) / n + sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE'])) * 1024 * n
         t[1] += n
 json.dump({k: v[0] / v[1] for k, v in traffic.items()},
-          open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)
+          open(os.path.join(outdir, 'pmc_traffic.json'), 'w'), indent=1)
 print('wrote', out, 'and profiles/pmc_traffic.json')
