@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $REPO/bench.py --steps 6 --warmup 2 --no-roofline --no-pipeline --no-secondary --cpu-frames 0 --aten-frames 0"
+CMD="python $REPO/bench.py --steps 6 --warmup 2 --clips 1 --no-roofline --no-pipeline --no-secondary --no-train-leg --cpu-frames 0 --aten-frames 0"
 i=0
 for PMC in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAVES" \
            "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_LDS_UNALIGNED_STALL" \
