@@ -138,6 +138,24 @@ int tg_convt3x3s2_fwd(const float* x, int64_t x_nstride, const float* w_packed,
                       const float* bias, float* y, int64_t y_nstride, int n,
                       int cin, int cout, int h, int w, int act,
                       tg_stream_t stream);
+/* The HR stage without the 64-channel HR tensor (inference; SRNet.forward tecogan_nets.py:119-131,
+ * 145): the LAST ConvTranspose2d + ReLU, run in "Z mode", contracts its output over the channels
+ * with conv_out's weights while the values are still in the MFMA accumulators and stores the
+ * 9*cz tap planes  z[tap*cz + o] = sum_oc Wout[o][oc][tap] * relu(convT(x)[oc] + b[oc])
+ * (cz = out_nc <= 3; z is (n, 32, 2h, 2w), the first 9*cz planes written); tg_convout_tail
+ * shift-adds them (zero padding of conv_out), adds conv_out's bias and upsample_func(lr_curr),
+ * and optionally emits the uint8 HWC frame.  Same result as tg_convt3x3s2_fwd +
+ * tg_conv3x3_small_fwd(_u8) up to summation order; 74 MB written + read instead of 176 MB.
+ * tg_convt_pack_wz packs conv_out's OIHW weights (cz, nf, 3, 3) into the 2048-float operand. */
+int tg_convt_pack_wz(const float* w_out_oihw, float* wz, int cz, int nf, tg_stream_t stream);
+int tg_convt3x3s2_z_fwd(const float* x, int64_t x_nstride, const float* w_packed,
+                        const float* bias, const float* wz, int cz, float* z,
+                        int64_t z_nstride, int n, int cin, int cout, int h, int w, int act,
+                        tg_stream_t stream);
+int tg_convout_tail(const float* z, int64_t z_nstride, int cz, const float* bias,
+                    const float* up_src, int up_mode, int up_scale, float* y,
+                    int64_t y_nstride, uint8_t* u8_out, int n, int h, int w,
+                    tg_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 3x3 conv with a tiny output-channel count (cout <= 4), direct fp32 VALU

@@ -27,6 +27,8 @@ struct tg_frnet_plan {
   std::vector<tg_layer_weights> L;
   float *A, *B, *FLOW, *S2D, *U1, *U2, *PART;
   float *FA, *FB, *FPART, *FLOW2;   // FNet's own buffers (phase 1 may overlap phase 2 of the previous frame)
+  float* WZ;                        // packed output-conv weights for the fused HR stage
+  bool wz_ready;
   int fh, fw, launches;
   int st_launch[16];
   double st_flops[16], st_bytes[16];
@@ -59,7 +61,7 @@ static size_t fnet_partial_floats(const tg_frnet_cfg* c) {
   return best;
 }
 
-static void carve(const tg_frnet_cfg* c, size_t off[12]) {
+static void carve(const tg_frnet_cfg* c, size_t off[13]) {
   size_t hw = (size_t)c->h * c->w, n = c->n;
   size_t o = 0;
   const size_t sr = c->fnet_only ? 0 : 1;                      // an FNet-only plan has no SRNet regions
@@ -74,7 +76,8 @@ static void carve(const tg_frnet_cfg* c, size_t off[12]) {
   off[8] = o; o += align64(n * 64 * hw);                       // FB   (FNet pong)
   off[9] = o; o += align64(fnet_partial_floats(c));            // FPART (split-K partial sums, FNet)
   off[10] = o; o += align64(n * 2 * hw);                       // FLOW2 (second flow slot)
-  off[11] = o;
+  off[11] = o; o += sr * 2048;                                 // WZ (A operand of the fused output-conv contraction)
+  off[12] = o;
 }
 
 static int cfg_ok(const tg_frnet_cfg* c) {
@@ -86,9 +89,9 @@ static int cfg_ok(const tg_frnet_cfg* c) {
 
 extern "C" size_t tg_frnet_workspace_floats(const tg_frnet_cfg* cfg) {
   if (!cfg_ok(cfg)) return 0;
-  size_t off[12];
+  size_t off[13];
   carve(cfg, off);
-  return off[11];
+  return off[12];
 }
 
 extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weights* layers,
@@ -106,8 +109,9 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   TG_REQUIRE(p, TG_E_ARG, "frnet_plan_create: out of host memory");
   p->cfg = *cfg;
   p->L.assign(layers, layers + n_layers);
-  size_t off[12];
+  size_t off[13];
   carve(cfg, off);
+  p->WZ = workspace + off[11]; p->wz_ready = false;
   p->FA = workspace + off[7]; p->FB = workspace + off[8]; p->FPART = workspace + off[9];
   p->FLOW2 = workspace + off[10];
   p->PART = workspace + off[6];
@@ -143,8 +147,18 @@ enum {
   K_QUANT = 8,
   K_FINAL = 9,      // splitk_finalize_kernel
   K_CONV64_KS = 10, // conv3x3_mfma_kernel<1,2,1,...,2>: in-workgroup K split (few tiles)
-  K_COUNT = 11
+  K_CONVT_Z = 11,   // convt3x3s2_mfma_kernel<4,2,true>: last up-sampling layer + output-conv contraction
+  K_TAIL = 12,      // convout_tail_kernel: 9-tap shift-add + residual + uint8
+  K_COUNT = 13
 };
+
+// The HR stage as two launches instead of three and without the 64-channel HR tensor: the last
+// ConvTranspose2d emits the 27 tap planes of conv_out (tecogan_nets.py:119-131), a streaming
+// kernel shift-adds them.  TG_HR_FUSE=0 selects the unfused launches (lab / A-B).
+static bool hr_fuse_enabled() {
+  static const int v = [] { const char* e = getenv("TG_HR_FUSE"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
 
 static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
                      const float* hr_prev, float* hr_out, uint8_t* u8_out, tg_stream_t st,
@@ -268,32 +282,62 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     conv(A, nf * hw, nf, nullptr, 0, nf, nf, h, w, TG_ACT_RELU, nullptr, 0, B, nf * hw);
     conv(B, nf * hw, nf, nullptr, 0, nf, nf, h, w, TG_ACT_NONE, A, nf * hw, A, nf * hw);
   }
+  const bool fuse = hr_fuse_enabled() && c.out_nc <= 3 && nf <= 64;
+  const tg_layer_weights lw_up1 = p->L[li++];
+  const tg_layer_weights lw_up2 = s == 4 ? p->L[li++] : tg_layer_weights{nullptr, nullptr};
+  const tg_layer_weights lw_out = p->L[li++];
+  const double hpx = (double)n * s * s * hw;
+  if (fuse) {
+    // WZ is derived from conv_out's weights once per plan (plans are rebuilt when weights change)
+    if (!dry && !p->wz_ready && (phases & 2)) {
+      rc = tg_convt_pack_wz(lw_out.w, p->WZ, c.out_nc, nf, st);
+      p->wz_ready = rc == TG_OK;
+    }
+    float* zbuf = s == 4 ? p->U2 : p->U1;          // the 64-channel tensor is never written: its space holds the planes
+    const int zh = s * h / 2, zw = s * w / 2;      // input size of the last up-sampling layer
+    const float* zin = A;
+    if (s == 4) {
+      float* ai = A;
+      go(K_CONVT, 2.0 * nf * 9 * nf * n * hw, 4.0 * n * hw * nf * 5.0, [&] {
+        return tg_convt3x3s2_fwd(ai, nf * hw, lw_up1.w, lw_up1.b, p->U1, nf * 4 * hw, n, nf, nf, h, w,
+                                 TG_ACT_RELU, st);
+      });
+      zin = p->U1;
+    }
+    const tg_layer_weights lw_last = s == 4 ? lw_up2 : lw_up1;
+    go(K_CONVT_Z, 2.0 * nf * 9 * nf * n * zh * zw + 2.0 * nf * 9 * c.out_nc * hpx,
+       4.0 * n * zh * zw * nf + 4.0 * hpx * 9 * c.out_nc, [&] {
+         return tg_convt3x3s2_z_fwd(zin, (int64_t)nf * zh * zw, lw_last.w, lw_last.b, p->WZ, c.out_nc, zbuf,
+                                    (int64_t)32 * s * s * hw, n, nf, nf, zh, zw, TG_ACT_RELU, st);
+       });
+    go(K_TAIL, 0, 4.0 * hpx * (9 * c.out_nc + c.out_nc), [&] {
+      return tg_convout_tail(zbuf, (int64_t)32 * s * s * hw, c.out_nc, lw_out.b, lr_curr, c.up_mode, s, hr_out,
+                             (int64_t)c.out_nc * s * s * hw, n == 1 ? u8_out : nullptr, n, s * h, s * w, st);
+    });
+    return rc;
+  }
   {
-    const tg_layer_weights lw = p->L[li++];
     float* ai = A;
     go(K_CONVT, 2.0 * nf * 9 * nf * n * hw, 4.0 * n * hw * nf * 5.0, [&] {
-      return tg_convt3x3s2_fwd(ai, nf * hw, lw.w, lw.b, p->U1, nf * 4 * hw, n, nf, nf, h, w,
+      return tg_convt3x3s2_fwd(ai, nf * hw, lw_up1.w, lw_up1.b, p->U1, nf * 4 * hw, n, nf, nf, h, w,
                                TG_ACT_RELU, st);
     });
   }
   const float* top = p->U1;
   if (s == 4) {
-    const tg_layer_weights lw = p->L[li++];
     go(K_CONVT, 2.0 * nf * 9 * nf * n * 4 * hw, 4.0 * n * 4 * hw * nf * 5.0, [&] {
-      return tg_convt3x3s2_fwd(p->U1, nf * 4 * hw, lw.w, lw.b, p->U2, nf * 16 * hw, n, nf, nf,
+      return tg_convt3x3s2_fwd(p->U1, nf * 4 * hw, lw_up2.w, lw_up2.b, p->U2, nf * 16 * hw, n, nf, nf,
                                2 * h, 2 * w, TG_ACT_RELU, st);
     });
     top = p->U2;
   }
   bool u8_fused = false;
   {
-    const tg_layer_weights lw = p->L[li++];
-    double hpx = (double)n * s * s * hw;
     u8_fused = !dry && u8_out &&
                tg_conv3x3_small_can_fuse_u8(top, (int64_t)nf * s * s * hw, hr_out,
                                             (int64_t)c.out_nc * s * s * hw, n, nf, s * h, s * w);
     go(K_SMALL, 2.0 * nf * 9 * c.out_nc * hpx, 4.0 * hpx * (nf + c.out_nc), [&] {
-      return tg_conv3x3_small_fwd_u8(top, (int64_t)nf * s * s * hw, lw.w, lw.b, lr_curr, c.up_mode, s,
+      return tg_conv3x3_small_fwd_u8(top, (int64_t)nf * s * s * hw, lw_out.w, lw_out.b, lr_curr, c.up_mode, s,
                                      hr_out, (int64_t)c.out_nc * s * s * hw, u8_fused ? u8_out : nullptr,
                                      n, nf, c.out_nc, s * h, s * w, TG_ACT_NONE, st);
     });
@@ -370,7 +414,8 @@ extern "C" const char* tg_frnet_kind_name(int kind) {
       "conv3x3_mfma_kernel<2,2,1>", "conv3x3_mfma_kernel<4,1,2>", "conv3x3_mfma_kernel<4,1,1>",
       "convt3x3s2_mfma_kernel<4,2>", "conv3x3_small_kernel",       "flowup_warp_s2d_kernel",
       "maxpool2_kernel",             "upsample_kernel",            "quantize_u8_hwc_kernel",
-      "splitk_finalize_kernel",      "conv3x3_mfma_kernel<1,2,1,KS=2>"};
+      "splitk_finalize_kernel",      "conv3x3_mfma_kernel<1,2,1,KS=2>",
+      "convt3x3s2_mfma_kernel<4,2,Z>", "convout_tail_kernel"};
   return (kind >= 0 && kind < K_COUNT) ? names[kind] : "?";
 }
 

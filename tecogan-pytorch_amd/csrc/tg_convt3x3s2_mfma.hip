@@ -35,9 +35,17 @@ struct ConvTArgs {
   long long x_ns, y_ns;
   int cin, cout, h, w, act;
   int tiles_x, tiles_y, nchunk, nocg;
+  // Z mode (the LAST up-sampling layer of SRNet, inference): instead of the 64-channel HR
+  // tensor the kernel emits the 9*cz "tap planes" of the following 3x3 output conv,
+  //   z[tap*cz + o][Y][X] = sum_oc  Wout[o][oc][tap] * act(convT(x)[oc][Y][X] + bias[oc]),
+  // i.e. the output conv's channel contraction done where the operand already sits in registers.
+  const float* wz;     // [2 oc-halves][16 steps][64 lanes] A operand of the 1x1 contraction
+  float* z;            // (n, 32, 2h, 2w) planes; the first zrows are written
+  long long z_ns;
+  int zrows;           // 9 * cz <= 32
 };
 
-template <int WM, int WN>
+template <int WM, int WN, bool ZMODE = false>
 __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs a) {
   static_assert(WN * 32 == TOCB, "WN waves x 32 oc must cover the 64-oc block");
   constexpr int NTHREADS = WM * WN * 64;
@@ -168,6 +176,58 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
     int oc = ocb0 + (r & 3) + 8 * (r >> 2);
     bv[r] = a.bias ? a.bias[oc < a.cout ? oc : a.cout - 1] : 0.f;
   }
+  if constexpr (ZMODE) {
+    // The accumulator layout IS the B operand of the contraction over oc: register r of lane l
+    // holds channel wn*32 + (r&3) + 8*(r>>2) + 4*(l>>5) of pixel column l&31, i.e. MFMA step r
+    // consumes the channel pair (c_r, c_r + 4).  The A operand (32 tap-plane rows x that pair)
+    // was packed in exactly this order (tg_convt_pack_wz).  16 MFMAs per phase and wave; the two
+    // oc-half waves of a row are summed through LDS (staging buffers are dead: the K loop ended
+    // on a barrier), the wn == 0 wave stores the planes.
+    float az[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) az[r] = a.wz[(wn * 16 + r) * 64 + lane];
+    float* red = smem;                          // [2 phases][WM][16][64]
+    const bool inimg = px < a.w && py < a.h;
+    const int ow = 2 * a.w;
+    const long long ohw = 4ll * hw;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {            // phase pairs (py = pp; px = 0, 1)
+      f32x16 z[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[q][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float t = acc[pp * 2 + q][r] + bv[r];
+          t = t >= 0.f ? t : t * slope + 0.f;
+          z[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(az[r], t, z[q], 0, 0, 0);
+        }
+      }
+      if (wn == 1) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((q * WM + wm) * 16 + r) * 64 + lane] = z[q][r];
+      }
+      __syncthreads();
+      if (wn == 0 && inimg) {
+        float* zb = a.z + (long long)n * a.z_ns + (long long)(2 * py + pp) * ow + 2 * px;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < a.zrows) {
+            float2 v;
+            v.x = z[0][r] + red[((0 * WM + wm) * 16 + r) * 64 + lane];
+            v.y = z[1][r] + red[((1 * WM + wm) * 16 + r) * 64 + lane];
+            *reinterpret_cast<float2*>(zb + (long long)m * ohw) = v;
+          }
+        }
+      }
+      if (pp == 0) __syncthreads();             // the second pair re-uses the reduction buffer
+    }
+    return;
+  }
   if (px < a.w && py < a.h) {
     const int ow = 2 * a.w;
     const long long ohw = 4ll * hw;
@@ -187,6 +247,110 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
         *reinterpret_cast<float2*>(yo) = v0;
         *reinterpret_cast<float2*>(yo + ow) = v1;
       }
+    }
+  }
+}
+
+// A operand of the Z-mode contraction: wz[(half*16 + r)*64 + l] = Wout[o][c][tap] for tap-plane
+// row m = l & 31 (m = tap*cz + o < 9*cz, else 0) and channel c = half*32 + (r&3) + 8*(r>>2) +
+// 4*(l>>5) (< nf, else 0).  Wout is the output conv's OIHW weight (cz, nf, 3, 3).
+__global__ void convt_pack_wz_kernel(const float* __restrict__ wout, float* __restrict__ wz, int cz,
+                                     int nf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * 16 * 64) return;
+  const int l = i & 63, r = (i >> 6) & 15, half = i >> 10;
+  const int m = l & 31, c = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+  float v = 0.f;
+  if (m < 9 * cz && c < nf) {
+    const int tap = m / cz, o = m - tap * cz;
+    v = wout[((long long)o * nf + c) * 9 + tap];
+  }
+  wz[i] = v;
+}
+
+// out[o][Y][X] = bias[o] + sum_tap z[tap*cz + o][Y + ky - 1][X + kx - 1]  (zero outside the image:
+// the output conv's zero padding) + upsample_func(lr_curr) (tecogan_nets.py:145), and the uint8
+// HWC frame (data_utils.py:80-87).  One thread per HR pixel; every z element is read once.
+template <int CZ>
+__global__ __launch_bounds__(256) void convout_tail_kernel(const float* __restrict__ z, long long z_ns,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ up, int up_mode,
+                                                           int up_scale, float* __restrict__ y,
+                                                           long long y_ns, uint8_t* __restrict__ u8,
+                                                           int n, int h, int w) {
+  const int X = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (X >= w || Y >= h) return;
+  const long long hw = (long long)h * w;
+  const float* zb = z + (long long)b * z_ns;
+  float v[CZ];
+#pragma unroll
+  for (int o = 0; o < CZ; ++o) v[o] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = Y + ky - 1;
+    if (yy < 0 || yy >= h) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xx = X + kx - 1;
+      if (xx < 0 || xx >= w) continue;
+      const float* p = zb + (long long)((ky * 3 + kx) * CZ) * hw + (long long)yy * w + xx;
+#pragma unroll
+      for (int o = 0; o < CZ; ++o) v[o] += p[(long long)o * hw];
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < CZ; ++o) v[o] += bias ? bias[o] : 0.f;
+  if (up) {
+    const int lh = h / up_scale, lw = w / up_scale;
+    const float* src = up + (long long)b * CZ * lh * lw;
+    if (up_mode == TG_UP_BICUBIC) {
+      const int i = Y / up_scale, dy = Y - i * up_scale, j = X / up_scale, dx = X - j * up_scale;
+      float kyw[4], kxw[4];
+      bicubic_w(dy, up_scale, kyw);
+      bicubic_w(dx, up_scale, kxw);
+      int ri[4], ci[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        int r = i - 1 + p; ri[p] = r < 0 ? 0 : (r > lh - 1 ? lh - 1 : r);
+        int c = j - 1 + p; ci[p] = c < 0 ? 0 : (c > lw - 1 ? lw - 1 : c);
+      }
+#pragma unroll
+      for (int o = 0; o < CZ; ++o) {
+        const float* s = src + (long long)o * lh * lw;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float vq = 0.f;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) vq += kyw[p] * s[ri[p] * lw + ci[q]];
+          acc += kxw[q] * vq;
+        }
+        v[o] += acc;
+      }
+    } else {
+      int y0, y1, x0, x1;
+      float ly0, ly1, lx0, lx1;
+      bilinear_src(Y, up_scale, lh, y0, y1, ly0, ly1);
+      bilinear_src(X, up_scale, lw, x0, x1, lx0, lx1);
+#pragma unroll
+      for (int o = 0; o < CZ; ++o) {
+        const float* s = src + (long long)o * lh * lw;
+        float top = lx0 * s[y0 * lw + x0] + lx1 * s[y0 * lw + x1];
+        float bot = lx0 * s[y1 * lw + x0] + lx1 * s[y1 * lw + x1];
+        v[o] += ly0 * top + ly1 * bot;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < CZ; ++o) y[(long long)b * y_ns + (long long)o * hw + (long long)Y * w + X] = v[o];
+  if (u8) {
+#pragma unroll
+    for (int o = 0; o < CZ; ++o) {
+      float r = rintf(v[o] * 255.0f);
+      r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
+      u8[((long long)Y * w + X) * CZ + o] = (uint8_t)r;
     }
   }
 }
@@ -221,4 +385,55 @@ extern "C" int tg_convt3x3s2_fwd(const float* x, int64_t x_nstride, const float*
   hipLaunchKernelGGL((convt3x3s2_mfma_kernel<WM, WN>), dim3((unsigned)blocks),
                      dim3(WM * WN * 64), lds, (hipStream_t)stream, a);
   return check_launch("convt3x3s2_mfma");
+}
+
+extern "C" int tg_convt_pack_wz(const float* w_out_oihw, float* wz, int cz, int nf, tg_stream_t stream) {
+  TG_REQUIRE(w_out_oihw && wz, TG_E_ARG, "convt_pack_wz: null pointer");
+  TG_REQUIRE(cz >= 1 && 9 * cz <= 32 && nf >= 1 && nf <= 64, TG_E_SHAPE, "convt_pack_wz: cz=%d (<=3) nf=%d (<=64)", cz, nf);
+  hipLaunchKernelGGL(convt_pack_wz_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, w_out_oihw, wz, cz, nf);
+  return check_launch("convt_pack_wz");
+}
+
+extern "C" int tg_convt3x3s2_z_fwd(const float* x, int64_t x_nstride, const float* w_packed,
+                                   const float* bias, const float* wz, int cz, float* z,
+                                   int64_t z_nstride, int n, int cin, int cout, int h, int w, int act,
+                                   tg_stream_t stream) {
+  TG_REQUIRE(x && w_packed && wz && z, TG_E_ARG, "convt3x3s2_z_fwd: null pointer");
+  TG_REQUIRE(n > 0 && cin > 0 && cout > 0 && cout <= 64 && h > 0 && w > 0 && cz >= 1 && 9 * cz <= 32,
+             TG_E_SHAPE, "convt3x3s2_z_fwd: n=%d cin=%d cout=%d (<=64) h=%d w=%d cz=%d (<=3)", n, cin, cout, h, w, cz);
+  TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_LRELU02, TG_E_ARG, "convt_z: act=%d", act);
+  TG_REQUIRE((z_nstride % 2) == 0 && ((uintptr_t)z % 8) == 0, TG_E_ARG, "convt3x3s2_z_fwd: z must be 8-byte aligned");
+  TG_REQUIRE((long long)(cin + CK) * h * w * 4 < (1ll << 31), TG_E_SHAPE, "convt3x3s2_z_fwd: one batch item must be < 2 GiB");
+  ConvTArgs a{};
+  a.x = x; a.wpk = w_packed; a.bias = bias; a.y = nullptr; a.x_ns = x_nstride; a.y_ns = 0;
+  a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
+  a.wz = wz; a.z = z; a.z_ns = z_nstride; a.zrows = 9 * cz;
+  constexpr int WM = 4, WN = 2;
+  a.tiles_x = cdiv(w, TTW); a.tiles_y = cdiv(h, WM); a.nocg = 1; a.nchunk = cdiv(cin, CK);
+  size_t lds = 2 * (size_t)((WM + 1) * 2 * TRS * 4 + 9 * CK * TOCB) * sizeof(float);   // >= 2*WM*16*64*4 B
+  long long blocks = (long long)a.tiles_x * a.tiles_y * n;
+  TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "convt_z: grid %lld", blocks);
+  hipLaunchKernelGGL((convt3x3s2_mfma_kernel<WM, WN, true>), dim3((unsigned)blocks), dim3(WM * WN * 64), lds,
+                     (hipStream_t)stream, a);
+  return check_launch("convt3x3s2_z");
+}
+
+extern "C" int tg_convout_tail(const float* z, int64_t z_nstride, int cz, const float* bias,
+                               const float* up_src, int up_mode, int up_scale, float* y,
+                               int64_t y_nstride, uint8_t* u8_out, int n, int h, int w,
+                               tg_stream_t stream) {
+  TG_REQUIRE(z && y, TG_E_ARG, "convout_tail: null pointer");
+  TG_REQUIRE(n > 0 && h > 0 && w > 0 && cz >= 1 && cz <= 3, TG_E_SHAPE, "convout_tail: n=%d h=%d w=%d cz=%d", n, h, w, cz);
+  TG_REQUIRE(!u8_out || n == 1, TG_E_ARG, "convout_tail: u8 output needs n == 1");
+  if (up_src)
+    TG_REQUIRE((up_mode == TG_UP_BICUBIC || up_mode == TG_UP_BILINEAR) && up_scale >= 1 && h % up_scale == 0 &&
+                   w % up_scale == 0, TG_E_SHAPE, "convout_tail: up_mode=%d up_scale=%d", up_mode, up_scale);
+  dim3 g(cdiv(w, 64), cdiv(h, 4), n), t(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (cz) {
+    case 1: hipLaunchKernelGGL(convout_tail_kernel<1>, g, t, 0, s, z, (long long)z_nstride, bias, up_src, up_mode, up_scale, y, (long long)y_nstride, u8_out, n, h, w); break;
+    case 2: hipLaunchKernelGGL(convout_tail_kernel<2>, g, t, 0, s, z, (long long)z_nstride, bias, up_src, up_mode, up_scale, y, (long long)y_nstride, u8_out, n, h, w); break;
+    default: hipLaunchKernelGGL(convout_tail_kernel<3>, g, t, 0, s, z, (long long)z_nstride, bias, up_src, up_mode, up_scale, y, (long long)y_nstride, u8_out, n, h, w); break;
+  }
+  return check_launch("convout_tail");
 }
