@@ -18,6 +18,7 @@
 //
 // Replaces SRNet.conv_up (codes/models/networks/tecogan_nets.py:119-126).
 #include "tg_common.h"
+#include <cstdlib>
 
 namespace tg {
 
@@ -374,16 +375,26 @@ extern "C" int tg_convt3x3s2_fwd(const float* x, int64_t x_nstride, const float*
   ConvTArgs a{};
   a.x = x; a.wpk = w_packed; a.bias = bias; a.y = y; a.x_ns = x_nstride; a.y_ns = y_nstride;
   a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
-  constexpr int WM = 4, WN = 2;
+  constexpr int WN = 2;
   a.tiles_x = cdiv(w, TTW);
-  a.tiles_y = cdiv(h, WM);
   a.nocg = cdiv(cout, TOCB);
   a.nchunk = cdiv(cin, CK);
-  size_t lds = 2 * (size_t)((WM + 1) * 2 * TRS * 4 + 9 * CK * TOCB) * sizeof(float);
+  // 4-row workgroups (8 waves) unless that leaves fewer than two workgroups per CU: a 134x320
+  // input is 340 of them = 1.33 per CU (the CUs with two finish last: 66 % balance); 2-row
+  // workgroups (670 = 2.62 per CU, 87 %) take the small frames.  TG_CONVT_ROWS overrides (lab).
+  static const int rows_env = [] { const char* e = getenv("TG_CONVT_ROWS"); return e ? atoi(e) : 0; }();
+  const long long wg4 = (long long)a.tiles_x * cdiv(h, 4) * a.nocg * n;
+  const int rows = rows_env == 2 || rows_env == 4 ? rows_env : (wg4 < 512 ? 2 : 4);
+  a.tiles_y = cdiv(h, rows);
+  size_t lds = 2 * (size_t)((rows + 1) * 2 * TRS * 4 + 9 * CK * TOCB) * sizeof(float);
   long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "convt: grid %lld", blocks);
-  hipLaunchKernelGGL((convt3x3s2_mfma_kernel<WM, WN>), dim3((unsigned)blocks),
-                     dim3(WM * WN * 64), lds, (hipStream_t)stream, a);
+  if (rows == 2)
+    hipLaunchKernelGGL((convt3x3s2_mfma_kernel<2, WN>), dim3((unsigned)blocks), dim3(2 * WN * 64), lds,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((convt3x3s2_mfma_kernel<4, WN>), dim3((unsigned)blocks), dim3(4 * WN * 64), lds,
+                       (hipStream_t)stream, a);
   return check_launch("convt3x3s2_mfma");
 }
 
