@@ -419,13 +419,23 @@ extern "C" int tg_convt3x3s2_z_fwd(const float* x, int64_t x_nstride, const floa
   a.x = x; a.wpk = w_packed; a.bias = bias; a.y = nullptr; a.x_ns = x_nstride; a.y_ns = 0;
   a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
   a.wz = wz; a.z = z; a.z_ns = z_nstride; a.zrows = 9 * cz;
-  constexpr int WM = 4, WN = 2;
-  a.tiles_x = cdiv(w, TTW); a.tiles_y = cdiv(h, WM); a.nocg = 1; a.nchunk = cdiv(cin, CK);
-  size_t lds = 2 * (size_t)((WM + 1) * 2 * TRS * 4 + 9 * CK * TOCB) * sizeof(float);   // >= 2*WM*16*64*4 B
+  constexpr int WN = 2;
+  static const int rows_env = [] { const char* e = getenv("TG_CONVTZ_ROWS"); return e ? atoi(e) : 0; }();
+  a.tiles_x = cdiv(w, TTW); a.nocg = 1; a.nchunk = cdiv(cin, CK);
+  // same balance rule as tg_convt3x3s2_fwd (at 268x640, 1340 four-row workgroups, the two-row form
+  // measured 153 vs 148 us: more workgroups than slots are balanced by the dispatcher anyway)
+  const long long wg4 = (long long)a.tiles_x * cdiv(h, 4) * n;
+  const int rows = rows_env == 2 || rows_env == 4 ? rows_env : (wg4 < 512 ? 2 : 4);
+  a.tiles_y = cdiv(h, rows);
+  size_t lds = 2 * (size_t)((rows + 1) * 2 * TRS * 4 + 9 * CK * TOCB) * sizeof(float);   // >= 2*rows*16*64*4 B
   long long blocks = (long long)a.tiles_x * a.tiles_y * n;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "convt_z: grid %lld", blocks);
-  hipLaunchKernelGGL((convt3x3s2_mfma_kernel<WM, WN, true>), dim3((unsigned)blocks), dim3(WM * WN * 64), lds,
-                     (hipStream_t)stream, a);
+  if (rows == 2)
+    hipLaunchKernelGGL((convt3x3s2_mfma_kernel<2, WN, true>), dim3((unsigned)blocks), dim3(2 * WN * 64), lds,
+                       (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((convt3x3s2_mfma_kernel<4, WN, true>), dim3((unsigned)blocks), dim3(4 * WN * 64), lds,
+                       (hipStream_t)stream, a);
   return check_launch("convt3x3s2_z");
 }
 
