@@ -443,7 +443,8 @@ int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weights* layers
                          int n_layers, float* workspace, tg_frnet_plan** out);
 void tg_frnet_plan_destroy(tg_frnet_plan* plan);
 /* hr_out may alias nothing else; lr_curr/lr_prev (n,c,h,w), hr_prev/hr_out (n,c,s*h,s*w).
- * u8_out (optional, n==1 only): (s*h, s*w, c) uint8 quantised frame. */
+ * u8_out (optional): (n, s*h, s*w, c) uint8 quantised frames (n > 1 needs the fused HR stage:
+ * out_nc <= 3, nf <= 64). */
 int tg_frnet_step(tg_frnet_plan* plan, const float* lr_curr, const float* lr_prev,
                   const float* hr_prev, float* hr_out, uint8_t* u8_out,
                   tg_stream_t stream);

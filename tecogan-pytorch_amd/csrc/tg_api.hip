@@ -159,6 +159,10 @@ static bool hr_fuse_enabled() {
   static const int v = [] { const char* e = getenv("TG_HR_FUSE"); return e ? atoi(e) : 1; }();
   return v != 0;
 }
+// the fused tail writes (n, H, W, c) uint8 frames for any n; the unfused quantise pass only n == 1
+static bool plan_u8_ok(const tg_frnet_plan* p) {
+  return p->cfg.n == 1 || (hr_fuse_enabled() && p->cfg.out_nc <= 3 && p->cfg.nf <= 64);
+}
 
 static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_prev,
                      const float* hr_prev, float* hr_out, uint8_t* u8_out, tg_stream_t st,
@@ -312,7 +316,7 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
        });
     go(K_TAIL, 0, 4.0 * hpx * (9 * c.out_nc + c.out_nc), [&] {
       return tg_convout_tail(zbuf, (int64_t)32 * s * s * hw, c.out_nc, lw_out.b, lr_curr, c.up_mode, s, hr_out,
-                             (int64_t)c.out_nc * s * s * hw, n == 1 ? u8_out : nullptr, n, s * h, s * w, st);
+                             (int64_t)c.out_nc * s * s * hw, u8_out, n, s * h, s * w, st);
     });
     return rc;
   }
@@ -360,7 +364,7 @@ extern "C" int tg_frnet_step_masked(tg_frnet_plan* p, const float* lr_curr, cons
                                     const float* hr_prev, float* hr_out, uint8_t* u8_out,
                                     unsigned kind_mask, tg_stream_t st) {
   TG_REQUIRE(p && lr_curr && lr_prev && hr_prev && hr_out, TG_E_ARG, "frnet_step: null pointer");
-  TG_REQUIRE(!u8_out || p->cfg.n == 1, TG_E_ARG, "frnet_step: u8 output needs n == 1");
+  TG_REQUIRE(!u8_out || plan_u8_ok(p), TG_E_ARG, "frnet_step: u8 output needs n == 1 (or the fused HR stage)");
   TG_REQUIRE(!p->cfg.fnet_only, TG_E_ARG, "frnet_step: the plan was created FNet-only");
   return step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, u8_out, st, kind_mask, false);
 }
@@ -375,7 +379,7 @@ extern "C" int tg_frnet_step_srnet(tg_frnet_plan* p, const float* lr_flow, const
                                    tg_stream_t st) {
   TG_REQUIRE(p && lr_flow && lr_curr && hr_prev && hr_out, TG_E_ARG, "frnet_step_srnet: null pointer");
   TG_REQUIRE(!p->cfg.fnet_only, TG_E_ARG, "frnet_step_srnet: the plan was created FNet-only");
-  TG_REQUIRE(!u8_out || p->cfg.n == 1, TG_E_ARG, "frnet_step_srnet: u8 output needs n == 1");
+  TG_REQUIRE(!u8_out || plan_u8_ok(p), TG_E_ARG, "frnet_step_srnet: u8 output needs n == 1 (or the fused HR stage)");
   return step_impl(p, lr_curr, nullptr, hr_prev, hr_out, u8_out, st, 0xFFFFFFFFu, false, 2, 0, lr_flow);
 }
 
@@ -387,7 +391,7 @@ extern "C" int tg_frnet_step_phase(tg_frnet_plan* p, int phases, int flow_slot, 
              "frnet_step_phase: phases=%d slot=%d", phases, flow_slot);
   TG_REQUIRE(!(phases & 1) || lr_prev, TG_E_ARG, "frnet_step_phase: phase 1 needs lr_prev");
   TG_REQUIRE(!(phases & 2) || (hr_prev && hr_out), TG_E_ARG, "frnet_step_phase: phase 2 needs hr_prev/hr_out");
-  TG_REQUIRE(!u8_out || p->cfg.n == 1, TG_E_ARG, "frnet_step_phase: u8 output needs n == 1");
+  TG_REQUIRE(!u8_out || plan_u8_ok(p), TG_E_ARG, "frnet_step_phase: u8 output needs n == 1 (or the fused HR stage)");
   TG_REQUIRE(!(phases & 2) || !p->cfg.fnet_only, TG_E_ARG, "frnet_step_phase: the plan was created FNet-only");
   return step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, u8_out, st, 0xFFFFFFFFu, false, phases,
                    flow_slot);

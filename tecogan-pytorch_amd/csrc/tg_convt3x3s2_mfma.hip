@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void convout_tail_kernel(const float* __restri
     for (int o = 0; o < CZ; ++o) {
       float r = rintf(v[o] * 255.0f);
       r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
-      u8[((long long)Y * w + X) * CZ + o] = (uint8_t)r;
+      u8[(((long long)b * h + Y) * w + X) * CZ + o] = (uint8_t)r;      // (n, h, w, cz)
     }
   }
 }
@@ -445,7 +445,6 @@ extern "C" int tg_convout_tail(const float* z, int64_t z_nstride, int cz, const 
                                tg_stream_t stream) {
   TG_REQUIRE(z && y, TG_E_ARG, "convout_tail: null pointer");
   TG_REQUIRE(n > 0 && h > 0 && w > 0 && cz >= 1 && cz <= 3, TG_E_SHAPE, "convout_tail: n=%d h=%d w=%d cz=%d", n, h, w, cz);
-  TG_REQUIRE(!u8_out || n == 1, TG_E_ARG, "convout_tail: u8 output needs n == 1");
   if (up_src)
     TG_REQUIRE((up_mode == TG_UP_BICUBIC || up_mode == TG_UP_BILINEAR) && up_scale >= 1 && h % up_scale == 0 &&
                    w % up_scale == 0, TG_E_SHAPE, "convout_tail: up_mode=%d up_scale=%d", up_mode, up_scale);

@@ -286,6 +286,13 @@ class FRNet(nn.Module):
         numpy, zero initial state (tecogan_nets.py:254-281).  Frames are quantised on the
         device and there is ONE host synchronisation at the end instead of one per frame.
 
+        A 5-D input (k, t, c, h, w) is a batch of k INDEPENDENT clips of equal length and size,
+        advanced in lockstep: every launch of a frame step covers the k clips (the recurrence is
+        serial in t only), which fills the tile-quantisation holes a single 134x320 frame leaves
+        on 256 CUs; the result is (k, t, s*h, s*w, c).  Each clip's frames equal those of running
+        that clip alone up to the summation order of differently batched launches (tile variant
+        and split-K factor depend on the pixel count): one uint8 level on a few pixels at most.
+
         pipeline=True: FNet depends only on the LR frames, so the flows of the next
         TG_FNET_BATCH (default 8) frame pairs are estimated by one batched FNet pass on a
         second HIP stream while warp+SRNet runs frame by frame on the first (two flow
@@ -295,34 +302,39 @@ class FRNet(nn.Module):
         a host clip is uploaded batch by batch and the uint8 frames of a finished batch are
         copied to pinned host memory on a third (copy) stream while the next batch computes;
         the returned array is backed by that pinned buffer."""
-        tot_frm, c, h, w = lr_data.size()
+        multi = lr_data.dim() == 5
+        if multi:                                           # (k, t, c, h, w) -> frame-major (t, k, c, h, w)
+            lr_data = lr_data.permute(1, 0, 2, 3, 4)
+        else:
+            lr_data = lr_data.unsqueeze(1)
+        tot_frm, k, c, h, w = lr_data.size()
         s = self.scale
         dev = torch.device(device) if device is not None else lr_data.device
         host_in = not lr_data.is_cuda
         stream_io = pipeline and tot_frm >= 2 and not return_device_tensor
-        zeros_lr = torch.zeros(1, c, h, w, dtype=torch.float32, device=dev)
         if host_in and stream_io:
-            lr_ext = torch.empty(tot_frm + 1, c, h, w, dtype=torch.float32, device=dev)
+            lr_ext = torch.empty(tot_frm + 1, k, c, h, w, dtype=torch.float32, device=dev)
             lr_ext[0].zero_()                               # frame -1 = zeros (tecogan_nets.py:266)
             lr_host = lr_data.to(dtype=torch.float32).contiguous()
         else:
-            lr_ext = torch.cat([zeros_lr, lr_data.to(dev, dtype=torch.float32, non_blocking=True)], 0)
+            lr_ext = torch.cat([torch.zeros(1, k, c, h, w, dtype=torch.float32, device=dev),
+                                lr_data.to(dev, dtype=torch.float32, non_blocking=True)], 0)
         lr = lr_ext[1:]
-        hr = [torch.zeros(1, c, s * h, s * w, dtype=torch.float32, device=dev),
-              torch.empty(1, c, s * h, s * w, dtype=torch.float32, device=dev)]
-        u8 = torch.empty(tot_frm, s * h, s * w, c, dtype=torch.uint8, device=dev)
+        hr = [torch.zeros(k, c, s * h, s * w, dtype=torch.float32, device=dev),
+              torch.empty(k, c, s * h, s * w, dtype=torch.float32, device=dev)]
+        u8 = torch.empty(tot_frm, k, s * h, s * w, c, dtype=torch.uint8, device=dev)
         host_out = None
         with torch.no_grad():
             if not pipeline or tot_frm < 2:
                 for i in range(tot_frm):
-                    self.step(lr[i:i + 1], lr_ext[i:i + 1], hr[i & 1], out=hr[(i + 1) & 1], u8_out=u8[i])
+                    self.step(lr[i], lr_ext[i], hr[i & 1], out=hr[(i + 1) & 1], u8_out=u8[i])
             else:
                 # FNet needs only the LR frames: the flows of FNET_BATCH consecutive frame
                 # pairs are estimated in ONE batched pass on the side stream (large grids, no
                 # split-K) while the main stream runs warp + SRNet frame by frame on the
                 # previous batch -- the serial part of the recurrence is SRNet alone.
-                nb_ = max(1, min(int(os.environ.get('TG_FNET_BATCH', '8')), tot_frm))
-                plan = self._get_plan(1, h, w, dev)
+                nb_ = max(1, min(max(1, int(os.environ.get('TG_FNET_BATCH', '8')) // k), tot_frm))
+                plan = self._get_plan(k, h, w, dev)
                 lib = L.lib()
                 main = torch.cuda.current_stream(dev)
                 side = self._side_stream(dev)
@@ -332,52 +344,54 @@ class FRNet(nn.Module):
                 copy = self._copy_stream(dev) if stream_io else None
                 ev_in = [torch.cuda.Event() for _ in range(nbatch)] if (stream_io and host_in) else None
                 if stream_io:
-                    host_out = torch.empty(tot_frm, s * h, s * w, c, dtype=torch.uint8, pin_memory=True)
+                    host_out = torch.empty(tot_frm, k, s * h, s * w, c, dtype=torch.uint8, pin_memory=True)
                     copy.wait_stream(main)                  # lr_ext / u8 allocations are visible
                 if ev_in is not None:                       # uploads run ahead on the copy stream
-                    for k in range(nbatch):
-                        i0 = k * nb_
+                    for b_ in range(nbatch):
+                        i0 = b_ * nb_
                         cnt = min(nb_, tot_frm - i0)
                         with torch.cuda.stream(copy):
                             lr_ext[i0 + 1:i0 + 1 + cnt].copy_(lr_host[i0:i0 + cnt], non_blocking=True)
-                            ev_in[k].record(copy)
-                fsz = 2 * plan.fh * plan.fw * 4             # bytes of one frame's LR flow
-                for k in range(nbatch):
-                    i0 = k * nb_
+                            ev_in[b_].record(copy)
+                fsz = k * 2 * plan.fh * plan.fw * 4         # bytes of one frame's LR flows (k clips)
+                for b_ in range(nbatch):
+                    i0 = b_ * nb_
                     cnt = min(nb_, tot_frm - i0)
-                    fplan = self._get_plan(cnt, h, w, dev, fnet_only=True)
+                    fplan = self._get_plan(cnt * k, h, w, dev, fnet_only=True)
                     if ev_in is not None:
-                        side.wait_event(ev_in[k])
-                        main.wait_event(ev_in[k])
-                    if k >= 2:
-                        side.wait_event(ev_s[k - 2])        # flow slot k&1 consumed by batch k-2
-                    L.check(lib.tg_frnet_step_phase(fplan.handle, 1, k & 1,
+                        side.wait_event(ev_in[b_])
+                        main.wait_event(ev_in[b_])
+                    if b_ >= 2:
+                        side.wait_event(ev_s[b_ - 2])       # flow slot b_&1 consumed by batch b_-2
+                    L.check(lib.tg_frnet_step_phase(fplan.handle, 1, b_ & 1,
                                                     lr_ext[i0 + 1:i0 + 1 + cnt].data_ptr(),
                                                     lr_ext[i0:i0 + cnt].data_ptr(), None, None, None,
                                                     side.cuda_stream), 'tg_frnet_step_phase(1)')
-                    ev_f[k].record(side)
-                    main.wait_event(ev_f[k])
-                    flow0 = lib.tg_frnet_plan_flow(fplan.handle, k & 1)
+                    ev_f[b_].record(side)
+                    main.wait_event(ev_f[b_])
+                    flow0 = lib.tg_frnet_plan_flow(fplan.handle, b_ & 1)
                     for j in range(cnt):
                         i = i0 + j
                         L.check(lib.tg_frnet_step_srnet(plan.handle, flow0 + j * fsz,
-                                                        lr[i:i + 1].data_ptr(), hr[i & 1].data_ptr(),
+                                                        lr[i].data_ptr(), hr[i & 1].data_ptr(),
                                                         hr[(i + 1) & 1].data_ptr(), u8[i].data_ptr(),
                                                         main.cuda_stream), 'tg_frnet_step_srnet')
-                    ev_s[k].record(main)
-                    if stream_io:                           # download batch k while batch k+1 computes
-                        copy.wait_event(ev_s[k])
+                    ev_s[b_].record(main)
+                    if stream_io:                           # download batch b_ while batch b_+1 computes
+                        copy.wait_event(ev_s[b_])
                         with torch.cuda.stream(copy):
                             host_out[i0:i0 + cnt].copy_(u8[i0:i0 + cnt], non_blocking=True)
                 main.wait_stream(side)
                 if stream_io:
                     main.wait_stream(copy)
         if return_device_tensor:
-            return u8
+            return u8.permute(1, 0, 2, 3, 4) if multi else u8[:, 0]
         if host_out is not None:
             torch.cuda.current_stream(dev).synchronize()
-            return host_out.numpy()
-        return u8.cpu().numpy()
+            out = host_out.numpy()
+        else:
+            out = u8.cpu().numpy()
+        return out.transpose(1, 0, 2, 3, 4) if multi else out[:, 0]
 
     def _copy_stream(self, dev):
         st = getattr(self, '_copy', None)

@@ -476,3 +476,20 @@ def test_infer_sequence_batched_flow_pipeline_matches_frame_by_frame(frames):
     d = np.abs(a.astype(np.int16) - b.astype(np.int16))
     assert d.max() <= 1, d.max()
     assert (d > 0).mean() <= 2e-3, (d > 0).mean()
+
+
+@pytest.mark.parametrize('pipeline', [True, False])
+def test_infer_sequence_batch_of_clips_matches_clip_by_clip(pipeline):
+    """(k, t, c, h, w) input: k independent clips advanced in lockstep through one launch list
+    (batched uint8 output of the fused HR tail).  Against each clip alone: same arithmetic up to
+    the split-K / tile choices of differently sized launches."""
+    net, _ = make_net('BD', 4)
+    clips = torch.stack([smooth_clip(11, 3, 24, 40, seed=50 + i) for i in range(3)])
+    both = net.infer_sequence(clips, 'cuda', pipeline=pipeline)
+    assert both.shape == (3, 11, 96, 160, 3) and both.dtype == np.uint8
+    dev_out = net.infer_sequence(clips.cuda(), 'cuda', pipeline=pipeline, return_device_tensor=True)
+    assert np.array_equal(dev_out.cpu().numpy(), both)
+    for i in range(3):
+        one = net.infer_sequence(clips[i], 'cuda', pipeline=pipeline)
+        d = np.abs(both[i].astype(np.int16) - one.astype(np.int16))
+        assert d.max() <= 1 and (d > 0).mean() <= 2e-3, (i, d.max(), (d > 0).mean())
