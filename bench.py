@@ -387,7 +387,7 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
             'workload': 'BASELINE configs[2]: same step, 2 x 10 -> 19 frames, crop 256 (Vimeo yml shape)',
             'ms_per_step': 1e3 * dt2, 'hr_frames_per_s': 2 * 19 / dt2, 'd_updates': nupd2}
         del m2
-    torch.cuda.empty_cache()
+    # (no torch.cuda.empty_cache() here: it segfaults under an RCCL process group on this stack)
     return out
 
 
@@ -605,7 +605,9 @@ def main():
             result['kernels'] = rows
             result['gpu_ms_per_frame_sum_of_kernels'] = sum(r['ms_per_frame'] for r in rows)
             result['slowest_kernel_class'] = dom['kernel']
-        if world == 1 and args.aten_frames > 0:
+        # context baselines only in a plain process (MIOpen's find segfaults next to an RCCL process
+        # group on this stack; the driver's N = 1 run is a plain process)
+        if world == 1 and not dist_on and args.aten_frames > 0:
             sd_dev = {k: v.detach() for k, v in net.state_dict().items()}
             # the reference's profile mode sets cudnn.benchmark = True (main.py:216), which
             # on ROCm is MIOpen's exhaustive find; report the better of both settings
