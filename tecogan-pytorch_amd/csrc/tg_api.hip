@@ -139,7 +139,7 @@ enum {
   K_CONV64_R2 = 0,  // conv3x3_mfma_kernel<2,2,1>
   K_CONV64_R4 = 1,  // conv3x3_mfma_kernel<4,1,2>
   K_CONV32 = 2,     // conv3x3_mfma_kernel<4,1,1>
-  K_CONVT = 3,      // convt3x3s2_mfma_kernel<4,2>
+  K_CONVT = 3,      // convt3x3s2_mfma_kernel<2|4,2>
   K_SMALL = 4,      // conv3x3_small_kernel<COUT>
   K_WARP = 5,       // flowup_warp_s2d_kernel<S,3>
   K_POOL = 6,
@@ -416,10 +416,10 @@ extern "C" int tg_frnet_plan_kinds(void) { return K_COUNT; }
 extern "C" const char* tg_frnet_kind_name(int kind) {
   static const char* names[K_COUNT] = {
       "conv3x3_mfma_kernel<2,2,1>", "conv3x3_mfma_kernel<4,1,2>", "conv3x3_mfma_kernel<4,1,1>",
-      "convt3x3s2_mfma_kernel<4,2>", "conv3x3_small_kernel",       "flowup_warp_s2d_kernel",
+      "convt3x3s2_mfma_kernel",      "conv3x3_small_kernel",       "flowup_warp_s2d_kernel",
       "maxpool2_kernel",             "upsample_kernel",            "quantize_u8_hwc_kernel",
       "splitk_finalize_kernel",      "conv3x3_mfma_kernel<1,2,1,KS=2>",
-      "convt3x3s2_mfma_kernel<4,2,Z>", "convout_tail_kernel"};
+      "convt3x3s2_mfma_kernel<Z>",   "convout_tail_kernel"};
   return (kind >= 0 && kind < K_COUNT) ? names[kind] : "?";
 }
 
