@@ -149,7 +149,8 @@ enum {
   K_CONV64_KS = 10, // conv3x3_mfma_kernel<1,2,1,...,2>: in-workgroup K split (few tiles)
   K_CONVT_Z = 11,   // convt3x3s2_mfma_kernel<4,2,true>: last up-sampling layer + output-conv contraction
   K_TAIL = 12,      // convout_tail_kernel: 9-tap shift-add + residual + uint8
-  K_COUNT = 13
+  K_CONV_ONESHOT = 13,  // conv3x3_oneshot_kernel: few tiles, cin <= 64, whole K range in flight
+  K_COUNT = 14
 };
 
 // The HR stage as two launches instead of three and without the 64-channel HR tensor: the last
@@ -200,7 +201,7 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     double by = 4.0 * px * (cin + cout + (res ? cout : 0)) + 4.0 * 9 * cin * cout;
     int ks = res ? 1 : tg_conv3x3_pick_ksplit(n, cin, cout, hh, ww);
     if (ks == 1 && kind == K_CONV64_R2 && tg::conv3x3_uses_wg_ksplit(n, cin, cout, hh, ww))
-      kind = K_CONV64_KS;          // same rule as the launcher (tg_conv3x3_mfma.hip)
+      kind = tg::conv3x3_uses_oneshot(n, cin, cout, hh, ww) ? K_CONV_ONESHOT : K_CONV64_KS;   // launcher's rule
     if (ks > 1) {
       go(kind, fl, by, [&] {
         return tg::conv3x3_splitk_conv(x, xns, c1, x2, x2ns, lw.w, ocb, n, cin, cout, hh, ww, ks,
@@ -419,7 +420,7 @@ extern "C" const char* tg_frnet_kind_name(int kind) {
       "convt3x3s2_mfma_kernel",      "conv3x3_small_kernel",       "flowup_warp_s2d_kernel",
       "maxpool2_kernel",             "upsample_kernel",            "quantize_u8_hwc_kernel",
       "splitk_finalize_kernel",      "conv3x3_mfma_kernel<1,2,1,KS=2>",
-      "convt3x3s2_mfma_kernel<Z>",   "convout_tail_kernel"};
+      "convt3x3s2_mfma_kernel<Z>",   "convout_tail_kernel",        "conv3x3_oneshot_kernel"};
   return (kind >= 0 && kind < K_COUNT) ? names[kind] : "?";
 }
 

@@ -48,6 +48,7 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // 64-channel-group layers with at most half as many 2-row tiles as CUs run the in-workgroup
 // K-split variant of the conv kernel (1-row tiles, two wave groups over alternating chunks).
 bool conv3x3_uses_wg_ksplit(int n, int cin, int cout, int h, int w);
+bool conv3x3_uses_oneshot(int n, int cin, int cout, int h, int w);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -500,6 +500,156 @@ __global__ __launch_bounds__(WM* WN* KS * 64) void conv3x3_mfma_kernel(Conv3x3Ar
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// One-shot variant for the training frames (2 x 64 x 64 LR: 256 one-row tiles for 256 CUs) and
+// cin <= 64.  The K-split variant above still walks the channel chunks in four double-buffered
+// iterations, each ending on a barrier; with ONE workgroup per CU nothing hides its prologue,
+// its barriers or its reduce, and a launch takes 13.4 us for 4.4 us of MFMAs (800 such launches
+// per training step).  Here the whole K range is in flight at once:
+//   * 8 waves = 2 oc halves x 4 K groups; every wave requests ITS weights (<= 2 chunks x 9 taps,
+//     one coalesced 16-byte load per tap: the packed layout is the A operand) straight into
+//     registers and its share of the input patch (all chunks, 3 rows x 34 px) for LDS -- one
+//     round of global loads, one barrier;
+//   * <= 72 MFMAs per wave, no loop-carried staging;
+//   * K groups 1..3 hand their accumulators to group 0 through LDS (fixed order: deterministic),
+//     the result is transposed through LDS and leaves as one 16-byte store per thread with
+//     bias / activation / residual / ReLU-mask applied -- three barriers per launch in all.
+template <bool DUAL>
+__global__ __launch_bounds__(512) void conv3x3_oneshot_kernel(Conv3x3Args a) {
+  constexpr int OCB = 64, KG = 4, MAXCH = 8;
+  constexpr int IN_FLOATS = 3 * 2 * RS * 4;            // one chunk's patch: 3 rows x 2 halves x 34 slots
+  constexpr int ITEMS_PER_CH = 3 * 2 * PW;             // 204 16-byte items
+  constexpr int W_VEC4 = 9 * CK * OCB / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_in = smem;                                  // [MAXCH][IN_FLOATS]; later the epilogue stage [64][36]
+  float* red = smem + MAXCH * IN_FLOATS;               // [2][KG-1][16][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+  const int lh = lane >> 5, ll = lane & 31;
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int x0 = tx * TW, y0 = ty;
+  const int hw = a.h * a.w;
+  const unsigned plane = (unsigned)hw * 4u;
+  const int nchunk = a.nchunk;
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (long long)n * a.x_ns), 0, a.c1 * hw * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(DUAL ? a.x2 + (long long)n * a.x2_ns : a.x), 0,
+      DUAL ? (a.cin - a.c1) * hw * 4 : 0, 0x00020000);
+
+  // ---- weights of this wave's chunks -> registers (issued first: longest latency)
+  const int cpw = (nchunk + KG - 1) / KG;              // chunks per K group (<= 2)
+  const int c0 = wk * cpw;
+  const f32x4* wlane = reinterpret_cast<const f32x4*>(a.wpk) + (lh * OCB + wn * 32 + ll);
+  f32x4 aw[2][9];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int c = c0 + ci;
+    const bool on = ci < cpw && c < nchunk;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (on) v = wlane[(size_t)c * W_VEC4 + tap * (2 * OCB)];
+      aw[ci][tap] = v;
+    }
+  }
+  // ---- the input patch of every chunk -> LDS
+  const int total = nchunk * ITEMS_PER_CH;
+  for (int q = tid; q < total; q += 512) {
+    const int ch = q / ITEMS_PER_CH, rem = q - ch * ITEMS_PER_CH;
+    const int r = rem / (2 * PW), rem2 = rem - r * (2 * PW);
+    const int hf = rem2 / PW, col = rem2 - hf * PW;
+    const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+    const bool ok = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+    const unsigned base = ok ? (unsigned)(((ch * CK + 4 * hf) * hw + gy * a.w + gx) * 4) : OOB;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned o1 = base + (unsigned)j * plane;
+      float t = buf_load(rs1, o1);
+      if (DUAL) t += buf_load(rs2, o1 - (unsigned)a.c1 * plane);
+      v[j] = t;
+    }
+    *reinterpret_cast<f32x4*>(s_in + ch * IN_FLOATS + ((r * 2 + hf) * RS + col) * 4) = v;
+  }
+  __syncthreads();
+
+  // ---- MFMAs of this wave's K range
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int c = c0 + ci;
+    if (ci < cpw && c < nchunk) {
+      const float* si = s_in + c * IN_FLOATS + (lh * RS + ll) * 4;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(si + (ky * 2 * RS + kx) * 4);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ci][tap][kk], bq[kk], acc, 0, 0, 0);
+      }
+    }
+  }
+  // ---- K groups 1..3 -> group 0 (fixed order), then the tile through LDS as [oc 64][36]
+  if (wk > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wn * (KG - 1) + wk - 1) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();                                      // all input reads are done as well
+  constexpr int ES = 36;
+  float* ep = smem;
+  if (wk == 0) {
+#pragma unroll
+    for (int g = 0; g < KG - 1; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[((wn * (KG - 1) + g) * 16 + r) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ep[(wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ES + ll] = acc[r];
+  }
+  __syncthreads();
+  const float slope = act_slope(a.act);
+  const int py = y0;
+  if (a.vec_ok) {
+    const int oc = tid >> 3, p4 = (tid & 7) * 4;
+    const int gx = x0 + p4;
+    if (oc < a.cout && gx < a.w) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(ep + oc * ES + p4);
+      const float bb = a.bias ? a.bias[oc] : 0.f;
+      const long long off = (long long)oc * hw + (long long)py * a.w + gx;
+      f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+      if (a.res) rr = *reinterpret_cast<const f32x4*>(a.res + (long long)n * a.res_ns + off);
+      f32x4 mm = {1.f, 1.f, 1.f, 1.f};
+      if (a.mask) mm = *reinterpret_cast<const f32x4*>(a.mask + (long long)n * a.mask_ns + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float q = v[e] + bb;
+        q = (q >= 0.f ? q : q * slope + 0.f) + rr[e];
+        v[e] = mm[e] > 0.f ? q : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(a.y + (long long)n * a.y_ns + off) = v;
+    }
+  } else {
+    for (int i = tid; i < 64 * TW; i += 512) {
+      const int oc = i >> 5, p = i & 31;
+      const int gx = x0 + p;
+      if (oc < a.cout && gx < a.w) {
+        const long long off = (long long)oc * hw + (long long)py * a.w + gx;
+        float q = ep[oc * ES + p] + (a.bias ? a.bias[oc] : 0.f);
+        q = (q >= 0.f ? q : q * slope + 0.f) + (a.res ? a.res[(long long)n * a.res_ns + off] : 0.f);
+        if (a.mask && a.mask[(long long)n * a.mask_ns + off] <= 0.f) q = 0.f;
+        a.y[(long long)n * a.y_ns + off] = q;
+      }
+    }
+  }
+}
+
 // 3 = LDS-transposed 16-byte epilogue + LDS-DMA weight staging (measured +2 % on the frame,
 // parity suite green); bit 4 (start-up stagger of co-resident workgroups) measured null.
 #ifndef TG_CONV_OPT
@@ -583,6 +733,12 @@ __global__ void splitk_finalize_kernel(const float* __restrict__ part, int S, lo
 }  // namespace tg
 
 namespace tg {
+// the one-shot kernel: the K-split variant's shapes with cin <= 64 (<= 8 chunks) and one oc block
+bool conv3x3_uses_oneshot(int n, int cin, int cout, int h, int w) {
+  static const int env = [] { const char* e = getenv("TG_CONV_ONESHOT"); return e ? atoi(e) : 1; }();
+  return env && cout <= 64 && cdiv(cin, CK) <= 8 && conv3x3_uses_wg_ksplit(n, cin, cout, h, w);
+}
+
 bool conv3x3_uses_wg_ksplit(int n, int cin, int cout, int h, int w) {
   static const int ks_env = [] { const char* e = getenv("TG_CONV_WG_KSPLIT"); return e ? atoi(e) : 1; }();
   if (!ks_env || tg_conv3x3_pick_ocb(cout) != 64 || conv3x3_rows_per_wg(64, (long long)n * h * w) != 2)
@@ -684,6 +840,25 @@ static int conv3x3_impl(const float* x, int64_t x_nstride, int c1, const float* 
   if (conv3x3_rows_per_wg(ocb, (long long)n * h * w) == 4) return launch_conv<4, 1, 2>(a, n, s);
   // At most half as many 2-row tiles as CUs (e.g. a training batch of 2 x 64 x 64): 1-row tiles
   // with the channel chunks split over two wave groups keep every SIMD busy in ONE launch.
+  if (a.ksplit <= 1 && !tapsel && conv3x3_uses_oneshot(n, cin, cout, h, w)) {
+    a.vec_ok = (a.w % 4 == 0) && ((uintptr_t)a.y % 16 == 0) && (a.y_ns % 4 == 0) &&
+               (!a.res || (((uintptr_t)a.res % 16 == 0) && (a.res_ns % 4 == 0))) &&
+               (!a.mask || (((uintptr_t)a.mask % 16 == 0) && (a.mask_ns % 4 == 0)));
+    a.tiles_x = cdiv(a.w, TW); a.tiles_y = a.h; a.nocg = 1; a.nchunk = cdiv(a.cin, CK);
+    const size_t lds = (size_t)(8 * 3 * 2 * RS * 4 + 2 * 3 * 16 * 64) * sizeof(float);    // 50.7 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_oneshot_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_oneshot_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    const unsigned grid = (unsigned)(a.tiles_x * a.tiles_y * n);
+    if (a.x2) hipLaunchKernelGGL(conv3x3_oneshot_kernel<true>, dim3(grid), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(conv3x3_oneshot_kernel<false>, dim3(grid), dim3(512), lds, s, a);
+    return check_launch("conv3x3_oneshot");
+  }
   if (a.ksplit <= 1 && conv3x3_uses_wg_ksplit(n, cin, cout, h, w)) return launch_conv<1, 2, 1, 2>(a, n, s);
   return launch_conv<2, 2, 1>(a, n, s);
 }
