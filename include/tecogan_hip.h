@@ -374,6 +374,44 @@ int tg_downsample_bd(const float* x, const float* kernel2d, float* y, int nc, in
                      int w, int ksize, int scale, int pad, tg_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Data movement of the training step, one launch each (they replace chains of ATen slice / flip /
+ * cat / zero-fill kernels):
+ *   tg_time_gather     y[n][k] = x[n][idx[k]] over (n, t, inner) tensors, idx a HOST array of k <= 64
+ *                      frame numbers (a negative entry writes a zero frame): the ping-pong augmentation cat(x, x.flip(1)[:, 1:])
+ *                      (vsrgan_model.py:112-119), the halves hr[:, :te-1] / hr[:, te:].flip(1) of the
+ *                      ping-pong loss (:246-247), data[:, :t] (tecogan_nets.py:437);
+ *   tg_transpose01     y (b, a, inner) = x (a, b, inner): clip-major (n, t, ...) <-> frame-major (t, n, ...),
+ *                      so that the recurrent unroll (tecogan_nets.py:196-214) reads / writes each
+ *                      time step as a contiguous slice instead of copying it out;
+ *   tg_stack_time      y (n, k, inner) with y[:, j] = src_host[j] (n, inner): torch.stack(frames, 1) of
+ *                      the k <= 64 per-frame outputs (tecogan_nets.py:216), src_host a HOST array of
+ *                      device pointers;
+ *   tg_index_gather    out[i] (+)= src[idx[i]], 0 where idx[i] is outside [0, n_src): the weight
+ *                      re-layouts that express ConvTranspose2d(k3,s2) backward and Conv2d(k4,s2) as
+ *                      3x3 convolutions over space_to_depth tensors, and their inverse on the gradient;
+ *   tg_pingpong_grad   the ping-pong loss gradient g (n, te-1, inner) routed onto the 2*te-1 frames:
+ *                      +g | 0 | -flip(g);
+ *   tg_d_assemble_fwd  SpatioTemporalDiscriminator's input (tecogan_nets.py:440-463): x (n*t/3, 9c, h, w)
+ *                      = [frame triplets rrrgggbbb | warped triplets centre-cropped (crop) and
+ *                      zero-padded (pad) | bicubic condition]; data / cond are (n, t_data|t_cond, c, h, w)
+ *                      of which the first t frames are used, warped is (n*t, c, h, w);
+ *   tg_d_assemble_bwd  its adjoint: g -> g_data (n, t_data, c, h, w; zero beyond t), g_warped (n*t, c, h, w).
+ * ---------------------------------------------------------------------- */
+int tg_time_gather(const float* x, float* y, const int* idx_host, int n, int t_in, int k,
+                   int64_t inner, tg_stream_t stream);
+int tg_transpose01(const float* x, float* y, int a, int b, int64_t inner, tg_stream_t stream);
+int tg_stack_time(const float* const* src_host, int k, float* y, int n, int64_t inner,
+                  tg_stream_t stream);
+int tg_index_gather(const float* src, const int64_t* idx, float* out, int64_t n_out, int64_t n_src,
+                    int accumulate, tg_stream_t stream);
+int tg_pingpong_grad(const float* g, float* out, int n, int te, int64_t inner, tg_stream_t stream);
+int tg_d_assemble_fwd(const float* data, int t_data, const float* warped, const float* cond,
+                      int t_cond, float* x, int n, int t, int c, int h, int w, int pad, int crop,
+                      tg_stream_t stream);
+int tg_d_assemble_bwd(const float* g, float* g_data, int t_data, float* g_warped, int n, int t, int c,
+                      int h, int w, int pad, int crop, tg_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Training-batch assembly from an HBM-resident uint8 training set (the decoded LMDB of
  * scripts/create_lmdb.py:57: raw RGB HWC frames).  Replaces the per-sample CPU work of
  * UnpairedLMDBDataset.__getitem__ (codes/data/unpaired_lmdb_dataset.py:55-89: frame windows

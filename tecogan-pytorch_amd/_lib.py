@@ -82,6 +82,13 @@ SIGNATURES = {
     'tg_linear1_fwd': (I, [P, P, P, P, I, I, P]),
     'tg_linear1_bwd': (I, [P, P, P, P, P, P, I, I, I, P]),
     'tg_downsample_bd': (I, [P, P, P, I, I, I, I, I, I, P]),
+    'tg_time_gather': (I, [P, P, P, I, I, I, I64, P]),
+    'tg_transpose01': (I, [P, P, I, I, I64, P]),
+    'tg_stack_time': (I, [P, I, P, I, I64, P]),
+    'tg_index_gather': (I, [P, P, P, I64, I64, I, P]),
+    'tg_pingpong_grad': (I, [P, P, I, I, I64, P]),
+    'tg_d_assemble_fwd': (I, [P, I, P, P, I, P, I, I, I, I, I, I, I, P]),
+    'tg_d_assemble_bwd': (I, [P, P, I, P, I, I, I, I, I, I, I, P]),
     'tg_gather_clips_u8': (I, [P, P, P, P, I, I, I, I, P]),
     'tg_comm_get_unique_id': (I, [P]),
     'tg_comm_init_rank': (I, [P, I, I, C.POINTER(C.c_void_p)]),

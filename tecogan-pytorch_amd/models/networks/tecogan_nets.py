@@ -12,6 +12,8 @@ import os
 from collections import OrderedDict
 
 import numpy as np
+import functools
+
 import torch
 import torch.nn as nn
 
@@ -437,44 +439,47 @@ class FRNet(nn.Module):
         n, t, c, h, w = lr_data.shape
         s = self.scale
         tape = TG.Tape()
-        lr_prev = lr_data[:, :-1].reshape(n * (t - 1), c, h, w).contiguous()
-        lr_curr = lr_data[:, 1:].reshape(n * (t - 1), c, h, w).contiguous()
+        lr_prev = ops.time_gather(lr_data, list(range(t - 1))).view(n * (t - 1), c, h, w)
+        lr_curr = ops.time_gather(lr_data, list(range(1, t))).view(n * (t - 1), c, h, w)
         lr_flow = self.fnet(lr_curr, lr_prev, tape=tape)
         hr_flow_all = TG.upsample(tape, lr_flow, s, self.srnet.up_mode(), mul=float(s))
         hr_flow = hr_flow_all.view(n, t - 1, 2, s * h, s * w)
-        g_flow = {}
+        # The recurrence walks time: frame-major copies (t, n, ...) of the LR frames and the HR
+        # flow make every step's operands contiguous slices (3 transposes instead of a copy per
+        # frame and operand), and the flow gradient is written slice by slice into one
+        # frame-major buffer that is transposed back once.
+        lr_fm = ops.transpose01(lr_data)
+        flow_fm = ops.transpose01(hr_flow)
+        g_flow_fm = {}
 
-        def flow_grad_finalize():          # runs after every per-frame slice has deposited
-            if 'g' in g_flow:
-                tape.add_grad(hr_flow_all, g_flow['g'])
+        def flow_grad_finalize():          # runs after every frame's warp has written its slice
+            if 'g' in g_flow_fm:
+                tape.add_grad(hr_flow_all, ops.transpose01(g_flow_fm.pop('g')).view_as(hr_flow_all))
         tape.record(flow_grad_finalize)
+
+        def flow_grad_slice(i):
+            if 'g' not in g_flow_fm:
+                g_flow_fm['g'] = torch.zeros_like(flow_fm)
+            return g_flow_fm['g'][i]
 
         frames = []
         zeros = torch.zeros(n, s * s * c, h, w, dtype=torch.float32, device=lr_data.device)
-        hr_prev = self.srnet(lr_data[:, 0].contiguous(), zeros, tape=tape)
+        hr_prev = self.srnet(lr_fm[0], zeros, tape=tape)
         frames.append(hr_prev)
         for i in range(1, t):
-            flow_i = hr_flow[:, i - 1].contiguous()
-
-            def slice_bwd(flow_i=flow_i, i=i):
-                g = tape.pop_grad(flow_i)
-                if g is None:
-                    return
-                if 'g' not in g_flow:
-                    g_flow['g'] = torch.zeros_like(hr_flow_all)
-                g_flow['g'].view(n, t - 1, 2, s * h, s * w)[:, i - 1].copy_(g)
-            tape.record(slice_bwd)
-            warped = TG.backward_warp(tape, hr_prev, flow_i)
+            warped = TG.backward_warp(tape, hr_prev, flow_fm[i - 1],
+                                      dflow_out=functools.partial(flow_grad_slice, i - 1))
             tran = TG.space_to_depth(tape, warped, s)
-            hr_prev = self.srnet(lr_data[:, i].contiguous(), tran, tape=tape)
+            hr_prev = self.srnet(lr_fm[i], tran, tape=tape)
             frames.append(hr_prev)
-        hr_data = torch.stack(frames, dim=1)
+        hr_data = ops.stack_time(frames)
 
         def stack_bwd():
             g = tape.pop_grad(hr_data)
             if g is not None:
+                g_fm = ops.transpose01(g)
                 for i, f in enumerate(frames):
-                    tape.add_grad(f, g[:, i].contiguous())
+                    tape.add_grad(f, g_fm[i])
         tape.record(stack_bwd)
         self.tape = tape
         return {'hr_data': hr_data, 'hr_flow': hr_flow, 'lr_prev': lr_prev, 'lr_curr': lr_curr,
@@ -541,6 +546,23 @@ class _BN(nn.Module):
         self.register_buffer('running_mean', torch.zeros(c))
         self.register_buffer('running_var', torch.ones(c))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        self._pending = 0       # forward passes since the buffer was last brought up to date
+
+    # nn.BatchNorm2d bumps num_batches_tracked with a device kernel per forward (12 per training
+    # step here); nothing on the path reads it, so passes are counted on the host and folded into
+    # the buffer when a state dict is taken.
+    def count_pass(self):
+        self._pending += 1
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self._pending:
+            self.num_batches_tracked += self._pending
+            self._pending = 0
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
 
 class _Linear1(nn.Module):
@@ -604,60 +626,61 @@ class SpatioTemporalDiscriminator(nn.Module):
         n_pad = (s_size - c_size) // 2
 
         if 'hr_flow_merge' not in args_dict:
-            bw = hr_flow[:, 0:t:3]
             if args_dict['use_pp_crit']:
-                fw = hr_flow.flip(1)[:, 1:t:3]          # valid: the sequence is time-symmetric
+                # [backward flow | 0 | forward flow read off the time-reversed half: valid
+                # because the ping-pong sequence is time-symmetric] per triplet, one launch
+                tf = hr_flow.shape[1]
+                idx = []
+                for j in range(t // 3):
+                    idx += [3 * j, -1, tf - 1 - (3 * j + 1)]
+                hr_flow_merge = ops.time_gather(hr_flow, idx).view(n_clip * 3, 2, hr_h, hr_w)
             else:
                 # forward flow frame1 -> frame2 from an extra FNet pass (tecogan_nets.py:413-425);
                 # detached, so no tape
+                bw = hr_flow[:, 0:t:3]
                 net_G = args_dict['net_G']
                 lr_curr = lr_data[:, 1:t:3].reshape(n_clip, c, lr_h, lr_w).contiguous()
                 lr_next = lr_data[:, 2:t:3].reshape(n_clip, c, lr_h, lr_w).contiguous()
                 lr_flow_fw = net_G.fnet(lr_curr, lr_next)
                 fw = ops.upsample(lr_flow_fw, self.scale, net_G.srnet.up_mode(),
                                   mul=float(self.scale)).view(n, t // 3, 2, hr_h, hr_w)
-            merge = torch.stack([bw, torch.zeros_like(bw), fw], dim=2)
-            hr_flow_merge = merge.reshape(n_clip * 3, 2, hr_h, hr_w).contiguous()
+                merge = torch.stack([bw, torch.zeros_like(bw), fw], dim=2)
+                hr_flow_merge = merge.reshape(n_clip * 3, 2, hr_h, hr_w).contiguous()
         else:
             hr_flow_merge = args_dict['hr_flow_merge']
 
-        def triplets(x):       # (n*t, c, H, W) frames -> (n_clip, 3c, H, W), rrrgggbbb
-            return x.view(n_clip, 3, c, hr_h, hr_w).permute(0, 2, 1, 3, 4).reshape(
-                n_clip, c * 3, hr_h, hr_w)
-
-        frames = data[:, :t].reshape(n * t, c, hr_h, hr_w).contiguous()
+        t_data = data.shape[1]
+        if t == t_data and data.is_contiguous():
+            frames = data.view(n * t, c, hr_h, hr_w)
+        else:
+            frames = ops.time_gather(data, list(range(t))).view(n * t, c, hr_h, hr_w)
         track = tape is not None and need_in
+        held = {}
         if track:
-            # recorded first => runs last: hands the gradient of the frame copies back to `data`
+            # recorded first => runs last: the gradient of the frames through the warp joins the
+            # one through the triplet channels and goes back to `data`
             def frames_bwd():
                 g = tape.pop_grad(frames)
+                full = held.pop('g_data', None)
+                if full is None:
+                    return
                 if g is not None:
-                    full = torch.zeros_like(data)
-                    full[:, :t] = g.view(n, t, c, hr_h, hr_w)
-                    tape.add_grad(data, full)
+                    g = g.view(n, t, c, hr_h, hr_w)
+                    for i in range(n):
+                        ops.axpy_(full[i, :t], g[i], 1.0)
+                tape.add_grad(data, full)
             tape.record(frames_bwd)
         warped = TG.backward_warp(tape if track else None, frames, hr_flow_merge,
                                   need_dimg=True, need_dflow=False)
-        x = torch.zeros(n_clip, 9 * c, hr_h, hr_w, dtype=torch.float32, device=data.device)
-        x[:, 0:3 * c] = triplets(frames)
-        x[:, 3 * c:6 * c, n_pad:n_pad + c_size, n_pad:n_pad + c_size] = \
-            triplets(warped)[:, :, n_pad:n_pad + c_size, n_pad:n_pad + c_size]
-        x[:, 6 * c:9 * c] = triplets(bi_data[:, :t].reshape(n * t, c, hr_h, hr_w))
+        x = ops.d_assemble_fwd(data, warped, bi_data, t, n_pad, c_size)
 
         if track:
             def assemble_bwd():
                 g = tape.pop_grad(x)
                 if g is None:
                     return
-
-                def untrip(z):     # inverse of triplets
-                    return z.reshape(n_clip, c, 3, hr_h, hr_w).permute(0, 2, 1, 3, 4).reshape(
-                        n * t, c, hr_h, hr_w).contiguous()
-                gw = torch.zeros(n_clip, 3 * c, hr_h, hr_w, dtype=torch.float32, device=g.device)
-                gw[:, :, n_pad:n_pad + c_size, n_pad:n_pad + c_size] = \
-                    g[:, 3 * c:6 * c, n_pad:n_pad + c_size, n_pad:n_pad + c_size]
-                tape.add_grad(warped, untrip(gw))
-                tape.add_grad(frames, untrip(g[:, 0:3 * c]))
+                held['g_data'], g_warped = ops.d_assemble_bwd(g, n, t, t_data, c, n_pad, c_size)
+                tape.add_grad(warped, g_warped)
             tape.record(assemble_bwd)
 
         out = TG.conv3x3(tape, self.conv_in['0'], x, TG.LRELU, need_dx=need_in)

@@ -82,7 +82,8 @@ class Tape:
                     ops.wgrad3x3(P, Q, ent['target'], cb_off=ent['cb_off'], accumulate=True)
             else:
                 p0, q0 = ent['p'][0], ent['q'][0]
-                ge = torch.zeros(p0.shape[1], q0.shape[1], 3, 3, dtype=torch.float32, device=p0.device)
+                # accumulate=False below: every tap the post hook reads is overwritten
+                ge = torch.empty(p0.shape[1], q0.shape[1], 3, 3, dtype=torch.float32, device=p0.device)
                 phased = ent.get('phased')
                 if phased is not None and (phased[0] % 64 != 0 or not (same(ent['p']) and same(ent['q']))):
                     phased = None                 # the kernel dispatches on 64-channel blocks
@@ -274,8 +275,7 @@ def _convt_embed(wt):
     """(ci, co, 3, 3) -> conv weight (cout_op = ci, cin_op = 4*co, 3, 3) acting on s2d(dY)."""
     ci, co = wt.shape[:2]
     fwd, _ = _embed_index('convt', ci, co, wt.device)
-    flat = torch.cat([wt.reshape(-1), wt.new_zeros(1)])          # trailing slot = 0
-    return flat.index_select(0, fwd).view(ci, 4 * co, 3, 3)
+    return ops.index_gather(wt.contiguous(), fwd).view(ci, 4 * co, 3, 3)   # out-of-range slot = 0
 
 
 def convt3x3s2(tape, layer, x, act=RELU):
@@ -300,7 +300,7 @@ def convt3x3s2(tape, layer, x, act=RELU):
         if w.requires_grad:
             def post(ge):                                          # G[ci][(ph,co)][ty][tx]
                 _, inv = _embed_index('convt', ci, co, ge.device)
-                ops.axpy_(_grad_buf(w), ge.reshape(-1).index_select(0, inv).view(ci, co, 3, 3), 1.0)
+                ops.index_gather(ge, inv, out=_grad_buf(w), accumulate=True)
             tape.defer_wgrad(('ct', id(layer)), x, s, None, 0, post, phased=(co, ops.TAPS_1, ops.TAPS_01))
             tape.defer_bias(_grad_buf(b), dz)
     tape.record(bwd)
@@ -318,8 +318,7 @@ def _conv4_embed(w4):
     """(co, ci, 4, 4) -> (co, 4*ci, 3, 3) acting on s2d(x, 2)."""
     co, ci = w4.shape[:2]
     fwd, _ = _embed_index('conv4', co, ci, w4.device)
-    flat = torch.cat([w4.reshape(-1), w4.new_zeros(1)])
-    return flat.index_select(0, fwd).view(co, 4 * ci, 3, 3)
+    return ops.index_gather(w4.contiguous(), fwd).view(co, 4 * ci, 3, 3)
 
 
 def conv4x4s2(tape, holder, x, need_dx=True):
@@ -344,7 +343,7 @@ def conv4x4s2(tape, holder, x, need_dx=True):
         if w.requires_grad:
             def post(ge):
                 _, inv = _embed_index('conv4', co, ci, ge.device)
-                ops.axpy_(_grad_buf(w), ge.reshape(-1).index_select(0, inv).view(co, ci, 4, 4), 1.0)
+                ops.index_gather(ge, inv, out=_grad_buf(w), accumulate=True)
             tape.defer_wgrad(('c4', id(holder)), g, s, None, 0, post, phased=(ci, ops.TAPS_12, ops.TAPS_01))
         if need_dx:
             pkd = _CACHE.get(holder, ('c4d',), _ver(w),
@@ -383,17 +382,21 @@ def upsample(tape, x, scale, up_mode, mul=1.0):
     return y
 
 
-def backward_warp(tape, x, flow, need_dimg=True, need_dflow=True):
+def backward_warp(tape, x, flow, need_dimg=True, need_dflow=True, dflow_out=None):
+    """`dflow_out`: a callable returning the buffer the flow gradient is written into (a slice of
+    a larger gradient tensor the caller owns, allocated when backward reaches it) instead of
+    the gradient being deposited on the tape."""
     y = ops.backward_warp(x, flow)
     if tape is not None and (need_dimg or need_dflow):
         def bwd():
             g = tape.pop_grad(y)
             if g is None:
                 return
-            dimg, dflow = ops.backward_warp_bwd(x, flow, g, need_dimg, need_dflow)
+            dimg, dflow = ops.backward_warp_bwd(x, flow, g, need_dimg, need_dflow,
+                                                dflow_out() if dflow_out is not None else None)
             if need_dimg:
                 tape.add_grad(x, dimg)
-            if need_dflow:
+            if need_dflow and dflow_out is None:
                 tape.add_grad(flow, dflow)
         tape.record(bwd)
     return y
@@ -451,7 +454,7 @@ def bn_lrelu(tape, bn, x, need_dx=True, sync=None):
     else:
         y, mean, invstd = ops.bn_lrelu_train_fwd(x, bn.weight, bn.bias, bn.running_mean,
                                                  bn.running_var)
-    bn.num_batches_tracked += 1
+    bn.count_pass() if hasattr(bn, 'count_pass') else bn.num_batches_tracked.add_(1)
     if tape is not None:
         def bwd():
             g = tape.pop_grad(y)

@@ -87,9 +87,7 @@ class VSRGANModel(VSRModel):
         bi_data = ops.upsample(lr_data.reshape(n * t, c, lr_h, lr_w).contiguous(), self.scale,
                                up_mode).view(n, t, c, gt_h, gt_w)
         if self.pp_crit is not None:        # ping-pong augmentation (:112-119)
-            lr_data = torch.cat([lr_data, lr_data.flip(1)[:, 1:]], dim=1).contiguous()
-            gt_data = torch.cat([gt_data, gt_data.flip(1)[:, 1:]], dim=1).contiguous()
-            bi_data = torch.cat([bi_data, bi_data.flip(1)[:, 1:]], dim=1).contiguous()
+            lr_data, gt_data, bi_data = ops.pingpong(lr_data), ops.pingpong(gt_data), ops.pingpong(bi_data)
 
         self.net_G.train()
         self.net_D.train()
@@ -112,8 +110,8 @@ class VSRGANModel(VSRModel):
         (fake_pred, _), _ = self.net_D(hr_data, d_in)        # no input grad: == hr_data.detach()
 
         n_clip = real_pred.numel()
-        st_real = torch.zeros(3, dtype=torch.float32, device=self.device)
-        st_fake = torch.zeros(3, dtype=torch.float32, device=self.device)
+        scal = torch.zeros(14, dtype=torch.float32, device=self.device)   # every scalar of the step
+        st_real, st_fake, st_g, losses = scal[0:3], scal[3:6], scal[6:9], scal[9:14]
         red = self.gan_crit[1]
         gsc = (1.0 / n_clip) if red == 'mean' else 1.0
         g_real = ops.bce_logits(real_pred, 1.0, st_real, 1.0 / n_clip, grad_scale=gsc)
@@ -138,7 +136,7 @@ class VSRGANModel(VSRModel):
         tape_D.nodes, tape_D.grads = [], {}
 
         # === generator ===
-        losses = torch.zeros(5, dtype=torch.float32, device=self.device)   # pix warp pp feat fm
+        # losses: pix warp pp feat fm
         if self.pix_crit is not None:
             w_ = opt_tr['pixel_crit'].get('weight', 1)
             tape_G.add_grad(hr_data, pointwise_loss(self.pix_crit, hr_data, gt_data, w_, losses[0:1]))
@@ -158,16 +156,11 @@ class VSRGANModel(VSRModel):
             del gt_feats
         if self.pp_crit is not None:
             te = opt_tr['tempo_extent']
-            hr_fw = hr_data[:, :te - 1].contiguous()
-            hr_bw = hr_data[:, te:].flip(1).contiguous()
+            hr_fw = ops.time_gather(hr_data, list(range(te - 1)))
+            hr_bw = ops.time_gather(hr_data, [2 * te - 2 - k for k in range(te - 1)])
             w_ = opt_tr['pingpong_crit'].get('weight', 1)
             g = pointwise_loss(self.pp_crit, hr_fw, hr_bw, w_, losses[2:3])
-            full = torch.zeros_like(hr_data)
-            full[:, :te - 1] = g
-            tape_G.add_grad(hr_data, full)
-            full2 = torch.zeros_like(hr_data)
-            full2[:, te:] = g.flip(1)
-            tape_G.add_grad(hr_data, self._neg(full2))
+            tape_G.add_grad(hr_data, ops.pingpong_grad(g, te))      # +g | 0 | -flip(g)
         # D's update lands here: the third D pass sees the UPDATED, frozen critic
         # (:201-202 after :188)
         if upd_D:
@@ -185,7 +178,6 @@ class VSRGANModel(VSRModel):
             for i, (ff, rf) in enumerate(zip(fake_feats, real_feats)):
                 tape_G.add_grad(ff, pointwise_loss(self.fm_crit, ff, rf, w_ / layer_norm[i],
                                                    losses[4:5]))
-        st_g = torch.zeros(3, dtype=torch.float32, device=self.device)
         gan_w = opt_tr['gan_crit'].get('weight', 1)
         tape_G.add_grad(fake_pred_G, ops.bce_logits(fake_pred_G, 1.0, st_g, 1.0 / n_clip,
                                                     grad_scale=gan_w * gsc))
@@ -194,7 +186,8 @@ class VSRGANModel(VSRModel):
         self.optim_G.step()
 
         # === logging: one host read of all scalars ===
-        sr, sf, sg, ls = st_real.tolist(), st_fake.tolist(), st_g.tolist(), losses.tolist()
+        sc_ = scal.tolist()
+        sr, sf, sg, ls = sc_[0:3], sc_[3:6], sc_[6:9], sc_[9:14]
         self.log_dict = OrderedDict()
         self.log_dict['l_gan_D'] = (sr[0] + sf[0]) if upd_D else 0.0
         self.log_dict['p_real_D'] = sr[1]
@@ -214,13 +207,6 @@ class VSRGANModel(VSRModel):
             self.log_dict['l_fm_G'] = ls[4]
         self.log_dict['l_gan_G'] = gan_w * sg[0]
         self.log_dict['p_fake_G'] = sg[1]
-
-    @staticmethod
-    def _neg(t):
-        """-t through the axpy kernel (y = 0 + (-1) * t)."""
-        out = torch.zeros_like(t)
-        ops.axpy_(out, t, -1.0)
-        return out
 
     def save(self, current_iter):
         self.save_network(self.net_G, 'G', current_iter)

@@ -413,11 +413,17 @@ def upsample_bwd(dy, scale, up_mode, mul=1.0):
     return dx
 
 
-def backward_warp_bwd(x, flow, dy, need_img=True, need_flow=True):
+def backward_warp_bwd(x, flow, dy, need_img=True, need_flow=True, dflow_out=None):
+    """`dflow_out`: write the flow gradient into this (contiguous, flow-shaped) buffer instead
+    of a new tensor (a slice of the frame-major gradient of the training unroll)."""
     _chk(x, 'x'); _chk(flow, 'flow'); _chk(dy, 'dy')
     n, c, h, w = x.shape
     dimg = torch.empty_like(x) if need_img else None
-    dflow = torch.empty_like(flow) if need_flow else None
+    if need_flow and dflow_out is not None:
+        dflow = _chk(dflow_out, 'dflow_out')
+        assert dflow.shape == flow.shape
+    else:
+        dflow = torch.empty_like(flow) if need_flow else None
     L.check(L.lib().tg_backward_warp_bwd(x.data_ptr(), flow.data_ptr(), dy.data_ptr(), _ptr(dimg),
                                          _ptr(dflow), n, c, h, w, _stream()), 'tg_backward_warp_bwd')
     return dimg, dflow
@@ -620,3 +626,94 @@ def sync_bn_lrelu_train_bwd(x, y, dy, gamma, mean, invstd, count, dgamma=None, d
                                           float(slope), 1.0 / count, dx.data_ptr(), n, c, h * w,
                                           _stream()), 'tg_bn_lrelu_bwd_apply')
     return dx
+
+
+# ---- data movement of the training step (tg_assemble.hip) ---------------------------------
+def time_gather(x, idx):
+    """x (n, t, ...) -> (n, len(idx), ...) with out[:, k] = x[:, idx[k]] (one launch)."""
+    import ctypes
+    _chk(x, 'x')
+    n, t = x.shape[:2]
+    inner = x[0, 0].numel()
+    out = torch.empty((n, len(idx)) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    arr = (ctypes.c_int * len(idx))(*[int(i) for i in idx])
+    L.check(L.lib().tg_time_gather(x.data_ptr(), out.data_ptr(), arr, n, t, len(idx), inner, _stream()),
+            'tg_time_gather')
+    return out
+
+
+def pingpong(x):
+    """cat([x, x.flip(1)[:, 1:]], 1) (vsrgan_model.py:112-119)."""
+    t = x.shape[1]
+    return time_gather(x, list(range(t)) + list(range(t - 2, -1, -1)))
+
+
+def pingpong_grad(g, te):
+    """Ping-pong loss gradient g (n, te-1, ...) -> (n, 2*te-1, ...): +g | 0 | -flip(g)."""
+    _chk(g, 'g')
+    n = g.shape[0]
+    inner = g[0, 0].numel()
+    out = torch.empty((n, 2 * te - 1) + tuple(g.shape[2:]), dtype=torch.float32, device=g.device)
+    L.check(L.lib().tg_pingpong_grad(g.data_ptr(), out.data_ptr(), n, te, inner, _stream()), 'tg_pingpong_grad')
+    return out
+
+
+def d_assemble_fwd(data, warped, cond, t, pad, crop):
+    """Discriminator input (n*t/3, 9c, h, w) from data (n, T, c, h, w), warped (n*t, c, h, w),
+    cond (n, T', c, h, w)."""
+    _chk(data, 'data'); _chk(warped, 'warped'); _chk(cond, 'cond')
+    n, t_data, c, h, w = data.shape
+    x = torch.empty(n * t // 3, 9 * c, h, w, dtype=torch.float32, device=data.device)
+    L.check(L.lib().tg_d_assemble_fwd(data.data_ptr(), t_data, warped.data_ptr(), cond.data_ptr(),
+                                      cond.shape[1], x.data_ptr(), n, t, c, h, w, pad, crop, _stream()),
+            'tg_d_assemble_fwd')
+    return x
+
+
+def d_assemble_bwd(g, n, t, t_data, c, pad, crop):
+    """-> (g_data (n, t_data, c, h, w), g_warped (n*t, c, h, w))."""
+    _chk(g, 'g')
+    h, w = g.shape[2:]
+    g_data = torch.empty(n, t_data, c, h, w, dtype=torch.float32, device=g.device)
+    g_warped = torch.empty(n * t, c, h, w, dtype=torch.float32, device=g.device)
+    L.check(L.lib().tg_d_assemble_bwd(g.data_ptr(), g_data.data_ptr(), t_data, g_warped.data_ptr(), n, t, c,
+                                      h, w, pad, crop, _stream()), 'tg_d_assemble_bwd')
+    return g_data, g_warped
+
+
+def transpose01(x):
+    """(a, b, ...) -> (b, a, ...) contiguous (clip-major <-> frame-major), one launch."""
+    _chk(x, 'x')
+    a, b = x.shape[:2]
+    y = torch.empty((b, a) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_transpose01(x.data_ptr(), y.data_ptr(), a, b, x[0, 0].numel(), _stream()),
+            'tg_transpose01')
+    return y
+
+
+def stack_time(frames):
+    """torch.stack(frames, dim=1) of k <= 64 contiguous (n, ...) tensors, one launch."""
+    import ctypes
+    for f in frames:
+        _chk(f, 'frame')
+    n = frames[0].shape[0]
+    y = torch.empty((n, len(frames)) + tuple(frames[0].shape[1:]), dtype=torch.float32,
+                    device=frames[0].device)
+    arr = (ctypes.c_void_p * len(frames))(*[f.data_ptr() for f in frames])
+    L.check(L.lib().tg_stack_time(arr, len(frames), y.data_ptr(), n, frames[0][0].numel(), _stream()),
+            'tg_stack_time')
+    return y
+
+
+def index_gather(src, idx, out=None, accumulate=False):
+    """out.flat[i] (+)= src.flat[idx[i]] (0 where idx[i] is out of range); idx int64 on device."""
+    _chk(src, 'src'); _chk(idx, 'idx', torch.int64)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(idx.numel(), dtype=torch.float32, device=src.device)
+    else:
+        _chk(out, 'out')
+        assert out.numel() == idx.numel()
+    L.check(L.lib().tg_index_gather(src.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(),
+                                    src.numel(), int(accumulate), _stream()), 'tg_index_gather')
+    return out

@@ -334,3 +334,75 @@ def test_strided_conv_embeddings_with_phase_restricted_taps(ops, ci, co, hw):
     assert err(tape.grad(xtd), xtr.grad) <= 2e-4 * max(1.0, xtr.grad.abs().max().item())
     assert err(layer.weight.grad, wtr.grad) <= 3e-4 * max(1.0, wtr.grad.abs().max().item())
     assert err(layer.bias.grad, btr.grad) <= 3e-4 * max(1.0, btr.grad.abs().max().item())
+
+
+def test_time_gather_pingpong_and_its_gradient(ops):
+    """tg_time_gather / tg_pingpong_grad against the ATen slice / flip / cat chains they
+    replace (vsrgan_model.py:112-119, :246-247) — bit-exact, they only move data."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 10, 3, 8, 12, generator=g).cuda()
+    assert torch.equal(ops.pingpong(x), torch.cat([x, x.flip(1)[:, 1:]], 1))
+    te = 10
+    pp = ops.pingpong(x)                                 # (2, 19, ...)
+    assert torch.equal(ops.time_gather(pp, list(range(te - 1))), pp[:, :te - 1])
+    assert torch.equal(ops.time_gather(pp, [2 * te - 2 - k for k in range(te - 1)]), pp[:, te:].flip(1))
+    z = ops.time_gather(x, [3, -1, 0])
+    assert torch.equal(z[:, 0], x[:, 3]) and torch.equal(z[:, 2], x[:, 0]) and not z[:, 1].any()
+    gg = torch.randn(2, te - 1, 3, 8, 12, generator=g).cuda()
+    want = torch.zeros(2, 2 * te - 1, 3, 8, 12, device='cuda')
+    want[:, :te - 1] = gg
+    want[:, te:] = -gg.flip(1)
+    assert torch.equal(ops.pingpong_grad(gg, te), want)
+    # and it IS the gradient: d/d(pp) sum(w * (pp[:, :te-1] - pp[:, te:].flip(1)))
+    ppr = pp.clone().requires_grad_(True)
+    ((ppr[:, :te - 1] - ppr[:, te:].flip(1)) * gg).sum().backward()
+    assert torch.equal(ppr.grad, want)
+
+
+@pytest.mark.parametrize('t_data,pad,crop', [(7, 2, 12), (6, 0, 16)])
+def test_discriminator_input_assembly_and_adjoint(ops, t_data, pad, crop):
+    """tg_d_assemble_fwd / _bwd against the reference's view / permute / pad / cat chain
+    (tecogan_nets.py:440-463) and its autograd adjoint."""
+    g = torch.Generator().manual_seed(5)
+    n, t, c, H, W = 2, 6, 3, 16, 16
+    data = torch.randn(n, t_data, c, H, W, generator=g).cuda().requires_grad_(True)
+    warped = torch.randn(n * t, c, H, W, generator=g).cuda().requires_grad_(True)
+    cond = torch.randn(n, t_data, c, H, W, generator=g).cuda()
+    nclip = n * t // 3
+
+    def trip(x):
+        return x.reshape(nclip, 3, c, H, W).permute(0, 2, 1, 3, 4).reshape(nclip, 3 * c, H, W)
+    wc = trip(warped)[:, :, pad:pad + crop, pad:pad + crop]
+    wc = F.pad(wc, (pad, W - pad - crop, pad, H - pad - crop))
+    want = torch.cat([trip(data[:, :t].reshape(n * t, c, H, W)), wc,
+                      trip(cond[:, :t].reshape(n * t, c, H, W))], 1)
+    got = ops.d_assemble_fwd(data.detach(), warped.detach(), cond, t, pad, crop)
+    assert torch.equal(got, want)
+    gy = torch.randn(want.shape, generator=g).cuda()
+    want.backward(gy)
+    g_data, g_warped = ops.d_assemble_bwd(gy, n, t, t_data, c, pad, crop)
+    assert torch.equal(g_data, data.grad) and torch.equal(g_warped, warped.grad)
+
+
+def test_transpose01_and_stack_time(ops):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 5, 2, 4, 8, generator=g).cuda()
+    assert torch.equal(ops.transpose01(x), x.transpose(0, 1).contiguous())
+    frames = [torch.randn(3, 2, 4, 8, generator=g).cuda() for _ in range(7)]
+    assert torch.equal(ops.stack_time(frames), torch.stack(frames, 1))
+
+
+def test_index_gather_applies_the_embedding_tables(ops):
+    from tecogan_pytorch_amd.models import train_graph as TG
+    g = torch.Generator().manual_seed(4)
+    for kind, shape in (('convt', (6, 4, 3, 3)), ('conv4', (7, 5, 4, 4))):
+        w = torch.randn(shape, generator=g).cuda()
+        fwd, inv = TG._embed_index(kind, shape[0], shape[1], w.device)
+        flat = torch.cat([w.reshape(-1), w.new_zeros(1)])
+        want = flat.index_select(0, fwd).view(shape[0], 4 * shape[1], 3, 3)
+        got = (TG._convt_embed if kind == 'convt' else TG._conv4_embed)(w)
+        assert torch.equal(got, want)
+        acc = torch.randn(shape, generator=g).cuda()
+        want_acc = acc + want.reshape(-1).index_select(0, inv).view(shape)
+        ops.index_gather(want, inv, out=acc, accumulate=True)
+        assert torch.equal(acc, want_acc) and torch.equal(want.reshape(-1).index_select(0, inv).view(shape), w)

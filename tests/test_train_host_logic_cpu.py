@@ -15,10 +15,19 @@ def rs(seed, shape):
     return torch.from_numpy(np.random.RandomState(seed).uniform(-1, 1, shape).astype(np.float32))
 
 
+def _embed_on_host(kind, w):
+    """Applies the product's slot table (TG._embed_index) with torch on the CPU; the product applies
+    the same table with tg_index_gather on the GPU (tests/test_hip_train_ops.py checks that)."""
+    a, b = w.shape[:2]
+    fwd, _ = TG._embed_index(kind, a, b, w.device)
+    flat = torch.cat([w.reshape(-1), w.new_zeros(1)])
+    return flat.index_select(0, fwd).view(a, 4 * b, 3, 3)
+
+
 def test_conv4x4s2_equals_conv3x3_on_space_to_depth():
     x, w = rs(1, (2, 5, 12, 16)), rs(2, (7, 5, 4, 4))
     ref = F.conv2d(x, w, None, stride=2, padding=1)
-    we = TG._conv4_embed(w)
+    we = _embed_on_host('conv4', w)
     assert we.shape == (7, 20, 3, 3)
     out = F.conv2d(O.space_to_depth(x, 2), we, None, padding=1)
     assert (out - ref).abs().max() <= 1e-5
@@ -33,7 +42,7 @@ def test_convt_data_gradient_equals_conv3x3_on_space_to_depth():
     y = F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1)
     dy = rs(3, tuple(y.shape))
     y.backward(dy)
-    we = TG._convt_embed(w)
+    we = _embed_on_host('convt', w)
     assert we.shape == (6, 16, 3, 3)
     dx = F.conv2d(O.space_to_depth(dy, 2), we, None, padding=1)
     assert (dx - x.grad).abs().max() <= 1e-5
