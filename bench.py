@@ -295,6 +295,13 @@ def warp_batched_roofline(dev, h, w, scale, deg, clips=8, reps=48):
                     'events; same kernel as roofline_warp' % nsets}
 
 
+def _barrier(dist, local_rank):
+    if dist.get_backend() == 'nccl':
+        dist.barrier(device_ids=[local_rank])
+    else:
+        dist.barrier()
+
+
 def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
     """BASELINE configs[3] (and configs[2] at N = 1): the full TecoGAN training step --
     prepare_training_data (on-device BD) + VSRGANModel.train() (G forward/BPTT, 3 D passes,
@@ -335,7 +342,7 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
         for i in range(warm):
             m.prepare_training_data(data[i % 2]); m.train()
         if dist_on:
-            dist.barrier(device_ids=[local_rank])
+            _barrier(dist, local_rank)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         nupd = 0
@@ -403,8 +410,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        # Rehearsal switch for a one-GPU box (tools/rehearse_multi_gpu.sh): TG_BENCH_REHEARSAL=1 puts
+        # every rank on cuda:0 and exchanges through gloo (host staged), which walks every N > 1
+        # code path of this file except RCCL itself.  Never set by the driver.
+        if os.environ.get('TG_BENCH_REHEARSAL') == '1':
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend='gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local_rank if dist_on else 0)
@@ -429,7 +444,7 @@ def main():
 
     def barrier():
         if dist_on:
-            dist.barrier(device_ids=[local_rank])
+            _barrier(dist, local_rank)
 
     # ---- headline: clip inference (FRNet.infer_sequence) ------------------------------
     # a K-frame synthetic LR clip, resident in HBM; true recurrence (hr_prev = previous
@@ -632,7 +647,7 @@ def main():
             result['cpu_baseline'] = None
         print(json.dumps(result), flush=True)
     if dist_on:
-        dist.barrier(device_ids=[local_rank])
+        _barrier(dist, local_rank)
         dist.destroy_process_group()
 
 
