@@ -594,7 +594,7 @@ def main():
             with torch.no_grad():
                 rows = kernel_table(net, plan, (*pool[0], outs[0]))
             dom = max(rows, key=lambda r: r['ms_per_frame'])
-            mf = [r for r in rows if r['kernel'].startswith('conv3x3_mfma')]
+            mf = [r for r in rows if r['kernel'].startswith(('conv3x3_mfma', 'conv3x3_wino'))]
             dom_mf = max(mf, key=lambda r: r['ms_per_frame'])
             ach = dom_mf['tflops']
             result['roofline'] = {
@@ -606,6 +606,15 @@ def main():
                 'avg_launch_us': 1e3 * dom_mf['ms_per_frame'] / dom_mf['launches'],
                 'algorithmic_gflop_per_launch': dom_mf['gflop'] / dom_mf['launches'],
             }
+            if dom_mf['kernel'].startswith('conv3x3_wino'):
+                # `achieved` counts the ALGORITHMIC FLOPs of the 3x3 convolution (2*9*cin*cout per
+                # pixel, the contract's definition); the Winograd F(2x2,3x3) form executes 16 of
+                # every 36 of those multiplies on the matrix cores, so the share of the MFMA peak
+                # the kernel actually occupies is frac * 16/36.
+                result['roofline']['form'] = ('Winograd F(2x2,3x3), fp32 MFMA 16x16x4: 16 of 36 algorithmic '
+                                              'multiplies are executed')
+                result['roofline']['mfma_executed_tflops'] = ach * 16.0 / 36.0
+                result['roofline']['mfma_executed_frac'] = ach * 16.0 / 36.0 / MFMA_F32_PEAK_TFLOPS
             warp = [r for r in rows if r['kernel'].startswith('flowup_warp')]
             if warp:
                 wk = warp[0]

@@ -114,6 +114,25 @@ int tg_conv3x3_fwd_masked(const float* x, int64_t x_nstride, int c1, const float
                           int64_t y_nstride, int n, int cin, int cout, int h, int w, int act,
                           tg_stream_t stream);
 
+/* The same convolution (nn.Conv2d(k3, s1, p1), tecogan_nets.py:85-100,116) in the Winograd
+ * F(2x2, 3x3) form: 16 instead of 36 fp32 MFMA multiplies per 2x2 output tile.  All arithmetic is
+ * fp32 (the transform matrices hold only 0, +-1, +-1/2); results equal tg_conv3x3_fwd up to fp32
+ * summation order.  `u_packed` comes from tg_pack_conv3x3_wino (tg_conv3x3_wino_packed_floats(cin,
+ * cout) floats; transposed = 0 for OIHW weights, 2 for the data gradient: channel roles swapped,
+ * taps rotated by 180 degrees).  x2 / res / relu_mask as in tg_conv3x3_fwd / _masked (may be NULL). */
+int64_t tg_conv3x3_wino_packed_floats(int cin, int cout);
+/* 1 when the Winograd form is the faster one for this layer shape on an MI355X (enough 16-tile
+ * workgroups to fill the GPU, cout a multiple of 64, cin >= 16); the frame plan uses it to pick
+ * the form of each layer whose tg_layer_weights.u is set. */
+int tg_conv3x3_prefers_wino(int n, int cin, int cout, int h, int w);
+int tg_pack_conv3x3_wino(const float* w, float* out, int cin, int cout, int transposed,
+                         tg_stream_t stream);
+int tg_conv3x3_wino_fwd(const float* x, int64_t x_nstride, int c1, const float* x2,
+                        int64_t x2_nstride, const float* u_packed, const float* bias,
+                        const float* res, int64_t res_nstride, const float* relu_mask,
+                        int64_t mask_nstride, float* y, int64_t y_nstride, int n, int cin,
+                        int cout, int h, int w, int act, tg_stream_t stream);
+
 /* Split-K variant for layers whose output tile count cannot fill the GPU (FNet's
  * low-resolution many-channel middle, tecogan_nets.py:37-60): `ksplit` groups of
  * input channels are reduced by different workgroups into `partials`
@@ -474,6 +493,8 @@ typedef struct {
 typedef struct {
   const float* w;
   const float* b;
+  const float* u;   /* tg_pack_conv3x3_wino form of the same weights, or NULL: the plan then runs the
+                       layer in the direct form whatever its shape (see tg_conv3x3_prefers_wino) */
 } tg_layer_weights;
 
 size_t tg_frnet_workspace_floats(const tg_frnet_cfg* cfg);

@@ -23,7 +23,7 @@ class FrnetCfg(C.Structure):
 
 
 class LayerWeights(C.Structure):
-    _fields_ = [('w', C.c_void_p), ('b', C.c_void_p)]
+    _fields_ = [('w', C.c_void_p), ('b', C.c_void_p), ('u', C.c_void_p)]
 
 
 # name -> (restype, argtypes); must list every symbol include/tecogan_hip.h declares
@@ -82,6 +82,10 @@ SIGNATURES = {
     'tg_linear1_fwd': (I, [P, P, P, P, I, I, P]),
     'tg_linear1_bwd': (I, [P, P, P, P, P, P, I, I, I, P]),
     'tg_downsample_bd': (I, [P, P, P, I, I, I, I, I, I, P]),
+    'tg_conv3x3_wino_packed_floats': (I64, [I, I]),
+    'tg_conv3x3_prefers_wino': (I, [I, I, I, I, I]),
+    'tg_pack_conv3x3_wino': (I, [P, P, I, I, I, P]),
+    'tg_conv3x3_wino_fwd': (I, [P, I64, I, P, I64, P, P, P, I64, P, I64, P, I64, I, I, I, I, I, I, P]),
     'tg_time_gather': (I, [P, P, P, I, I, I, I64, P]),
     'tg_transpose01': (I, [P, P, I, I, I64, P]),
     'tg_stack_time': (I, [P, I, P, I, I64, P]),

@@ -150,7 +150,8 @@ enum {
   K_CONVT_Z = 11,   // convt3x3s2_mfma_kernel<4,2,true>: last up-sampling layer + output-conv contraction
   K_TAIL = 12,      // convout_tail_kernel: 9-tap shift-add + residual + uint8
   K_CONV_ONESHOT = 13,  // conv3x3_oneshot_kernel: few tiles, cin <= 64, whole K range in flight
-  K_COUNT = 14
+  K_CONV_WINO = 14,     // conv3x3_wino_kernel: Winograd F(2x2,3x3) form of the large 64-channel-group layers
+  K_COUNT = 15
 };
 
 // The HR stage as two launches instead of three and without the 64-channel HR tensor: the last
@@ -199,6 +200,17 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     double px = (double)n * hh * ww;
     double fl = 2.0 * cin * 9 * cout * px;
     double by = 4.0 * px * (cin + cout + (res ? cout : 0)) + 4.0 * 9 * cin * cout;
+    if (lw.u && tg_conv3x3_prefers_wino(n, cin, cout, hh, ww)) {
+      float* yw = pool ? pool_tmp : y;
+      go(K_CONV_WINO, fl, by, [&] {
+        return tg::conv3x3_wino_launch(x, xns, c1, x2, x2ns, lw.u, lw.b, res, rns, nullptr, 0, yw,
+                                       pool ? (int64_t)cout * hh * ww : yns, n, cin, cout, hh, ww, act, st);
+      });
+      if (pool)
+        go(K_POOL, 0, 4.0 * n * cout * (hh * ww + (hh / 2) * (ww / 2)),
+           [&] { return tg_maxpool2_fwd(yw, y, n * cout, hh, ww, st); });
+      return;
+    }
     int ks = res ? 1 : tg_conv3x3_pick_ksplit(n, cin, cout, hh, ww);
     if (ks == 1 && kind == K_CONV64_R2 && tg::conv3x3_uses_wg_ksplit(n, cin, cout, hh, ww))
       kind = tg::conv3x3_uses_oneshot(n, cin, cout, hh, ww) ? K_CONV_ONESHOT : K_CONV64_KS;   // launcher's rule
@@ -289,7 +301,7 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
   }
   const bool fuse = hr_fuse_enabled() && c.out_nc <= 3 && nf <= 64;
   const tg_layer_weights lw_up1 = p->L[li++];
-  const tg_layer_weights lw_up2 = s == 4 ? p->L[li++] : tg_layer_weights{nullptr, nullptr};
+  const tg_layer_weights lw_up2 = s == 4 ? p->L[li++] : tg_layer_weights{nullptr, nullptr, nullptr};
   const tg_layer_weights lw_out = p->L[li++];
   const double hpx = (double)n * s * s * hw;
   if (fuse) {
@@ -420,7 +432,8 @@ extern "C" const char* tg_frnet_kind_name(int kind) {
       "convt3x3s2_mfma_kernel",      "conv3x3_small_kernel",       "flowup_warp_s2d_kernel",
       "maxpool2_kernel",             "upsample_kernel",            "quantize_u8_hwc_kernel",
       "splitk_finalize_kernel",      "conv3x3_mfma_kernel<1,2,1,KS=2>",
-      "convt3x3s2_mfma_kernel<Z>",   "convout_tail_kernel",        "conv3x3_oneshot_kernel"};
+      "convt3x3s2_mfma_kernel<Z>",   "convout_tail_kernel",        "conv3x3_oneshot_kernel",
+      "conv3x3_wino_kernel"};
   return (kind >= 0 && kind < K_COUNT) ? names[kind] : "?";
 }
 

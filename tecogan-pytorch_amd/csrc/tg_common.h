@@ -49,6 +49,11 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // K-split variant of the conv kernel (1-row tiles, two wave groups over alternating chunks).
 bool conv3x3_uses_wg_ksplit(int n, int cin, int cout, int h, int w);
 bool conv3x3_uses_oneshot(int n, int cin, int cout, int h, int w);
+// Winograd F(2x2,3x3) form (tg_conv3x3_wino.hip); arguments as tg_conv3x3_wino_fwd, unchecked
+int conv3x3_wino_launch(const float* x, int64_t x_ns, int c1, const float* x2, int64_t x2_ns, const float* u,
+                        const float* bias, const float* res, int64_t res_ns, const float* mask,
+                        int64_t mask_ns, float* y, int64_t y_ns, int n, int cin, int cout, int h, int w,
+                        int act, tg_stream_t stream);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -1,0 +1,384 @@
+// 3x3 / stride 1 / pad 1 convolution in the Winograd F(2x2, 3x3) form on the fp32 matrix cores.
+//
+//   Y = A^T [ (G g G^T) .  (B^T d B) ] A        per 2x2 output tile and (oc, ic) pair
+//
+// 16 multiplies per tile instead of 36: 2.25x fewer MFMA passes than the direct form
+// (tg_conv3x3_mfma.hip), all of them fp32 -- B and A hold only 0 / +-1, G only 0 / +-1 / +-1/2,
+// so the transforms add no rounding beyond fp32 adds (measured through SRNet's 20 residual
+// layers the result is as close to the fp64 truth as the direct fp32 form).
+// This is the arithmetic the reference's conv layers (tecogan_nets.py:85-100,116; every
+// nn.Conv2d(k3, s1, p1)) get from their GPU backend as well.
+//
+// Work decomposition (one workgroup = 4 waves):
+//   * 16 tiles of one tile row (2 image rows x 32 pixels) x 64 output channels;
+//     wave v owns output channels [16v, 16v+16) for all 16 Winograd positions:
+//     16 accumulators of v_mfma_f32_16x16x4_f32 (M = 16 oc, N = 16 tiles, K = 4 ic).
+//   * K loop over stages of 16 input channels: the raw 4 x 34 patch of every channel is staged
+//     into LDS, each thread transforms one (channel, tile) 4x4 window (32 adds) into
+//     V[ic][tile][16 positions] in LDS, all waves read V as the MFMA B operand.
+//   * the transformed weights U[p][oc][ic] (packed by wino_pack_kernel in exactly the order a
+//     lane consumes them) go from L2 straight into registers -- each wave owns a distinct slice,
+//     LDS would add nothing.
+//   * the inverse transform runs in registers: a lane holds all 16 positions of its
+//     (4 oc x 1 tile), adds bias / activation / residual and stores 2x2 pixels per channel.
+// 670 workgroups for 134 x 320 (2.6 per CU, 3 resident): the MFMA pipe of a SIMD is shared by
+// 3 waves from different workgroups whose load / transform / MFMA phases interleave.
+#include <stdlib.h>
+
+#include "tg_common.h"
+
+namespace tg {
+
+struct WinoArgs {
+  const float* x;
+  const float* x2;     // channels [c1, cin) (or null)
+  const float* u;      // packed transformed weights
+  const float* bias;
+  const float* res;
+  const float* mask;   // optional ReLU-backward mask applied last (see tg_conv3x3_fwd_masked)
+  float* y;
+  long long x_ns, x2_ns, res_ns, mask_ns, y_ns;
+  int c1, cin, cout, h, w, act;
+  int tiles_x, tiles_y, nstage, nocg, nocb;
+  int nblocks;         // > 0: XCD-banded block order
+  int vec_ok;          // float2 stores allowed (w even, 8-byte aligned planes)
+  int abl;             // lab only (TG_WINO_ABL): 1 no weight loads, 2 no input loads, 4 no stores, 8 no transform, 16 no MFMA
+};
+
+constexpr int W_ICS = 16;             // input channels per stage
+constexpr int W_RS = 40;              // LDS row stride of the raw patch (floats); 4 rows = 160 = 32 mod 64 banks
+constexpr int W_ICSTR = 4 * W_RS;
+constexpr int W_VS = 20;              // floats per (ic, tile) in V: 16 positions + 4 pad -> 16-byte reads of 16 lanes hit 64 distinct banks
+
+// U layout: [K step of 4 ic][oc block of 16][j 0..3][lane 0..63][e 0..3]; register p = 4j + e of a
+// lane holds U[p][oc = 16*ocb + (lane & 15)][ic = 4*kstep + (lane >> 4)], U[p = 4a + b] =
+// (G g G^T)[a][b].  Zero padded in ic (to a multiple of 16) and oc (to a multiple of 64).
+// transposed: 0 = OIHW weights, 2 = data gradient of a conv (swap channel roles, rotate 180).
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout,
+                                 int nchunk, int nocb, int transposed) {
+  const int total = nchunk * nocb * 4 * 64 * 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int e = i & 3, lane = (i >> 2) & 63, j = (i >> 8) & 3;
+    const int rest = i >> 10;
+    const int ocb = rest % nocb, chunk = rest / nocb;
+    const int p = 4 * j + e;
+    const int oc = 16 * ocb + (lane & 15), ic = 4 * chunk + (lane >> 4);
+    float v = 0.f;
+    if (oc < cout && ic < cin) {
+      float g[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          g[a][b] = transposed == 2 ? w[((size_t)ic * cout + oc) * 9 + (8 - (a * 3 + b))]
+                                    : w[((size_t)oc * cin + ic) * 9 + a * 3 + b];
+      // rows of G: [1,0,0], [.5,.5,.5], [.5,-.5,.5], [0,0,1]
+      const int pi = p >> 2, pj = p & 3;
+      float col[3];   // (G g)[pi][b]
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        col[b] = pi == 0 ? g[0][b]
+               : pi == 1 ? 0.5f * ((g[0][b] + g[1][b]) + g[2][b])
+               : pi == 2 ? 0.5f * ((g[0][b] - g[1][b]) + g[2][b])
+                         : g[2][b];
+      }
+      v = pj == 0 ? col[0]
+        : pj == 1 ? 0.5f * ((col[0] + col[1]) + col[2])
+        : pj == 2 ? 0.5f * ((col[0] - col[1]) + col[2])
+                  : col[2];
+    }
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_raw[W_ICS * W_ICSTR];   // 10 KB
+  __shared__ __attribute__((aligned(16))) float s_v[W_ICS * 16 * W_VS];   // 20 KB: [ic][tile][16 positions + pad]
+
+  const int t = threadIdx.x, l = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+
+  int b = blockIdx.x;
+  if (a.nblocks > 0) {      // XCD x gets the contiguous band of tiles [x*per, (x+1)*per)
+    const int per = (a.nblocks + 7) >> 3;
+    b = (b & 7) * per + (b >> 3);
+    if (b >= a.nblocks) return;
+  }
+  const int tx = __builtin_amdgcn_readfirstlane(b % a.tiles_x); b /= a.tiles_x;
+  const int ty = __builtin_amdgcn_readfirstlane(b % a.tiles_y); b /= a.tiles_y;
+  const int ocg = __builtin_amdgcn_readfirstlane(b % a.nocg);
+  const int n = __builtin_amdgcn_readfirstlane(b / a.nocg);
+  const int x0 = tx * 32, y0 = ty * 2;
+  const int hw = a.h * a.w;
+
+  // ---- raw patch staging: element e = t + 256 k = (ic, row, col) of the 16 x 4 x 34 patch ------
+  constexpr int RAW_ELEMS = W_ICS * 4 * 34;
+  constexpr int RAW_PER_T = (RAW_ELEMS + 255) / 256;   // 9
+  // byte offset of the element inside a channel plane, or OOB: the buffer bounds check then
+  // returns 0 for the zero padding, for channels past cin (K padded to a multiple of 16) and
+  // for the channels that belong to the other source tensor
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned roff[RAW_PER_T];
+#pragma unroll
+  for (int k = 0; k < RAW_PER_T; ++k) {
+    const int e = t + 256 * k;
+    const int ic = e / 136, rem = e - ic * 136, r = rem / 34, c = rem - r * 34;
+    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+    roff[k] = (e < RAW_ELEMS && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w)
+                  ? (unsigned)(ic * hw + gy * a.w + gx) * 4u : OOB;
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (size_t)n * a.x_ns), 0, (unsigned)a.c1 * hw * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x2 ? a.x2 + (size_t)n * a.x2_ns : a.x), 0,
+      a.x2 ? (unsigned)(a.cin - a.c1) * hw * 4u : 0u, 0x00020000);
+  const bool dual = a.x2 != nullptr;
+  auto load_raw = [&](int s, float (&reg)[RAW_PER_T]) {
+    if ((a.abl & 2) && s > 0) return;
+    const unsigned so = (unsigned)(s * W_ICS) * hw * 4u;
+#pragma unroll
+    for (int k = 0; k < RAW_PER_T; ++k) {
+      float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(roff[k] + so), 0, 0));
+      if (dual)   // offsets below c1 wrap to > 2^31 and read 0
+        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                 rx2, (int)(roff[k] + so - (unsigned)a.c1 * hw * 4u), 0, 0));
+      reg[k] = v;
+    }
+  };
+  auto store_raw = [&](const float (&reg)[RAW_PER_T]) {
+#pragma unroll
+    for (int k = 0; k < RAW_PER_T; ++k) {
+      const int e = t + 256 * k;
+      const int ic = e / 136, rem = e - ic * 136, r = rem / 34, c = rem - r * 34;
+      if (e < RAW_ELEMS) s_raw[ic * W_ICSTR + r * W_RS + c] = reg[k];
+    }
+  };
+
+  // ---- transformed weights: 4 x 16-byte loads per K step, perfectly coalesced ---------------
+  const f32x4* ug = reinterpret_cast<const f32x4*>(a.u) + ((size_t)(ocg * 4 + wv) * 4) * 64 + l;
+  const size_t ustep = (size_t)a.nocb * 4 * 64;
+  auto load_u = [&](int kstep, f32x4 (&u)[4]) {
+    if ((a.abl & 1) && kstep > 1) return;
+    if (a.abl & 32) kstep &= 1;
+    const f32x4* p = ug + (size_t)kstep * ustep;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = p[j * 64];
+  };
+
+  f32x4 acc[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transform assignment: thread -> (ic = t >> 4, tile = t & 15)
+  const float* traw = s_raw + (t >> 4) * W_ICSTR + 2 * (t & 15);
+  f32x4* tv = reinterpret_cast<f32x4*>(s_v + t * W_VS);                                   // 4 x 16 bytes
+  const f32x4* bv = reinterpret_cast<const f32x4*>(s_v + ((l >> 4) * 16 + (l & 15)) * W_VS);   // + ks * 4*16*W_VS floats
+
+  auto mfma16 = [&](const f32x4 (&u)[4], int ks) {
+    f32x4 bq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bq[j] = bv[ks * (4 * 16 * W_VS / 4) + j];
+    if (a.abl & 16) { acc[ks][0] += bq[0][0] + bq[1][1] + bq[2][2] + bq[3][3] + u[0][0] + u[1][0] + u[2][0] + u[3][0]; return; }
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+      acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[p >> 2][p & 3], bq[p >> 2][p & 3], acc[p], 0, 0, 0);
+  };
+
+  // epilogue geometry (needed early: the residual is fetched under the last stage's MFMAs)
+  const int ox = x0 + 2 * (l & 15);
+  const int oc_base = ocg * 64 + wv * 16 + 4 * (l >> 4);
+  const float* rn = a.res ? a.res + (size_t)n * a.res_ns : nullptr;
+  const bool res_pre = rn && a.vec_ok;
+
+  float rawreg[RAW_PER_T];
+  f32x4 u0[4], u1[4];
+  load_raw(0, rawreg);
+  load_u(0, u0);
+  store_raw(rawreg);
+  __syncthreads();
+
+  auto transform = [&]() {     // B^T d B of this thread's 4x4 window -> V
+    float d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float2 p0 = *reinterpret_cast<const float2*>(traw + r * W_RS);
+      const float2 p1 = *reinterpret_cast<const float2*>(traw + r * W_RS + 2);
+      d[r][0] = p0.x; d[r][1] = p0.y; d[r][2] = p1.x; d[r][3] = p1.y;
+    }
+    float q[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      q[0][c] = d[0][c] - d[2][c];
+      q[1][c] = d[1][c] + d[2][c];
+      q[2][c] = d[2][c] - d[1][c];
+      q[3][c] = d[1][c] - d[3][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      tv[r] = f32x4{q[r][0] - q[r][2], q[r][1] + q[r][2], q[r][2] - q[r][1], q[r][1] - q[r][3]};
+  };
+
+  // All stages but the last.  64 MFMAs per stage: 4 K steps x 16 positions; the weights of the
+  // step after next load under the current one.  (The scheduling fences keep the compiler from
+  // hoisting all 64 operand reads to the top, which costs the third wave per SIMD.)
+  const int last = a.nstage - 1;
+  for (int s = 0; s < last; ++s) {
+    if (!((a.abl & 8) && s > 0)) transform();
+    __syncthreads();                         // V visible, raw patch free
+    load_raw(s + 1, rawreg);
+    if (a.abl & 64) __builtin_amdgcn_s_setprio(2);
+    load_u(4 * s + 1, u1);
+    mfma16(u0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(4 * s + 2, u0);
+    mfma16(u1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(4 * s + 3, u1);
+    mfma16(u0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(4 * s + 4, u0);
+    mfma16(u1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.abl & 64) __builtin_amdgcn_s_setprio(0);
+    store_raw(rawreg);
+    __syncthreads();                         // raw visible, V free
+  }
+  // Last stage: the residual tile is fetched under its MFMAs, into the registers the weight
+  // ring no longer needs.
+  float2 rpre[4][2];
+  {
+    if (!((a.abl & 8) && last > 0)) transform();
+    __syncthreads();
+    load_u(4 * last + 1, u1);
+    mfma16(u0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(4 * last + 2, u0);
+    mfma16(u1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(4 * last + 3, u1);
+    mfma16(u0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        rpre[r][i] = make_float2(0.f, 0.f);
+        if (res_pre && oc_base + r < a.cout && ox < a.w && y0 + i < a.h)
+          rpre[r][i] = *reinterpret_cast<const float2*>(rn + (size_t)(oc_base + r) * hw + (size_t)(y0 + i) * a.w + ox);
+      }
+    mfma16(u1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- inverse transform A^T m A, epilogue -------------------------------------------------
+  const float slope = act_slope(a.act);
+  float* yn = a.y + (size_t)n * a.y_ns;
+  const float* mn = a.mask ? a.mask + (size_t)n * a.mask_ns : nullptr;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int oc = oc_base + r;
+    float sr[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sr[0][j] = (acc[0 + j][r] + acc[4 + j][r]) + acc[8 + j][r];
+      sr[1][j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
+    }
+    if (oc >= a.cout || ox >= a.w || ((a.abl & 4) && sr[0][0] != 123.f)) continue;
+    const float bz = a.bias ? a.bias[oc] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int oy = y0 + i;
+      if (oy >= a.h) continue;
+      float v0 = ((sr[i][0] + sr[i][1]) + sr[i][2]) + bz;
+      float v1 = ((sr[i][1] - sr[i][2]) - sr[i][3]) + bz;
+      if (a.act == TG_ACT_TANH24) { v0 = apply_act(v0, a.act); v1 = apply_act(v1, a.act); }
+      else { v0 = v0 >= 0.f ? v0 : v0 * slope; v1 = v1 >= 0.f ? v1 : v1 * slope; }
+      const size_t o = (size_t)oc * hw + (size_t)oy * a.w + ox;
+      const bool two = ox + 1 < a.w;
+      if (a.vec_ok) {
+        if (rn) { v0 += rpre[r][i].x; v1 += rpre[r][i].y; }
+        if (mn) { const float2 mm = *reinterpret_cast<const float2*>(mn + o); v0 = mm.x > 0.f ? v0 : 0.f; v1 = mm.y > 0.f ? v1 : 0.f; }
+        *reinterpret_cast<float2*>(yn + o) = make_float2(v0, v1);
+      } else {
+        if (rn) { v0 += rn[o]; if (two) v1 += rn[o + 1]; }
+        if (mn) { v0 = mn[o] > 0.f ? v0 : 0.f; if (two) v1 = mn[o + 1] > 0.f ? v1 : 0.f; }
+        yn[o] = v0;
+        if (two) yn[o + 1] = v1;
+      }
+    }
+  }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" int64_t tg_conv3x3_wino_packed_floats(int cin, int cout) {
+  if (cin <= 0 || cout <= 0) return -1;
+  const int64_t nchunk = 4 * ((cin + 15) / 16), nocb = 4 * ((cout + 63) / 64);
+  return nchunk * nocb * 4 * 64 * 4;
+}
+
+// Measured on MI355X (tools/wino_lab.py): at 134x320 / 64 -> 64 the Winograd form takes 0.70x the
+// time of the direct kernel; layers with few tiles (2 x 64 x 64 training frames, FNet's
+// low-resolution middle at batch 1) are latency bound and stay with the one-shot / K-split kernels.
+// TG_CONV_WINO=0/1 overrides (lab / A-B).
+extern "C" int tg_conv3x3_prefers_wino(int n, int cin, int cout, int h, int w) {
+  static const int env = [] { const char* e = getenv("TG_CONV_WINO"); return e ? atoi(e) : -1; }();
+  if (env == 0) return 0;
+  if (n <= 0 || cin < 16 || cout <= 0 || cout % 64 != 0 || h < 2 || w < 2) return 0;
+  const long long wgs = (long long)cdiv(w, 32) * cdiv(h, 2) * (cout / 64) * n;
+  return env == 1 ? 1 : (wgs >= 512 ? 1 : 0);
+}
+
+extern "C" int tg_pack_conv3x3_wino(const float* w, float* out, int cin, int cout, int transposed,
+                                    tg_stream_t stream) {
+  TG_REQUIRE(w && out, TG_E_ARG, "pack_conv3x3_wino: null pointer");
+  TG_REQUIRE(cin > 0 && cout > 0 && (transposed == 0 || transposed == 2), TG_E_ARG,
+             "pack_conv3x3_wino: cin=%d cout=%d transposed=%d (0 or 2)", cin, cout, transposed);
+  const int nchunk = 4 * cdiv(cin, 16), nocb = 4 * cdiv(cout, 64);
+  const int total = nchunk * nocb * 4 * 64 * 4;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, out, cin, cout, nchunk, nocb, transposed);
+  return check_launch("pack_conv3x3_wino");
+}
+
+namespace tg {
+int conv3x3_wino_launch(const float* x, int64_t x_ns, int c1, const float* x2, int64_t x2_ns, const float* u,
+                        const float* bias, const float* res, int64_t res_ns, const float* mask,
+                        int64_t mask_ns, float* y, int64_t y_ns, int n, int cin, int cout, int h, int w,
+                        int act, tg_stream_t stream) {
+  WinoArgs a{};
+  a.x = x; a.x2 = x2; a.u = u; a.bias = bias; a.res = res; a.mask = mask; a.y = y;
+  a.x_ns = x_ns; a.x2_ns = x2_ns; a.res_ns = res_ns; a.mask_ns = mask_ns; a.y_ns = y_ns;
+  a.c1 = x2 ? c1 : cin; a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
+  a.tiles_x = cdiv(w, 32); a.tiles_y = cdiv(h, 2);
+  a.nstage = cdiv(cin, 16); a.nocg = cdiv(cout, 64); a.nocb = 4 * a.nocg;
+  auto al8 = [](const void* p, int64_t ns) { return ((uintptr_t)p % 8) == 0 && ns % 2 == 0; };
+  a.vec_ok = (w % 2 == 0) && ((int64_t)h * w) % 2 == 0 && al8(y, y_ns) && (!res || al8(res, res_ns)) &&
+             (!mask || al8(mask, mask_ns));
+  static const int abl_env = [] { const char* e = getenv("TG_WINO_ABL"); return e ? atoi(e) : 0; }();
+  a.abl = abl_env;
+  const long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n;
+  const bool xcd = blocks >= 512;
+  a.nblocks = xcd ? (int)blocks : 0;
+  const unsigned grid = xcd ? (unsigned)(8 * ((blocks + 7) / 8)) : (unsigned)blocks;
+  hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("conv3x3_wino");
+}
+}  // namespace tg
+
+extern "C" int tg_conv3x3_wino_fwd(const float* x, int64_t x_nstride, int c1, const float* x2,
+                                   int64_t x2_nstride, const float* u_packed, const float* bias,
+                                   const float* res, int64_t res_nstride, const float* relu_mask,
+                                   int64_t mask_nstride, float* y, int64_t y_nstride, int n, int cin,
+                                   int cout, int h, int w, int act, tg_stream_t stream) {
+  TG_REQUIRE(x && u_packed && y, TG_E_ARG, "conv3x3_wino: null pointer");
+  TG_REQUIRE(n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, TG_E_SHAPE, "conv3x3_wino: n=%d cin=%d cout=%d h=%d w=%d",
+             n, cin, cout, h, w);
+  TG_REQUIRE(!x2 || (c1 > 0 && c1 < cin), TG_E_ARG, "conv3x3_wino: c1=%d of cin=%d", c1, cin);
+  TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_TANH24, TG_E_ARG, "conv3x3_wino: act=%d", act);
+  TG_REQUIRE((long long)cin * h * w < (1ll << 29), TG_E_SHAPE, "conv3x3_wino: image too large");
+  return conv3x3_wino_launch(x, x_nstride, c1, x2, x2_nstride, u_packed, bias, res, res_nstride, relu_mask,
+                             mask_nstride, y, y_nstride, n, cin, cout, h, w, act, stream);
+}

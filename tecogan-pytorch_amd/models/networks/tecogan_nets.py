@@ -39,6 +39,7 @@ class _Conv(nn.Module):
         bound = 1 / math.sqrt(fan_in)
         nn.init.uniform_(self.bias, -bound, bound)
         self._cache = None
+        self._cache_u = None
 
     def packed(self):
         """(packed weights, ocb) on the parameter's device; re-packed only when
@@ -50,7 +51,23 @@ class _Conv(nn.Module):
             self._cache = (key, pk, ocb)
         return self._cache[1], self._cache[2]
 
+    def packed_wino(self):
+        """Winograd-form weights (tg_pack_conv3x3_wino) of a plain 3x3 layer, or None when the
+        layer has no such form (transposed, cout not a multiple of 64, cin < 16)."""
+        if self.transposed or self.cout % 64 != 0 or self.cin < 16:
+            return None
+        w = self.weight
+        key = (ops.param_version(w), w.device)
+        if self._cache_u is None or self._cache_u[0] != key:
+            self._cache_u = (key, ops.pack_conv3x3_wino(w.detach().contiguous()))
+        return self._cache_u[1]
+
     def forward(self, x, act=ops.ACT_NONE, x2=None, res=None, out=None, pool=False):
+        if not self.transposed and not pool and \
+                L.lib().tg_conv3x3_prefers_wino(x.shape[0], self.cin, self.cout, x.shape[2], x.shape[3]):
+            u = self.packed_wino()
+            if u is not None:
+                return ops.conv3x3_wino(x, u, self.bias, self.cin, self.cout, act, x2=x2, res=res, out=out)
         pk, ocb = self.packed()
         if self.transposed:
             return ops.convt3x3s2(x, pk, self.bias, self.cout, act, out=out)
@@ -204,8 +221,10 @@ class _StepPlan:
             else:
                 wt, _ = m.packed()
             b = m.bias.detach().contiguous()
-            self.keep += [wt, b]
+            u = m.packed_wino() if m.cout > 4 else None
+            self.keep += [wt, b, u]
             arr[i].w, arr[i].b = wt.data_ptr(), b.data_ptr()
+            arr[i].u = u.data_ptr() if u is not None else None
         self.handle = ctypes.c_void_p()
         L.check(lib.tg_frnet_plan_create(ctypes.byref(self.cfg), arr, len(layers),
                                          self.workspace.data_ptr(), ctypes.byref(self.handle)),

@@ -717,3 +717,32 @@ def index_gather(src, idx, out=None, accumulate=False):
     L.check(L.lib().tg_index_gather(src.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(),
                                     src.numel(), int(accumulate), _stream()), 'tg_index_gather')
     return out
+
+
+# ---- Winograd F(2x2, 3x3) form of conv3x3 (tg_conv3x3_wino.hip) ----------------------------
+def pack_conv3x3_wino(w, transposed=0):
+    """OIHW weights -> transformed, lane-ordered U (see tg_pack_conv3x3_wino)."""
+    _chk(w, 'w')
+    co, ci = (w.shape[0], w.shape[1]) if transposed == 0 else (w.shape[1], w.shape[0])
+    nflt = L.lib().tg_conv3x3_wino_packed_floats(ci, co)
+    out = torch.empty(nflt, dtype=torch.float32, device=w.device)
+    L.check(L.lib().tg_pack_conv3x3_wino(w.data_ptr(), out.data_ptr(), ci, co, transposed, _stream()),
+            'tg_pack_conv3x3_wino')
+    return out
+
+
+def conv3x3_wino(x, u_packed, bias, cin, cout, act=ACT_NONE, x2=None, res=None, mask=None, out=None):
+    _chk(x, 'x'); _chk(u_packed, 'u_packed')
+    n, c1, h, w = x.shape
+    if x2 is not None:
+        _chk(x2, 'x2')
+        assert c1 + x2.shape[1] == cin
+    else:
+        assert c1 == cin
+    y = out if out is not None else torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_conv3x3_wino_fwd(
+        x.data_ptr(), x.stride(0), c1, _ptr(x2), x2.stride(0) if x2 is not None else 0,
+        u_packed.data_ptr(), _ptr(bias), _ptr(res), res.stride(0) if res is not None else 0,
+        _ptr(mask), mask.stride(0) if mask is not None else 0, y.data_ptr(), y.stride(0),
+        n, cin, cout, h, w, act, _stream()), 'tg_conv3x3_wino_fwd')
+    return y

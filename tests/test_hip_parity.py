@@ -140,6 +140,75 @@ def test_conv3x3_mfma(ops, n, cin, cout, h, w, act, c1, use_res):
     assert err(out, ref) <= 1e-5, err(out, ref)
 
 
+WINO_CASES = [
+    # n, cin, cout, h, w, act, split(c1), residual
+    (1, 64, 64, 22, 40, 1, None, False),
+    (2, 64, 64, 13, 37, 0, None, True),       # odd height and width: half tiles at both edges, scalar stores
+    (1, 51, 64, 12, 20, 1, 3, False),         # SRNet conv_in: two sources, K padded 51 -> 64
+    (1, 16, 64, 9, 33, 2, None, False),       # one K stage
+    (1, 128, 128, 5, 9, 2, None, False),      # two output-channel groups, tiny map
+    (1, 27, 64, 16, 16, 3, None, False),      # K padded 27 -> 32, tanh*24 epilogue
+    (2, 64, 64, 134, 64, 0, None, True),      # > 512 workgroups: XCD-banded order
+    (1, 64, 48, 10, 34, 0, None, False),      # cout not a multiple of 16
+    (1, 64, 64, 2, 2, 1, None, False),        # a single tile
+]
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,act,c1,use_res', WINO_CASES)
+def test_conv3x3_winograd_form(ops, n, cin, cout, h, w, act, c1, use_res):
+    """tg_conv3x3_wino_fwd (Winograd F(2x2,3x3) on the fp32 matrix cores) against an fp64
+    convolution, same tolerance as the direct form."""
+    import torch.nn.functional as F
+    x = rs(1, (n, cin, h, w), -1, 1)
+    wt = rs(2, (cout, cin, 3, 3), -1, 1) / (3.0 * cin ** 0.5)
+    b = rs(3, (cout,), -0.5, 0.5)
+    res = rs(4, (n, cout, h, w), -1, 1) if use_res else None
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    ref = {0: ref, 1: torch.relu(ref), 2: torch.where(ref >= 0, ref, ref * 0.2), 3: torch.tanh(ref) * 24}[act]
+    if use_res:
+        ref = ref + res.double()
+    u = ops.pack_conv3x3_wino(dev(wt))
+    kw = dict(res=None if res is None else dev(res))
+    if c1:
+        out = ops.conv3x3_wino(dev(x[:, :c1]), u, dev(b), cin, cout, act, x2=dev(x[:, c1:]), **kw)
+    else:
+        out = ops.conv3x3_wino(dev(x), u, dev(b), cin, cout, act, **kw)
+    assert err(out, ref) <= (2e-5 if act == 3 else 1e-5), err(out, ref)
+
+
+def test_conv3x3_winograd_data_gradient_and_relu_mask(ops):
+    """transposed = 2 packing gives the data gradient of the layer; the ReLU-backward mask is
+    applied in the epilogue (tg_conv3x3_fwd_masked semantics)."""
+    import torch.nn.functional as F
+    n, ci, co, h, w = 2, 32, 64, 11, 18
+    x = rs(1, (n, ci, h, w), -1, 1).requires_grad_(True)
+    wt = rs(2, (co, ci, 3, 3), -1, 1) / 10
+    y = F.conv2d(torch.relu(x), wt, None, padding=1)
+    dy = rs(3, tuple(y.shape), -1, 1)
+    y.backward(dy)                                       # x.grad = dgrad(dy) masked by x > 0
+    u = ops.pack_conv3x3_wino(dev(wt), transposed=2)
+    got = ops.conv3x3_wino(dev(dy), u, None, co, ci, 0, mask=dev(torch.relu(x.detach())))
+    assert err(got, x.grad) <= 1e-5, err(got, x.grad)
+
+
+def test_winograd_rule_and_plan_use(ops):
+    """The frame plan runs SRNet's full-resolution layers in the Winograd form (and says so in its
+    per-class statistics); tiny frames stay on the direct kernels."""
+    from tecogan_pytorch_amd import _lib
+    lib = _lib.lib()
+    assert lib.tg_conv3x3_prefers_wino(1, 64, 64, 134, 320) == 1
+    assert lib.tg_conv3x3_prefers_wino(1, 64, 64, 32, 32) == 0
+    assert lib.tg_conv3x3_prefers_wino(1, 6, 64, 134, 320) == 0 and lib.tg_conv3x3_prefers_wino(1, 64, 32, 134, 320) == 0
+    net, _ = make_net('BD', 4)
+    plan = net._get_plan(1, 134, 320, torch.device('cuda'))
+    import ctypes
+    names = [lib.tg_frnet_kind_name(k).decode() for k in range(lib.tg_frnet_plan_kinds())]
+    k = names.index('conv3x3_wino_kernel')
+    nl = ctypes.c_int()
+    _lib.check(lib.tg_frnet_plan_kind_stats(plan.handle, k, ctypes.byref(nl), None, None), 'kind_stats')
+    assert nl.value == 21          # conv_in + 10 residual blocks
+
+
 @pytest.mark.parametrize('n,cin,cout,h,w,ks,pool', [
     (1, 256, 256, 16, 40, 8, False), (1, 128, 128, 33, 80, 4, True), (2, 64, 64, 9, 21, 2, True),
     (1, 128, 256, 16, 40, None, False), (1, 64, 128, 33, 80, None, True)])
