@@ -27,6 +27,11 @@
 
 #include "tg_common.h"
 
+#ifndef TG_WINO_LAB
+#define TG_WINO_LAB 0   // 1: ablation switches of tools/wino_abl.sh (TG_WINO_ABL) compiled in
+#endif
+#define WABL(bit) (TG_WINO_LAB && (a.abl & (bit)))
+
 namespace tg {
 
 struct WinoArgs {
@@ -42,7 +47,7 @@ struct WinoArgs {
   int tiles_x, tiles_y, nstage, nocg, nocb;
   int nblocks;         // > 0: XCD-banded block order
   int vec_ok;          // float2 stores allowed (w even, 8-byte aligned planes)
-  int abl;             // lab only (TG_WINO_ABL): 1 no weight loads, 2 no input loads, 4 no stores, 8 no transform, 16 no MFMA
+  int abl;             // lab builds only (TG_WINO_LAB, env TG_WINO_ABL): 1 no weight loads, 2 no input loads, 4 no stores, 16 no MFMA, 32 weights from L1
 };
 
 constexpr int W_ICS = 16;             // input channels per stage
@@ -93,7 +98,7 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 
 __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   __shared__ __attribute__((aligned(16))) float s_raw[W_ICS * W_ICSTR];   // 10 KB
-  __shared__ __attribute__((aligned(16))) float s_v[W_ICS * 16 * W_VS];   // 20 KB: [ic][tile][16 positions + pad]
+  __shared__ __attribute__((aligned(16))) float s_v[2 * W_ICS * 16 * W_VS];   // 2 x 20 KB: [buffer][ic][tile][16 positions + pad]
 
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
       a.x2 ? (unsigned)(a.cin - a.c1) * hw * 4u : 0u, 0x00020000);
   const bool dual = a.x2 != nullptr;
   auto load_raw = [&](int s, float (&reg)[RAW_PER_T]) {
-    if ((a.abl & 2) && s > 0) return;
+    if (WABL(2) && s > 0) return;
     const unsigned so = (unsigned)(s * W_ICS) * hw * 4u;
 #pragma unroll
     for (int k = 0; k < RAW_PER_T; ++k) {
@@ -158,8 +163,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   const f32x4* ug = reinterpret_cast<const f32x4*>(a.u) + ((size_t)(ocg * 4 + wv) * 4) * 64 + l;
   const size_t ustep = (size_t)a.nocb * 4 * 64;
   auto load_u = [&](int kstep, f32x4 (&u)[4]) {
-    if ((a.abl & 1) && kstep > 1) return;
-    if (a.abl & 32) kstep &= 1;
+    if (WABL(1) && kstep > 1) return;
+    if (WABL(32)) kstep &= 1;
     const f32x4* p = ug + (size_t)kstep * ustep;
 #pragma unroll
     for (int j = 0; j < 4; ++j) u[j] = p[j * 64];
@@ -170,18 +175,38 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   for (int p = 0; p < 16; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // transform assignment: thread -> (ic = t >> 4, tile = t & 15)
+  constexpr int VBUF4 = W_ICS * 16 * W_VS / 4;          // one V buffer in 16-byte units
   const float* traw = s_raw + (t >> 4) * W_ICSTR + 2 * (t & 15);
-  f32x4* tv = reinterpret_cast<f32x4*>(s_v + t * W_VS);                                   // 4 x 16 bytes
+  f32x4* tv = reinterpret_cast<f32x4*>(s_v + t * W_VS);                                        // 4 x 16 bytes per buffer
   const f32x4* bv = reinterpret_cast<const f32x4*>(s_v + ((l >> 4) * 16 + (l & 15)) * W_VS);   // + ks * 4*16*W_VS floats
 
-  auto mfma16 = [&](const f32x4 (&u)[4], int ks) {
+  auto mfma16 = [&](const f32x4 (&u)[4], int buf, int ks) {
     f32x4 bq[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bq[j] = bv[ks * (4 * 16 * W_VS / 4) + j];
-    if (a.abl & 16) { acc[ks][0] += bq[0][0] + bq[1][1] + bq[2][2] + bq[3][3] + u[0][0] + u[1][0] + u[2][0] + u[3][0]; return; }
+    for (int j = 0; j < 4; ++j) bq[j] = bv[buf * VBUF4 + ks * (4 * 16 * W_VS / 4) + j];
+    if (WABL(16)) { acc[ks][0] += bq[0][0] + bq[1][1] + bq[2][2] + bq[3][3] + u[0][0] + u[1][0] + u[2][0] + u[3][0]; return; }
 #pragma unroll
     for (int p = 0; p < 16; ++p)
       acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[p >> 2][p & 3], bq[p >> 2][p & 3], acc[p], 0, 0, 0);
+  };
+  // B^T d B of this thread's 4x4 window, two output rows per call (hp = 0: rows 0, 1 from raw
+  // rows 0..2; hp = 1: rows 2, 3 from raw rows 1..3) -> V[buf]
+  auto transform_half = [&](int buf, int hp) {
+    float d[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float2 p0 = *reinterpret_cast<const float2*>(traw + (r + hp) * W_RS);
+      const float2 p1 = *reinterpret_cast<const float2*>(traw + (r + hp) * W_RS + 2);
+      d[r][0] = p0.x; d[r][1] = p0.y; d[r][2] = p1.x; d[r][3] = p1.y;
+    }
+    float qa[4], qb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      qa[c] = hp == 0 ? d[0][c] - d[2][c] : d[1][c] - d[0][c];    // rows 0 / 2 of B^T d
+      qb[c] = hp == 0 ? d[1][c] + d[2][c] : d[0][c] - d[2][c];    // rows 1 / 3
+    }
+    tv[buf * VBUF4 + 2 * hp] = f32x4{qa[0] - qa[2], qa[1] + qa[2], qa[2] - qa[1], qa[1] - qa[3]};
+    tv[buf * VBUF4 + 2 * hp + 1] = f32x4{qb[0] - qb[2], qb[1] + qb[2], qb[2] - qb[1], qb[1] - qb[3]};
   };
 
   // epilogue geometry (needed early: the residual is fetched under the last stage's MFMAs)
@@ -190,73 +215,58 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   const float* rn = a.res ? a.res + (size_t)n * a.res_ns : nullptr;
   const bool res_pre = rn && a.vec_ok;
 
+  // ---- prologue: stage 0 transformed, stage 1's patch in LDS (not yet published) -------------
   float rawreg[RAW_PER_T];
   f32x4 u0[4], u1[4];
+  const int last = a.nstage - 1;
   load_raw(0, rawreg);
   load_u(0, u0);
   store_raw(rawreg);
   __syncthreads();
+  if (last > 0) load_raw(1, rawreg);
+  transform_half(0, 0);
+  transform_half(0, 1);
+  __syncthreads();                           // V[0] visible, raw patch free
+  if (last > 0) store_raw(rawreg);
 
-  auto transform = [&]() {     // B^T d B of this thread's 4x4 window -> V
-    float d[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float2 p0 = *reinterpret_cast<const float2*>(traw + r * W_RS);
-      const float2 p1 = *reinterpret_cast<const float2*>(traw + r * W_RS + 2);
-      d[r][0] = p0.x; d[r][1] = p0.y; d[r][2] = p1.x; d[r][3] = p1.y;
-    }
-    float q[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      q[0][c] = d[0][c] - d[2][c];
-      q[1][c] = d[1][c] + d[2][c];
-      q[2][c] = d[2][c] - d[1][c];
-      q[3][c] = d[1][c] - d[3][c];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      tv[r] = f32x4{q[r][0] - q[r][2], q[r][1] + q[r][2], q[r][2] - q[r][1], q[r][1] - q[r][3]};
-  };
-
-  // All stages but the last.  64 MFMAs per stage: 4 K steps x 16 positions; the weights of the
-  // step after next load under the current one.  (The scheduling fences keep the compiler from
-  // hoisting all 64 operand reads to the top, which costs the third wave per SIMD.)
-  const int last = a.nstage - 1;
+  // ---- main loop: the MFMAs of stage s (64 per wave: 4 K steps x 16 positions) run with the
+  // input transform of stage s+1 and the global loads of stage s+2 in their shadow; the weights
+  // of the K step after next load under the current one.  (The scheduling fences keep the
+  // compiler from hoisting all operand reads to the top, which costs the third wave per SIMD.)
   for (int s = 0; s < last; ++s) {
-    if (!((a.abl & 8) && s > 0)) transform();
-    __syncthreads();                         // V visible, raw patch free
-    load_raw(s + 1, rawreg);
-    if (a.abl & 64) __builtin_amdgcn_s_setprio(2);
+    const int cur = s & 1, nxt = cur ^ 1;
     load_u(4 * s + 1, u1);
-    mfma16(u0, 0);
+    mfma16(u0, cur, 0);
     __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                         // patch of stage s+1 visible
+    if (s + 2 <= last) load_raw(s + 2, rawreg);
     load_u(4 * s + 2, u0);
-    mfma16(u1, 1);
+    mfma16(u1, cur, 1);
+    transform_half(nxt, 0);
     __builtin_amdgcn_sched_barrier(0);
     load_u(4 * s + 3, u1);
-    mfma16(u0, 2);
+    mfma16(u0, cur, 2);
+    transform_half(nxt, 1);
     __builtin_amdgcn_sched_barrier(0);
     load_u(4 * s + 4, u0);
-    mfma16(u1, 3);
+    mfma16(u1, cur, 3);
     __builtin_amdgcn_sched_barrier(0);
-    if (a.abl & 64) __builtin_amdgcn_s_setprio(0);
-    store_raw(rawreg);
-    __syncthreads();                         // raw visible, V free
+    __syncthreads();                         // V[nxt] visible, V[cur] and the patch free
+    if (s + 2 <= last) store_raw(rawreg);
   }
-  // Last stage: the residual tile is fetched under its MFMAs, into the registers the weight
-  // ring no longer needs.
+  // ---- last stage: the residual tile is fetched under its MFMAs, into the registers the
+  // weight ring no longer needs
   float2 rpre[4][2];
   {
-    if (!((a.abl & 8) && last > 0)) transform();
-    __syncthreads();
+    const int cur = last & 1;
     load_u(4 * last + 1, u1);
-    mfma16(u0, 0);
+    mfma16(u0, cur, 0);
     __builtin_amdgcn_sched_barrier(0);
     load_u(4 * last + 2, u0);
-    mfma16(u1, 1);
+    mfma16(u1, cur, 1);
     __builtin_amdgcn_sched_barrier(0);
     load_u(4 * last + 3, u1);
-    mfma16(u0, 2);
+    mfma16(u0, cur, 2);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
         if (res_pre && oc_base + r < a.cout && ox < a.w && y0 + i < a.h)
           rpre[r][i] = *reinterpret_cast<const float2*>(rn + (size_t)(oc_base + r) * hw + (size_t)(y0 + i) * a.w + ox);
       }
-    mfma16(u1, 3);
+    mfma16(u1, cur, 3);
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
       sr[0][j] = (acc[0 + j][r] + acc[4 + j][r]) + acc[8 + j][r];
       sr[1][j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
     }
-    if (oc >= a.cout || ox >= a.w || ((a.abl & 4) && sr[0][0] != 123.f)) continue;
+    if (oc >= a.cout || ox >= a.w || (WABL(4) && sr[0][0] != 123.f)) continue;
     const float bz = a.bias ? a.bias[oc] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {

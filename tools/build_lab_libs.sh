@@ -16,3 +16,7 @@ for abl in 1 2 4 3; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libtecogan_warp_abl$abl.so $OBJS $OUT/tg_warp_abl$abl.o -ldl
 done
 ls -la $OUT/*.so
+# Winograd kernel with its ablation switches (TG_WINO_ABL): TECOGAN_HIP_LIB=tools/_lab_libs/libtecogan_wino_lab.so
+/opt/rocm/bin/hipcc $FLAGS -DTG_WINO_LAB=1 -c tg_conv3x3_wino.hip -o $OUT/tg_conv3x3_wino_lab.o
+OBJS=$(ls tg_*.o | grep -v tg_conv3x3_wino.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libtecogan_wino_lab.so $OBJS $OUT/tg_conv3x3_wino_lab.o -ldl

@@ -1,1 +1,3 @@
-for a in ${ABLS:-0 64 32}; do echo "ABL $a"; TG_WINO_ABL=$a bash tools/wino_prof.sh 134 320 64 64 2>&1 | grep -E "wino_kernel|err"; done
+# Ablations of the Winograd kernel (needs tools/build_lab_libs.sh first): kernel time with parts switched off
+export TECOGAN_HIP_LIB=$(pwd)/tools/_lab_libs/libtecogan_wino_lab.so
+for a in ${ABLS:-0 1 2 4 16 31}; do echo "ABL $a"; TG_WINO_ABL=$a bash tools/wino_prof.sh 134 320 64 64 2>&1 | grep -E "wino_kernel"; done
