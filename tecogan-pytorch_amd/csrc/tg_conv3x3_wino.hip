@@ -162,12 +162,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   // ---- transformed weights: 4 x 16-byte loads per K step, perfectly coalesced ---------------
   const f32x4* ug = reinterpret_cast<const f32x4*>(a.u) + ((size_t)(ocg * 4 + wv) * 4) * 64 + l;
   const size_t ustep = (size_t)a.nocb * 4 * 64;
-  auto load_u = [&](int kstep, f32x4 (&u)[4]) {
-    if (WABL(1) && kstep > 1) return;
+  const int ktotal = 4 * a.nstage;
+  // one half (positions 8*half .. 8*half+7) of the weights of K step `kstep`
+  auto load_uh = [&](int kstep, int half, f32x4 (&u)[4]) {
+    if (kstep >= ktotal || (WABL(1) && kstep > 1)) return;
     if (WABL(32)) kstep &= 1;
-    const f32x4* p = ug + (size_t)kstep * ustep;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) u[j] = p[j * 64];
+    const f32x4* p = ug + (size_t)kstep * ustep + half * 128;
+    u[2 * half] = p[0];
+    u[2 * half + 1] = p[64];
   };
 
   f32x4 acc[16];
@@ -180,14 +182,28 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   f32x4* tv = reinterpret_cast<f32x4*>(s_v + t * W_VS);                                        // 4 x 16 bytes per buffer
   const f32x4* bv = reinterpret_cast<const f32x4*>(s_v + ((l >> 4) * 16 + (l & 15)) * W_VS);   // + ks * 4*16*W_VS floats
 
-  auto mfma16 = [&](const f32x4 (&u)[4], int buf, int ks) {
-    f32x4 bq[4];
+  // 8 MFMAs: positions 8*half .. 8*half+7 of K step ks (B operand from V[buf])
+  auto mfma8 = [&](const f32x4 (&u)[4], int buf, int ks, int half) {
+    f32x4 bq[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bq[j] = bv[buf * VBUF4 + ks * (4 * 16 * W_VS / 4) + j];
-    if (WABL(16)) { acc[ks][0] += bq[0][0] + bq[1][1] + bq[2][2] + bq[3][3] + u[0][0] + u[1][0] + u[2][0] + u[3][0]; return; }
+    for (int j = 0; j < 2; ++j) bq[j] = bv[buf * VBUF4 + ks * (4 * 16 * W_VS / 4) + 2 * half + j];
+    if (WABL(16)) { acc[ks][0] += bq[0][0] + bq[1][1] + u[2 * half][0] + u[2 * half + 1][0]; return; }
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
-      acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[p >> 2][p & 3], bq[p >> 2][p & 3], acc[p], 0, 0, 0);
+    for (int p = 0; p < 8; ++p)
+      acc[8 * half + p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[2 * half + (p >> 2)][p & 3], bq[p >> 2][p & 3],
+                                                               acc[8 * half + p], 0, 0, 0);
+  };
+  // K step k of the running count (ks = k & 3 inside its stage): as soon as a half of its weight
+  // block has been consumed, the same half of K step k+2 is requested into it -- 1.5 K steps
+  // (24 MFMAs of this wave, ~3x that with three waves per SIMD) of distance on two blocks
+  auto kstep = [&](int k, f32x4 (&u)[4], int buf, auto&& between) {
+    mfma8(u, buf, k & 3, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_uh(k + 2, 0, u);
+    between();
+    mfma8(u, buf, k & 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_uh(k + 2, 1, u);
   };
   // B^T d B of this thread's 4x4 window, two output rows per call (hp = 0: rows 0, 1 from raw
   // rows 0..2; hp = 1: rows 2, 3 from raw rows 1..3) -> V[buf]
@@ -220,7 +236,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   f32x4 u0[4], u1[4];
   const int last = a.nstage - 1;
   load_raw(0, rawreg);
-  load_u(0, u0);
+  load_uh(0, 0, u0); load_uh(0, 1, u0);
+  load_uh(1, 0, u1); load_uh(1, 1, u1);
   store_raw(rawreg);
   __syncthreads();
   if (last > 0) load_raw(1, rawreg);
@@ -230,44 +247,28 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   if (last > 0) store_raw(rawreg);
 
   // ---- main loop: the MFMAs of stage s (64 per wave: 4 K steps x 16 positions) run with the
-  // input transform of stage s+1 and the global loads of stage s+2 in their shadow; the weights
-  // of the K step after next load under the current one.  (The scheduling fences keep the
-  // compiler from hoisting all operand reads to the top, which costs the third wave per SIMD.)
+  // input transform of stage s+1 and the global loads of stage s+2 in their shadow.  (The
+  // scheduling fences keep the compiler from hoisting all operand reads to the top, which
+  // would cost the third wave per SIMD.)
+  auto nothing = [] {};
   for (int s = 0; s < last; ++s) {
     const int cur = s & 1, nxt = cur ^ 1;
-    load_u(4 * s + 1, u1);
-    mfma16(u0, cur, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    kstep(4 * s + 0, u0, cur, nothing);
     __syncthreads();                         // patch of stage s+1 visible
     if (s + 2 <= last) load_raw(s + 2, rawreg);
-    load_u(4 * s + 2, u0);
-    mfma16(u1, cur, 1);
-    transform_half(nxt, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_u(4 * s + 3, u1);
-    mfma16(u0, cur, 2);
-    transform_half(nxt, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_u(4 * s + 4, u0);
-    mfma16(u1, cur, 3);
-    __builtin_amdgcn_sched_barrier(0);
+    kstep(4 * s + 1, u1, cur, [&] { transform_half(nxt, 0); });
+    kstep(4 * s + 2, u0, cur, [&] { transform_half(nxt, 1); });
+    kstep(4 * s + 3, u1, cur, nothing);
     __syncthreads();                         // V[nxt] visible, V[cur] and the patch free
     if (s + 2 <= last) store_raw(rawreg);
   }
-  // ---- last stage: the residual tile is fetched under its MFMAs, into the registers the
-  // weight ring no longer needs
+  // ---- last stage: the residual tile is fetched under its MFMAs
   float2 rpre[4][2];
   {
     const int cur = last & 1;
-    load_u(4 * last + 1, u1);
-    mfma16(u0, cur, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_u(4 * last + 2, u0);
-    mfma16(u1, cur, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_u(4 * last + 3, u1);
-    mfma16(u0, cur, 2);
-    __builtin_amdgcn_sched_barrier(0);
+    kstep(4 * last + 0, u0, cur, nothing);
+    kstep(4 * last + 1, u1, cur, nothing);
+    kstep(4 * last + 2, u0, cur, nothing);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -276,8 +277,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
         if (res_pre && oc_base + r < a.cout && ox < a.w && y0 + i < a.h)
           rpre[r][i] = *reinterpret_cast<const float2*>(rn + (size_t)(oc_base + r) * hw + (size_t)(y0 + i) * a.w + ox);
       }
-    mfma16(u1, cur, 3);
-    __builtin_amdgcn_sched_barrier(0);
+    kstep(4 * last + 3, u1, cur, nothing);
   }
 
   // ---- inverse transform A^T m A, epilogue -------------------------------------------------
@@ -370,7 +370,8 @@ int conv3x3_wino_launch(const float* x, int64_t x_ns, int c1, const float* x2, i
   static const int abl_env = [] { const char* e = getenv("TG_WINO_ABL"); return e ? atoi(e) : 0; }();
   a.abl = abl_env;
   const long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n;
-  const bool xcd = blocks >= 512;
+  static const int xcd_env = [] { const char* e = getenv("TG_WINO_XCD"); return e ? atoi(e) : -1; }();   // lab
+  const bool xcd = xcd_env >= 0 ? xcd_env != 0 : blocks >= 512;
   a.nblocks = xcd ? (int)blocks : 0;
   const unsigned grid = xcd ? (unsigned)(8 * ((blocks + 7) / 8)) : (unsigned)blocks;
   hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
