@@ -137,11 +137,21 @@ def _ver(w):
 # ---------------------------------------------------------------------------
 # conv3x3 (+bias, +activation, two-source input, residual)
 # ---------------------------------------------------------------------------
+def _prefers_wino(n, cin, cout, h, w):
+    from .. import _lib as L
+    return bool(L.lib().tg_conv3x3_prefers_wino(n, cin, cout, h, w))
+
+
 def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=True):
     w, b = layer.weight, layer.bias
     cout, cin = w.shape[0], w.shape[1]
-    pk, ocb = layer.packed()
-    y = ops.conv3x3(x, pk, b, cin, cout, ocb, act, x2=x2, res=res, ksplit=None if res is None else 1)
+    n_, _, h_, w_ = x.shape
+    u = layer.packed_wino() if hasattr(layer, 'packed_wino') and _prefers_wino(n_, cin, cout, h_, w_) else None
+    if u is not None:     # large layers (D's conv_in, VGG19 on the HR frames): Winograd form
+        y = ops.conv3x3_wino(x, u, b, cin, cout, act, x2=x2, res=res)
+    else:
+        pk, ocb = layer.packed()
+        y = ops.conv3x3(x, pk, b, cin, cout, ocb, act, x2=x2, res=res, ksplit=None if res is None else 1)
     if tape is None:
         return y
     c1 = x.shape[1]
@@ -166,6 +176,9 @@ def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=
             wdg = _CACHE.get(layer, ('dgs',), _ver(w),
                              lambda: wd.flip(2, 3).permute(1, 0, 2, 3).contiguous())
             tape.add_grad(x, ops.conv3x3_small(dz, wdg, None))
+        elif need_dx and x2 is None and _prefers_wino(n_, cout, cin, h_, w_):
+            ud = _CACHE.get(layer, ('dgu',), _ver(w), lambda: ops.pack_conv3x3_wino(wd.contiguous(), transposed=2))
+            tape.add_grad(x, ops.conv3x3_wino(dz, ud, None, cout, cin, NONE))
         elif need_dx:
             pkd = _CACHE.get(layer, ('dg', 0), _ver(w), lambda: ops.pack_conv3x3_dgrad(
                 wd[:, :c1].contiguous()))

@@ -25,6 +25,7 @@ head -8 $OUT/${TAG}_kernel_stats_single_stream_rocprofv3.csv | cut -c1-160
 echo "== training steps"; for c in 256 128; do timeout 300 python tools/bench_train.py --crop $c --steps 10 --force-d 2>/dev/null | tail -1 >> $OUT/${TAG}_bench_train.jsonl; done
 timeout 300 python tools/bench_train.py --crop 256 --steps 10 2>/dev/null | tail -1 >> $OUT/${TAG}_bench_train.jsonl
 timeout 300 python tools/bench_train.py --crop 256 --steps 10 --model FRVSR 2>/dev/null | tail -1 >> $OUT/${TAG}_bench_train.jsonl
+for c in 128 256; do timeout 300 python tools/bench_train.py --crop $c --steps 6 --force-d --feature-crit 2>/dev/null | tail -1 >> $OUT/${TAG}_bench_train.jsonl; done
 cut -c1-220 $OUT/${TAG}_bench_train.jsonl
 echo "== PMC passes"; bash tools/gpu_pmc.sh $TAG 2>&1 | grep "^pass"
 # summarise on the box (the raw per-dispatch tables are too large to travel back)
