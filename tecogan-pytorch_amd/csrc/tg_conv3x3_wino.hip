@@ -47,7 +47,7 @@ struct WinoArgs {
   int tiles_x, tiles_y, nstage, nocg, nocb;
   int nblocks;         // > 0: XCD-banded block order
   int vec_ok;          // float2 stores allowed (w even, 8-byte aligned planes)
-  int abl;             // lab builds only (TG_WINO_LAB, env TG_WINO_ABL): 1 no weight loads, 2 no input loads, 4 no stores, 16 no MFMA, 32 weights from L1
+  int abl;             // lab builds only (TG_WINO_LAB, env TG_WINO_ABL): 1 no weight loads, 2 no input loads, 4 no stores, 16 no MFMA, 32 weights from L1, 64 empty launch, 128 no main loop
 };
 
 constexpr int W_ICS = 16;             // input channels per stage
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   __shared__ __attribute__((aligned(16))) float s_raw[W_ICS * W_ICSTR];   // 10 KB
   __shared__ __attribute__((aligned(16))) float s_v[2 * W_ICS * 16 * W_VS];   // 2 x 20 KB: [buffer][ic][tile][16 positions + pad]
 
+  if (WABL(64)) return;                      // empty launch
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
 
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   // scheduling fences keep the compiler from hoisting all operand reads to the top, which
   // would cost the third wave per SIMD.)
   auto nothing = [] {};
-  for (int s = 0; s < last; ++s) {
+  for (int s = 0; s < (WABL(128) ? 0 : last); ++s) {
     const int cur = s & 1, nxt = cur ^ 1;
     kstep(4 * s + 0, u0, cur, nothing);
     __syncthreads();                         // patch of stage s+1 visible
