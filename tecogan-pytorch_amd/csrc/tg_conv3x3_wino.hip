@@ -394,3 +394,23 @@ extern "C" int tg_conv3x3_wino_fwd(const float* x, int64_t x_nstride, int c1, co
   return conv3x3_wino_launch(x, x_nstride, c1, x2, x2_nstride, u_packed, bias, res, res_nstride, relu_mask,
                              mask_nstride, y, y_nstride, n, cin, cout, h, w, act, stream);
 }
+
+#if TG_WINO_LAB
+// lab only (tools/wino_split_probe.py): `layers` dependent 64->64 layers on ONE stream, or the same
+// on two independent half-height chains whose launches alternate between two streams (all enqueued
+// from C so that the host is not the bottleneck)
+extern "C" int tg_lab_wino_chains(float* a0, float* c0, float* a1, float* c1, const float* u, const float* bias,
+                                  int layers, int h, int w, tg_stream_t s0, tg_stream_t s1, int two) {
+  float *pa[2] = {a0, a1}, *pc[2] = {c0, c1};
+  tg_stream_t st[2] = {s0, s1};
+  const int64_t ns = (int64_t)64 * h * w;
+  for (int l = 0; l < layers; ++l)
+    for (int k = 0; k < (two ? 2 : 1); ++k) {
+      int rc = conv3x3_wino_launch(pa[k], ns, 64, nullptr, 0, u, bias, nullptr, 0, nullptr, 0, pc[k], ns, 1, 64, 64, h, w,
+                                   TG_ACT_RELU, st[k]);
+      if (rc != TG_OK) return rc;
+      float* t = pa[k]; pa[k] = pc[k]; pc[k] = t;
+    }
+  return TG_OK;
+}
+#endif
