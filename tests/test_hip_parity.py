@@ -191,6 +191,34 @@ def test_conv3x3_winograd_data_gradient_and_relu_mask(ops):
     assert err(got, x.grad) <= 1e-5, err(got, x.grad)
 
 
+def test_winograd_full_size_properties(ops):
+    """Size-independent properties at the BASELINE layer size (64 -> 64 at 134x320), where a CPU
+    convolution is too slow for the suite: linearity in the input, equivariance under a shift by one
+    2x2 tile, agreement with the direct MFMA form, run-to-run bit reproducibility."""
+    g = torch.Generator().manual_seed(11)
+    x1 = dev(torch.rand(1, 64, 134, 320, generator=g) - 0.5)
+    x2 = dev(torch.rand(1, 64, 134, 320, generator=g) - 0.5)
+    wt = dev((torch.rand(64, 64, 3, 3, generator=g) - 0.5) / 12)
+    u = ops.pack_conv3x3_wino(wt)
+    f = lambda x: ops.conv3x3_wino(x, u, None, 64, 64, 0)      # noqa: E731
+    y1, y2 = f(x1), f(x2)
+    y12 = f(ops_axpby(x1, 0.75, x2, -1.5))
+    assert float((y12 - (0.75 * y1 - 1.5 * y2)).abs().max()) <= 2e-5
+    xs = torch.zeros_like(x1)
+    xs[:, :, 2:, 2:] = x1[:, :, :-2, :-2]                       # shift down / right by one tile
+    ys = f(xs)
+    # (the last row / column of ys sees zero padding where y1 saw data)
+    assert torch.equal(ys[:, :, 4:-1, 4:-1], y1[:, :, 2:-3, 2:-3])
+    pk = ops.pack_conv3x3(wt)
+    yd = ops.conv3x3(x1, pk[0], None, 64, 64, pk[3], 0, ksplit=1)
+    assert float((yd - y1).abs().max()) <= 2e-5
+    assert torch.equal(f(x1), y1)
+
+
+def ops_axpby(a, alpha, b, beta):
+    return a * alpha + b * beta
+
+
 def test_winograd_rule_and_plan_use(ops):
     """The frame plan runs SRNet's full-resolution layers in the Winograd form (and says so in its
     per-class statistics); tiny frames stay on the direct kernels."""
