@@ -331,15 +331,18 @@ extern "C" int64_t tg_conv3x3_wino_packed_floats(int cin, int cout) {
 }
 
 // Measured on MI355X (tools/wino_lab.py): at 134x320 / 64 -> 64 the Winograd form takes 0.70x the
-// time of the direct kernel; layers with few tiles (2 x 64 x 64 training frames, FNet's
-// low-resolution middle at batch 1) are latency bound and stay with the one-shot / K-split kernels.
+// time of the direct kernel, at 67x160 (170 workgroups) 0.75x; with 128 workgroups and fewer (2 x 64 x 64
+// training frames, FNet's low-resolution middle at batch 1: 33x80, 16x40) the one-shot / split-K
+// kernels win by 5-30 %.
 // TG_CONV_WINO=0/1 overrides (lab / A-B).
 extern "C" int tg_conv3x3_prefers_wino(int n, int cin, int cout, int h, int w) {
   static const int env = [] { const char* e = getenv("TG_CONV_WINO"); return e ? atoi(e) : -1; }();
   if (env == 0) return 0;
   if (n <= 0 || cin < 16 || cout <= 0 || cout % 64 != 0 || h < 2 || w < 2) return 0;
   const long long wgs = (long long)cdiv(w, 32) * cdiv(h, 2) * (cout / 64) * n;
-  return env == 1 ? 1 : (wgs >= 512 ? 1 : 0);
+  // a workgroup computes 2 x 32 pixels whatever the image: narrow images waste its columns
+  const bool filled = 4ll * w * h >= 3ll * cdiv(w, 32) * 32 * cdiv(h, 2) * 2;
+  return env == 1 ? 1 : ((wgs >= 160 && filled) ? 1 : 0);
 }
 
 extern "C" int tg_pack_conv3x3_wino(const float* w, float* out, int cin, int cout, int transposed,

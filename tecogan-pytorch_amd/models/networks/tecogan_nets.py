@@ -64,7 +64,7 @@ class _Conv(nn.Module):
 
     def forward(self, x, act=ops.ACT_NONE, x2=None, res=None, out=None, pool=False):
         if not self.transposed and not pool and \
-                L.lib().tg_conv3x3_prefers_wino(x.shape[0], self.cin, self.cout, x.shape[2], x.shape[3]):
+                TG._prefers_wino(x.shape[0], self.cin, self.cout, x.shape[2], x.shape[3]):
             u = self.packed_wino()
             if u is not None:
                 return ops.conv3x3_wino(x, u, self.bias, self.cin, self.cout, act, x2=x2, res=res, out=out)

@@ -137,9 +137,19 @@ def _ver(w):
 # ---------------------------------------------------------------------------
 # conv3x3 (+bias, +activation, two-source input, residual)
 # ---------------------------------------------------------------------------
+_WINO_RULE = {}
+
+
 def _prefers_wino(n, cin, cout, h, w):
-    from .. import _lib as L
-    return bool(L.lib().tg_conv3x3_prefers_wino(n, cin, cout, h, w))
+    """tg_conv3x3_prefers_wino, memoised per shape (the tape asks ~2000 times per training step)."""
+    if cout % 64 or cin < 16:
+        return False
+    key = (n, cin, cout, h, w)
+    r = _WINO_RULE.get(key)
+    if r is None:
+        from .. import _lib as L
+        r = _WINO_RULE[key] = bool(L.lib().tg_conv3x3_prefers_wino(n, cin, cout, h, w))
+    return r
 
 
 def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=True):

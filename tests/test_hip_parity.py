@@ -225,7 +225,8 @@ def test_winograd_rule_and_plan_use(ops):
     from tecogan_pytorch_amd import _lib
     lib = _lib.lib()
     assert lib.tg_conv3x3_prefers_wino(1, 64, 64, 134, 320) == 1
-    assert lib.tg_conv3x3_prefers_wino(1, 64, 64, 32, 32) == 0
+    assert lib.tg_conv3x3_prefers_wino(1, 64, 64, 32, 32) == 0 and lib.tg_conv3x3_prefers_wino(36, 32, 64, 16, 16) == 0
+    assert lib.tg_conv3x3_prefers_wino(1, 64, 64, 67, 160) == 1
     assert lib.tg_conv3x3_prefers_wino(1, 6, 64, 134, 320) == 0 and lib.tg_conv3x3_prefers_wino(1, 64, 32, 134, 320) == 0
     net, _ = make_net('BD', 4)
     plan = net._get_plan(1, 134, 320, torch.device('cuda'))
@@ -234,7 +235,7 @@ def test_winograd_rule_and_plan_use(ops):
     k = names.index('conv3x3_wino_kernel')
     nl = ctypes.c_int()
     _lib.check(lib.tg_frnet_plan_kind_stats(plan.handle, k, ctypes.byref(nl), None, None), 'kind_stats')
-    assert nl.value == 21          # conv_in + 10 residual blocks
+    assert nl.value == 25          # SRNet conv_in + 10 residual blocks, FNet's four 67x160 layers
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,ks,pool', [
