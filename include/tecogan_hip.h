@@ -122,7 +122,7 @@ int tg_conv3x3_fwd_masked(const float* x, int64_t x_nstride, int c1, const float
  * taps rotated by 180 degrees).  x2 / res / relu_mask as in tg_conv3x3_fwd / _masked (may be NULL). */
 int64_t tg_conv3x3_wino_packed_floats(int cin, int cout);
 /* 1 when the Winograd form is the faster one for this layer shape on an MI355X (at least 160 16-tile
- * workgroups at least 3/4 filled with image pixels, cout a multiple of 64, cin >= 16); the frame plan uses it to pick
+ * workgroups, cout a multiple of 64, cin >= 16); the frame plan uses it to pick
  * the form of each layer whose tg_layer_weights.u is set. */
 int tg_conv3x3_prefers_wino(int n, int cin, int cout, int h, int w);
 int tg_pack_conv3x3_wino(const float* w, float* out, int cin, int cout, int transposed,
