@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(BiasGradSegs dy, int n_p
   __shared__ float sm[4];
   const int ch = blockIdx.x, sl = blockIdx.y;
   const long long total = (long long)n * hw;
-  const long long per = (total + nslice - 1) / nslice;
+  const long long per = ((total + nslice - 1) / nslice + 3) & ~3ll;    // multiple of 4: slices stay 16-byte aligned
   const long long lo = (long long)sl * per;
   long long hi = lo + per; if (hi > total) hi = total;
   float s = 0.f;
@@ -76,7 +76,12 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(BiasGradSegs dy, int n_p
     const int sg = b / n_per_seg, lb = b - sg * n_per_seg;
     const float* __restrict__ pl = dy.seg[sg] + ((long long)lb * c + ch) * hw;
     const long long cnt = (hw - r0 < left) ? hw - r0 : left;
-    for (long long r = threadIdx.x; r < cnt; r += 256) s += pl[r0 + r];
+    if (((hw | r0 | cnt) & 3) == 0 && (((uintptr_t)pl) & 15) == 0) {     // 16-byte loads (every slice of an hw % 4 == 0 plane)
+      const f32x4* p4 = reinterpret_cast<const f32x4*>(pl + r0);
+      for (long long r = threadIdx.x; r < (cnt >> 2); r += 256) { const f32x4 v = p4[r]; s += (v[0] + v[1]) + (v[2] + v[3]); }
+    } else {
+      for (long long r = threadIdx.x; r < cnt; r += 256) s += pl[r0 + r];
+    }
     left -= cnt;
   }
   float r = block_sum(s, sm);
@@ -527,9 +532,10 @@ static int bias_grad_launch(const float* const* dy_list, int nseg, float* db, in
   }
   const int n = nseg * n_per_seg;
   long long total = (long long)n * hw;
-  int nslice = (int)((total + 16383) / 16384);
+  // slices of 4096 elements (a multiple of 4: the 16-byte path stays aligned), at most ~8192 blocks
+  int nslice = (int)((total + 4095) / 4096);
   if (nslice < 1) nslice = 1;
-  if (nslice * c > 4096) nslice = 4096 / c > 0 ? 4096 / c : 1;
+  if (nslice * c > 8192) nslice = 8192 / c > 0 ? 8192 / c : 1;
   hipLaunchKernelGGL(bias_grad_kernel, dim3(c, nslice), dim3(256), 0, ST, segs, n_per_seg, db, n, c, hw,
                      nslice);
   return check_launch("bias_grad");
