@@ -24,6 +24,16 @@ print('ATen / library launches', sum(aten.values()), 'of', len(rows), ' time ms'
       '(all 6 steps incl. warmup + setup)')
 for k, v in aten.most_common(25):
     print(f'{v:6d} {aten_ns[k]/1e3:9.1f} us  {k}')
+# conv classes by grid size (which layer shapes they are)
+g = collections.Counter(); gns = collections.Counter()
+for r in rows:
+    k = r['Kernel_Name']
+    if 'conv3x3' in k or 'wgrad3x3' in k or 'convt3x3' in k:
+        key = (k.split('(')[0][-60:], r.get('Grid_Size_X', r.get('Grid_Size', '?')), r.get('Workgroup_Size_X', ''))
+        g[key] += 1; gns[key] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+print('conv launches by (kernel, grid, block): count, avg us, total ms')
+for key, v in sorted(g.items(), key=lambda kv: -gns[kv[0]])[:28]:
+    print(f'{v:6d} {gns[key]/v/1e3:8.1f} {gns[key]/1e6:8.2f}  {key}')
 PY
 cp $f $REPO/gpurun_out/train_crop${CROP}_kernel_stats.csv
 rm -rf $REPO/gpurun_out/prof_train
