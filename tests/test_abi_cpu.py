@@ -133,3 +133,22 @@ def test_lr_schedules_match_torch():
     assert define_lr_schedule({'type': 'FixedLR'}, mine) is None
     with pytest.raises(ValueError):
         define_lr_schedule({'type': 'Nope'}, mine)
+
+
+def test_winograd_rule_and_packed_size_are_host_functions():
+    """tg_conv3x3_prefers_wino / tg_conv3x3_wino_packed_floats do no device work: the layer-form
+    rule the frame plan and the training tape rely on can be checked without a GPU."""
+    from tecogan_pytorch_amd import _lib
+    lib = _lib.lib()
+    assert lib.tg_conv3x3_prefers_wino(1, 64, 64, 134, 320) == 1       # SRNet layer, configs[1]
+    assert lib.tg_conv3x3_prefers_wino(1, 51, 64, 134, 320) == 1       # conv_in: two sources, K padded
+    assert lib.tg_conv3x3_prefers_wino(1, 64, 64, 268, 640) == 1       # configs[4]
+    assert lib.tg_conv3x3_prefers_wino(2, 64, 64, 64, 64) == 0         # training frames: one-shot kernel
+    assert lib.tg_conv3x3_prefers_wino(1, 6, 32, 134, 320) == 0        # cin < 16, cout % 64 != 0
+    assert lib.tg_conv3x3_prefers_wino(1, 64, 32, 134, 320) == 0
+    assert lib.tg_conv3x3_prefers_wino(0, 64, 64, 134, 320) == 0
+    # [K steps of 4][oc blocks of 16][4][64 lanes][4], K padded to 16, oc to 64
+    assert lib.tg_conv3x3_wino_packed_floats(64, 64) == 16 * 4 * 4 * 64 * 4
+    assert lib.tg_conv3x3_wino_packed_floats(51, 64) == 16 * 4 * 4 * 64 * 4
+    assert lib.tg_conv3x3_wino_packed_floats(27, 128) == 8 * 8 * 4 * 64 * 4
+    assert lib.tg_conv3x3_wino_packed_floats(0, 64) == -1
