@@ -133,6 +133,31 @@ int tg_conv3x3_wino_fwd(const float* x, int64_t x_nstride, int c1, const float* 
                         int64_t mask_nstride, float* y, int64_t y_nstride, int n, int cin,
                         int cout, int h, int w, int act, tg_stream_t stream);
 
+/* Several DEPENDENT 3x3 layers (layer i+1 reads what layer i writes: SRNet's conv_in and residual
+ * blocks, tecogan_nets.py:108-116,141-143) in ONE launch.  Every separate launch of the Winograd
+ * kernel pays ~10 us that nothing overlaps (launch, first loads, final stores); here the workgroups
+ * of layer i+1 are dispatched behind those of layer i and start as soon as the 3x3 tile
+ * neighbourhood they read has been written (per-tile flags, agent-scope loads / stores; a
+ * workgroup only waits for workgroups dispatched before it, so the launch cannot deadlock, and a
+ * poll limit turns a lost flag into an error count instead of a hang).
+ *   layers[i]: as tg_conv3x3_wino_fwd (x2 / bias / res may be NULL; res is added after the
+ *              activation; y may alias res: in-place residual sum); cout <= 64 for every layer.
+ *   flags:     tg_conv3x3_wino_chain_flag_ints(n_layers, n, h, w) int32, caller owned, zeroed ONCE
+ *              before the first call; its last 16 ints are an error counter the caller may read
+ *              (non-zero: a workgroup gave up waiting -- never seen; results are then undefined).
+ *   epoch:     any non-zero value not used before with these flags (a frame counter).
+ * Buffers may be reused along the chain only in the patterns of the reference's SRNet: a layer may
+ * overwrite a tensor that the PREVIOUS layer read, or its own residual input. */
+typedef struct {
+  const float* x; const float* x2; const float* u_packed; const float* bias; const float* res;
+  float* y;
+  int64_t x_nstride, x2_nstride, res_nstride, y_nstride;
+  int c1, cin, act;
+} tg_wino_layer;
+int64_t tg_conv3x3_wino_chain_flag_ints(int n_layers, int n, int h, int w);
+int tg_conv3x3_wino_chain(const tg_wino_layer* layers, int n_layers, int n, int cout, int h, int w,
+                          int32_t* flags, int epoch, tg_stream_t stream);
+
 /* Split-K variant for layers whose output tile count cannot fill the GPU (FNet's
  * low-resolution many-channel middle, tecogan_nets.py:37-60): `ksplit` groups of
  * input channels are reduced by different workgroups into `partials`

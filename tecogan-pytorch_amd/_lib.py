@@ -22,6 +22,13 @@ class FrnetCfg(C.Structure):
                 ('in_nc', 'out_nc', 'nf', 'nb', 'scale', 'up_mode', 'n', 'h', 'w', 'fnet_only')]
 
 
+class WinoLayer(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('x2', C.c_void_p), ('u_packed', C.c_void_p), ('bias', C.c_void_p),
+                ('res', C.c_void_p), ('y', C.c_void_p), ('x_nstride', C.c_int64), ('x2_nstride', C.c_int64),
+                ('res_nstride', C.c_int64), ('y_nstride', C.c_int64), ('c1', C.c_int), ('cin', C.c_int),
+                ('act', C.c_int)]
+
+
 class LayerWeights(C.Structure):
     _fields_ = [('w', C.c_void_p), ('b', C.c_void_p), ('u', C.c_void_p)]
 
@@ -83,6 +90,8 @@ SIGNATURES = {
     'tg_linear1_bwd': (I, [P, P, P, P, P, P, I, I, I, P]),
     'tg_downsample_bd': (I, [P, P, P, I, I, I, I, I, I, P]),
     'tg_conv3x3_wino_packed_floats': (I64, [I, I]),
+    'tg_conv3x3_wino_chain_flag_ints': (I64, [I, I, I, I]),
+    'tg_conv3x3_wino_chain': (I, [C.POINTER(WinoLayer), I, I, I, I, I, P, I, P]),
     'tg_conv3x3_prefers_wino': (I, [I, I, I, I, I]),
     'tg_pack_conv3x3_wino': (I, [P, P, I, I, I, P]),
     'tg_conv3x3_wino_fwd': (I, [P, I64, I, P, I64, P, P, P, I64, P, I64, P, I64, I, I, I, I, I, I, P]),

@@ -29,6 +29,9 @@ struct tg_frnet_plan {
   float *FA, *FB, *FPART, *FLOW2;   // FNet's own buffers (phase 1 may overlap phase 2 of the previous frame)
   float* WZ;                        // packed output-conv weights for the fused HR stage
   bool wz_ready;
+  int32_t* CHAINF;                  // per-tile flags of the chained SRNet launch (tg_conv3x3_wino_chain)
+  bool chain_ready;                 // flags zeroed
+  int epoch;                        // one per chained launch
   int fh, fw, launches;
   int st_launch[16];
   double st_flops[16], st_bytes[16];
@@ -61,7 +64,8 @@ static size_t fnet_partial_floats(const tg_frnet_cfg* c) {
   return best;
 }
 
-static void carve(const tg_frnet_cfg* c, size_t off[13]) {
+static const int CHAIN_MAX_LAYERS = 24;
+static void carve(const tg_frnet_cfg* c, size_t off[14]) {
   size_t hw = (size_t)c->h * c->w, n = c->n;
   size_t o = 0;
   const size_t sr = c->fnet_only ? 0 : 1;                      // an FNet-only plan has no SRNet regions
@@ -77,7 +81,9 @@ static void carve(const tg_frnet_cfg* c, size_t off[13]) {
   off[9] = o; o += align64(fnet_partial_floats(c));            // FPART (split-K partial sums, FNet)
   off[10] = o; o += align64(n * 2 * hw);                       // FLOW2 (second flow slot)
   off[11] = o; o += sr * 2048;                                 // WZ (A operand of the fused output-conv contraction)
-  off[12] = o;
+  off[12] = o;                                                 // CHAINF (int32 flags: 24 layers x 16-tile workgroups + error counter)
+  o += sr * align64((size_t)CHAIN_MAX_LAYERS * n * ((c->h + 1) / 2) * ((c->w + 31) / 32) + 16);
+  off[13] = o;
 }
 
 static int cfg_ok(const tg_frnet_cfg* c) {
@@ -89,9 +95,9 @@ static int cfg_ok(const tg_frnet_cfg* c) {
 
 extern "C" size_t tg_frnet_workspace_floats(const tg_frnet_cfg* cfg) {
   if (!cfg_ok(cfg)) return 0;
-  size_t off[13];
+  size_t off[14];
   carve(cfg, off);
-  return off[12];
+  return off[13];
 }
 
 extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weights* layers,
@@ -109,9 +115,10 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   TG_REQUIRE(p, TG_E_ARG, "frnet_plan_create: out of host memory");
   p->cfg = *cfg;
   p->L.assign(layers, layers + n_layers);
-  size_t off[13];
+  size_t off[14];
   carve(cfg, off);
   p->WZ = workspace + off[11]; p->wz_ready = false;
+  p->CHAINF = reinterpret_cast<int32_t*>(workspace + off[12]); p->chain_ready = false; p->epoch = 0;
   p->FA = workspace + off[7]; p->FB = workspace + off[8]; p->FPART = workspace + off[9];
   p->FLOW2 = workspace + off[10];
   p->PART = workspace + off[6];
@@ -151,7 +158,8 @@ enum {
   K_TAIL = 12,      // convout_tail_kernel: 9-tap shift-add + residual + uint8
   K_CONV_ONESHOT = 13,  // conv3x3_oneshot_kernel: few tiles, cin <= 64, whole K range in flight
   K_CONV_WINO = 14,     // conv3x3_wino_kernel: Winograd F(2x2,3x3) form of the large 64-channel-group layers
-  K_COUNT = 15
+  K_WINO_CHAIN = 15,    // conv3x3_wino_chain_kernel: SRNet's conv_in + residual blocks as ONE launch
+  K_COUNT = 16
 };
 
 // The HR stage as two launches instead of three and without the 64-channel HR tensor: the last
@@ -160,6 +168,16 @@ enum {
 static bool hr_fuse_enabled() {
   static const int v = [] { const char* e = getenv("TG_HR_FUSE"); return e ? atoi(e) : 1; }();
   return v != 0;
+}
+// SRNet's 1 + 2*nb full-resolution layers as one chained launch (tg_conv3x3_wino_chain) when a layer
+// has more 16-tile workgroups than fit on the GPU at once (768) but only a few rounds of them:
+// measured against one launch per layer (tools/wino_chain_probe.py) -15 % at 2 clips of 134x320,
+// -6.5 % at 4, -4.6 % at 268x640, +-0 at 8 clips, and +3..15 % (slower) for a single 134x320 clip, whose
+// 670 workgroups are all resident at once and therefore cannot pipeline.  TG_WINO_CHAIN=0 / 1: never / whenever eligible.
+static bool chain_wanted(long long ntile) {
+  static const int v = [] { const char* e = getenv("TG_WINO_CHAIN"); return e ? atoi(e) : -1; }();
+  if (v >= 0) return v != 0;
+  return ntile > 768 && ntile <= 3000;
 }
 // the fused tail writes (n, H, W, c) uint8 frames for any n; the unfused quantise pass only n == 1
 static bool plan_u8_ok(const tg_frnet_plan* p) {
@@ -293,11 +311,51 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
   // ---- SRNet (tecogan_nets.py:136-147) ----------------------------------------
   A = p->A; B = p->B;
   const int nf = c.nf;
-  conv(lr_curr, c.in_nc * hw, c.in_nc, p->S2D, s2dc * hw, c.in_nc + s2dc, nf, h, w, TG_ACT_RELU,
-       nullptr, 0, A, nf * hw);
-  for (int b = 0; b < c.nb; ++b) {
-    conv(A, nf * hw, nf, nullptr, 0, nf, nf, h, w, TG_ACT_RELU, nullptr, 0, B, nf * hw);
-    conv(B, nf * hw, nf, nullptr, 0, nf, nf, h, w, TG_ACT_NONE, A, nf * hw, A, nf * hw);
+  const int nchain = 1 + 2 * c.nb;
+  bool chain = nf <= 64 && nchain <= CHAIN_MAX_LAYERS &&
+               chain_wanted((long long)n * tg::cdiv(h, 2) * tg::cdiv(w, 32)) &&
+               tg_conv3x3_prefers_wino(n, c.in_nc + s2dc, nf, h, w) && tg_conv3x3_prefers_wino(n, nf, nf, h, w);
+  for (int i = 0; i < nchain && chain; ++i) chain = p->L[li + i].u != nullptr;
+  if (chain) {
+    tg_wino_layer cl[CHAIN_MAX_LAYERS];
+    double fl = 0, by = 0;
+    const double px = (double)n * h * w;
+    for (int i = 0; i < nchain; ++i) {
+      const tg_layer_weights lw = p->L[li + i];
+      tg_wino_layer& d = cl[i];
+      const bool first = i == 0, conv2 = !first && (i % 2 == 0);
+      d.x = first ? lr_curr : (conv2 ? B : A);
+      d.x2 = first ? p->S2D : nullptr;
+      d.u_packed = lw.u; d.bias = lw.b;
+      d.res = conv2 ? A : nullptr;
+      d.y = (first || conv2) ? A : B;
+      d.x_nstride = first ? c.in_nc * hw : nf * hw;
+      d.x2_nstride = first ? s2dc * hw : 0;
+      d.res_nstride = nf * hw; d.y_nstride = nf * hw;
+      d.c1 = first ? c.in_nc : nf;
+      d.cin = first ? c.in_nc + s2dc : nf;
+      d.act = conv2 ? TG_ACT_NONE : TG_ACT_RELU;
+      fl += 2.0 * d.cin * 9 * nf * px;
+      by += 4.0 * px * (d.cin + nf + (conv2 ? nf : 0)) + 4.0 * 9 * d.cin * nf;
+    }
+    li += nchain;
+    go(K_WINO_CHAIN, fl, by, [&] {
+      if (!p->chain_ready) {
+        const size_t ints = (size_t)tg_conv3x3_wino_chain_flag_ints(nchain, n, h, w);
+        if (hipMemsetAsync(p->CHAINF, 0, ints * sizeof(int32_t), (hipStream_t)st) != hipSuccess)
+          return tg::check_launch("wino_chain flags memset");
+        p->chain_ready = true;
+      }
+      if (++p->epoch == 0) p->epoch = 1;
+      return tg_conv3x3_wino_chain(cl, nchain, n, nf, h, w, p->CHAINF, p->epoch, st);
+    });
+  } else {
+    conv(lr_curr, c.in_nc * hw, c.in_nc, p->S2D, s2dc * hw, c.in_nc + s2dc, nf, h, w, TG_ACT_RELU,
+         nullptr, 0, A, nf * hw);
+    for (int b = 0; b < c.nb; ++b) {
+      conv(A, nf * hw, nf, nullptr, 0, nf, nf, h, w, TG_ACT_RELU, nullptr, 0, B, nf * hw);
+      conv(B, nf * hw, nf, nullptr, 0, nf, nf, h, w, TG_ACT_NONE, A, nf * hw, A, nf * hw);
+    }
   }
   const bool fuse = hr_fuse_enabled() && c.out_nc <= 3 && nf <= 64;
   const tg_layer_weights lw_up1 = p->L[li++];
@@ -433,7 +491,7 @@ extern "C" const char* tg_frnet_kind_name(int kind) {
       "maxpool2_kernel",             "upsample_kernel",            "quantize_u8_hwc_kernel",
       "splitk_finalize_kernel",      "conv3x3_mfma_kernel<1,2,1,KS=2>",
       "convt3x3s2_mfma_kernel<Z>",   "convout_tail_kernel",        "conv3x3_oneshot_kernel",
-      "conv3x3_wino_kernel"};
+      "conv3x3_wino_kernel",         "conv3x3_wino_chain_kernel"};
   return (kind >= 0 && kind < K_COUNT) ? names[kind] : "?";
 }
 

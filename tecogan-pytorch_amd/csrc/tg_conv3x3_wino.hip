@@ -98,24 +98,43 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
+template <bool COH> __device__ __forceinline__ float2 ld2(const float* p) {
+  if constexpr (COH) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__builtin_bit_cast(float, (unsigned)v), __builtin_bit_cast(float, (unsigned)(v >> 32)));
+  } else {
+    return *reinterpret_cast<const float2*>(p);
+  }
+}
+template <bool COH> __device__ __forceinline__ float ld1(const float* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH> __device__ __forceinline__ void st2(float* p, float v0, float v1) {
+  if constexpr (COH) {
+    const unsigned long long v = (unsigned long long)__builtin_bit_cast(unsigned, v0) | ((unsigned long long)__builtin_bit_cast(unsigned, v1) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *reinterpret_cast<float2*>(p) = make_float2(v0, v1);
+  }
+}
+template <bool COH> __device__ __forceinline__ void st1(float* p, float v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+// One workgroup's tile.  COH (chained launches, below): activations move with agent-scope (sc1)
+// loads / stores -- they bypass the XCD's non-coherent L2 copy -- because producer and consumer
+// workgroups of consecutive layers run in the same launch, possibly behind different L2s.
+constexpr int AUX_SC1 = 16;       // cache-policy bit of the buffer instructions on gfx940+
+
+template <bool COH>
+__device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int ocg, int n) {
   __shared__ __attribute__((aligned(16))) float s_raw[W_ICS * W_ICSTR];   // 10 KB
   __shared__ __attribute__((aligned(16))) float s_v[2 * W_ICS * 16 * W_VS];   // 2 x 20 KB: [buffer][ic][tile][16 positions + pad]
 
-  if (WABL(64)) return;                      // empty launch
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-
-  int b = blockIdx.x;
-  if (a.nblocks > 0) {      // XCD x gets the contiguous band of tiles [x*per, (x+1)*per)
-    const int per = (a.nblocks + 7) >> 3;
-    b = (b & 7) * per + (b >> 3);
-    if (b >= a.nblocks) return;
-  }
-  const int tx = __builtin_amdgcn_readfirstlane(b % a.tiles_x); b /= a.tiles_x;
-  const int ty = __builtin_amdgcn_readfirstlane(b % a.tiles_y); b /= a.tiles_y;
-  const int ocg = __builtin_amdgcn_readfirstlane(b % a.nocg);
-  const int n = __builtin_amdgcn_readfirstlane(b / a.nocg);
   const int x0 = tx * 32, y0 = ty * 2;
   const int hw = a.h * a.w;
 
@@ -146,10 +165,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
     const unsigned so = (unsigned)(s * W_ICS) * hw * 4u;
 #pragma unroll
     for (int k = 0; k < RAW_PER_T; ++k) {
-      float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(roff[k] + so), 0, 0));
+      float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(roff[k] + so), 0, COH ? AUX_SC1 : 0));
       if (dual)   // offsets below c1 wrap to > 2^31 and read 0
         v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                 rx2, (int)(roff[k] + so - (unsigned)a.c1 * hw * 4u), 0, 0));
+                 rx2, (int)(roff[k] + so - (unsigned)a.c1 * hw * 4u), 0, COH ? AUX_SC1 : 0));
       reg[k] = v;
     }
   };
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
       for (int i = 0; i < 2; ++i) {
         rpre[r][i] = make_float2(0.f, 0.f);
         if (res_pre && oc_base + r < a.cout && ox < a.w && y0 + i < a.h)
-          rpre[r][i] = *reinterpret_cast<const float2*>(rn + (size_t)(oc_base + r) * hw + (size_t)(y0 + i) * a.w + ox);
+          rpre[r][i] = ld2<COH>(rn + (size_t)(oc_base + r) * hw + (size_t)(y0 + i) * a.w + ox);
       }
     kstep(4 * last + 3, u1, cur, nothing);
   }
@@ -311,15 +330,103 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
       if (a.vec_ok) {
         if (rn) { v0 += rpre[r][i].x; v1 += rpre[r][i].y; }
         if (mn) { const float2 mm = *reinterpret_cast<const float2*>(mn + o); v0 = mm.x > 0.f ? v0 : 0.f; v1 = mm.y > 0.f ? v1 : 0.f; }
-        *reinterpret_cast<float2*>(yn + o) = make_float2(v0, v1);
+        st2<COH>(yn + o, v0, v1);
       } else {
-        if (rn) { v0 += rn[o]; if (two) v1 += rn[o + 1]; }
+        if (rn) { v0 += ld1<COH>(rn + o); if (two) v1 += ld1<COH>(rn + o + 1); }
         if (mn) { v0 = mn[o] > 0.f ? v0 : 0.f; if (two) v1 = mn[o + 1] > 0.f ? v1 : 0.f; }
-        yn[o] = v0;
-        if (two) yn[o + 1] = v1;
+        st1<COH>(yn + o, v0);
+        if (two) st1<COH>(yn + o + 1, v1);
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
+  if (WABL(64)) return;                      // empty launch
+  int b = blockIdx.x;
+  if (a.nblocks > 0) {      // XCD x gets the contiguous band of tiles [x*per, (x+1)*per)
+    const int per = (a.nblocks + 7) >> 3;
+    b = (b & 7) * per + (b >> 3);
+    if (b >= a.nblocks) return;
+  }
+  const int tx = __builtin_amdgcn_readfirstlane(b % a.tiles_x); b /= a.tiles_x;
+  const int ty = __builtin_amdgcn_readfirstlane(b % a.tiles_y); b /= a.tiles_y;
+  const int ocg = __builtin_amdgcn_readfirstlane(b % a.nocg);
+  const int n = __builtin_amdgcn_readfirstlane(b / a.nocg);
+  wino_tile<false>(a, tx, ty, ocg, n);
+}
+
+// ---- several dependent layers in ONE launch ----------------------------------------------------
+// Every launch of the kernel above pays ~10 us that nothing overlaps (launch, first loads, the
+// final stores: all workgroups are resident at once and walk the same timeline).  Here the
+// workgroups of layer k+1 are dispatched right behind those of layer k (same grid, in-order
+// dispatch per XCD) and start as soon as the 3x3 tile neighbourhood they read has been written:
+//   * flag[layer][tile] = epoch is stored (agent scope) after the tile's stores have left the
+//     workgroup; a consumer polls the <= 9 flags of its neighbourhood (s_sleep between polls, a
+//     poll limit instead of a hang: err[0] counts bail-outs);
+//   * that neighbourhood also covers the write-after-read hazards of SRNet's buffers (in-place
+//     residual sum, two ping-pong tensors): whoever still reads the old content of tile T is one
+//     of the tiles T's writer waits for;
+//   * a workgroup only ever waits for workgroups dispatched BEFORE it, so the launch cannot
+//     deadlock however few of them are resident;
+//   * activations use sc1 loads / stores (COH above): no L2 invalidation between layers, the
+//     weights stay cached.
+struct WinoLayer {
+  const float *x, *x2, *u, *bias, *res;
+  float* y;
+  long long x_ns, x2_ns, res_ns, y_ns;
+  int c1, cin, act, nstage;
+};
+constexpr int W_MAX_CHAIN = 24;
+struct WinoChainArgs {
+  WinoLayer L[W_MAX_CHAIN];
+  int nlayer, bpl;           // blocks per layer in the grid (tiles rounded up to a multiple of 8)
+  int cout, h, w, tiles_x, tiles_y, ntile, vec_ok;
+  int* flags;                // [nlayer][ntile]
+  int* err;
+  int epoch;
+};
+
+template <bool COHX>
+__global__ __launch_bounds__(256, 3) void conv3x3_wino_chain_kernel(WinoChainArgs c) {
+  const int layer = __builtin_amdgcn_readfirstlane((int)blockIdx.x / c.bpl);
+  int b = (int)blockIdx.x - layer * c.bpl;
+  {
+    const int per = c.bpl >> 3;              // XCD x gets the band of tiles [x*per, (x+1)*per) of every layer
+    b = (b & 7) * per + (b >> 3);
+    if (b >= c.ntile) return;
+  }
+  const int tile = b;
+  const int tx = __builtin_amdgcn_readfirstlane(b % c.tiles_x); b /= c.tiles_x;
+  const int ty = __builtin_amdgcn_readfirstlane(b % c.tiles_y);
+  const int n = __builtin_amdgcn_readfirstlane(b / c.tiles_y);
+  const WinoLayer& L = c.L[layer];
+  WinoArgs a;
+  a.x = L.x; a.x2 = L.x2; a.u = L.u; a.bias = L.bias; a.res = L.res; a.mask = nullptr; a.y = L.y;
+  a.x_ns = L.x_ns; a.x2_ns = L.x2_ns; a.res_ns = L.res_ns; a.mask_ns = 0; a.y_ns = L.y_ns;
+  a.c1 = L.c1; a.cin = L.cin; a.cout = c.cout; a.h = c.h; a.w = c.w; a.act = L.act;
+  a.tiles_x = c.tiles_x; a.tiles_y = c.tiles_y; a.nstage = L.nstage; a.nocg = 1; a.nocb = 4;
+  a.nblocks = 0; a.vec_ok = c.vec_ok; a.abl = 0;
+  if (layer > 0) {                            // wait for the producers of the 3x3 neighbourhood
+    const int t = threadIdx.x;
+    if (t < 9) {
+      const int ny = ty - 1 + t / 3, nx = tx - 1 + t % 3;
+      if (ny >= 0 && ny < c.tiles_y && nx >= 0 && nx < c.tiles_x) {
+        const int* f = c.flags + (size_t)(layer - 1) * c.ntile + (n * c.tiles_y + ny) * c.tiles_x + nx;
+        int polls = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != c.epoch) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++polls > (1 << 21)) { atomicAdd(c.err, 1); break; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  wino_tile<COHX>(a, tx, ty, 0, n);
+  __builtin_amdgcn_s_waitcnt(0);              // this wave's stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(c.flags + (size_t)layer * c.ntile + tile, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace tg
@@ -419,3 +526,45 @@ extern "C" int tg_lab_wino_chains(float* a0, float* c0, float* a1, float* c1, co
   return TG_OK;
 }
 #endif
+
+extern "C" int64_t tg_conv3x3_wino_chain_flag_ints(int n_layers, int n, int h, int w) {
+  if (n_layers <= 0 || n_layers > W_MAX_CHAIN || n <= 0 || h <= 0 || w <= 0) return -1;
+  return (int64_t)n_layers * n * cdiv(h, 2) * cdiv(w, 32) + 16;     // + the error counter (last 16 ints)
+}
+
+extern "C" int tg_conv3x3_wino_chain(const tg_wino_layer* layers, int n_layers, int n, int cout, int h, int w,
+                                     int32_t* flags, int epoch, tg_stream_t stream) {
+  TG_REQUIRE(layers && flags, TG_E_ARG, "conv3x3_wino_chain: null pointer");
+  TG_REQUIRE(n_layers >= 1 && n_layers <= W_MAX_CHAIN, TG_E_ARG, "conv3x3_wino_chain: %d layers (1..%d)", n_layers, W_MAX_CHAIN);
+  TG_REQUIRE(n > 0 && h > 0 && w > 0 && cout > 0 && cout <= 64, TG_E_SHAPE,
+             "conv3x3_wino_chain: n=%d cout=%d (<= 64: one output-channel group) h=%d w=%d", n, cout, h, w);
+  TG_REQUIRE(epoch != 0, TG_E_ARG, "conv3x3_wino_chain: epoch 0 is the cleared state of the flags");
+  WinoChainArgs c{};
+  c.nlayer = n_layers; c.cout = cout; c.h = h; c.w = w;
+  c.tiles_x = cdiv(w, 32); c.tiles_y = cdiv(h, 2);
+  const long long ntile = (long long)c.tiles_x * c.tiles_y * n;
+  TG_REQUIRE(ntile * n_layers < (1ll << 30), TG_E_SHAPE, "conv3x3_wino_chain: too many tiles");
+  c.ntile = (int)ntile;
+  c.bpl = (int)(8 * ((ntile + 7) / 8));
+  c.flags = flags; c.err = flags + (size_t)n_layers * ntile; c.epoch = epoch;
+  bool vec = (w % 2 == 0) && ((int64_t)h * w) % 2 == 0;
+  auto al8 = [](const void* p, int64_t ns) { return ((uintptr_t)p % 8) == 0 && ns % 2 == 0; };
+  for (int i = 0; i < n_layers; ++i) {
+    const tg_wino_layer& l = layers[i];
+    TG_REQUIRE(l.x && l.u_packed && l.y, TG_E_ARG, "conv3x3_wino_chain: layer %d: null pointer", i);
+    TG_REQUIRE(l.cin > 0 && (!l.x2 || (l.c1 > 0 && l.c1 < l.cin)), TG_E_ARG, "conv3x3_wino_chain: layer %d: cin=%d c1=%d", i, l.cin, l.c1);
+    TG_REQUIRE((long long)l.cin * h * w < (1ll << 29), TG_E_SHAPE, "conv3x3_wino_chain: layer %d too large", i);
+    TG_REQUIRE(l.act >= TG_ACT_NONE && l.act <= TG_ACT_TANH24, TG_E_ARG, "conv3x3_wino_chain: layer %d: act=%d", i, l.act);
+    WinoLayer& d = c.L[i];
+    d.x = l.x; d.x2 = l.x2; d.u = l.u_packed; d.bias = l.bias; d.res = l.res; d.y = l.y;
+    d.x_ns = l.x_nstride; d.x2_ns = l.x2_nstride; d.res_ns = l.res_nstride; d.y_ns = l.y_nstride;
+    d.c1 = l.x2 ? l.c1 : l.cin; d.cin = l.cin; d.act = l.act; d.nstage = cdiv(l.cin, 16);
+    vec = vec && al8(l.y, l.y_nstride) && (!l.res || al8(l.res, l.res_nstride));
+  }
+  c.vec_ok = vec ? 1 : 0;
+  static const int noncoh = [] { const char* e = getenv("TG_WINO_CHAIN_NONCOH"); return e ? atoi(e) : 0; }();   // lab: timing only, results may be stale
+  static const int pad_lds = [] { const char* e = getenv("TG_WINO_CHAIN_LDS"); return e ? atoi(e) : 0; }();   // lab: dynamic LDS to cap residency
+  if (noncoh) hipLaunchKernelGGL(conv3x3_wino_chain_kernel<false>, dim3((unsigned)(c.bpl * n_layers)), dim3(256), pad_lds, (hipStream_t)stream, c);
+  else hipLaunchKernelGGL(conv3x3_wino_chain_kernel<true>, dim3((unsigned)(c.bpl * n_layers)), dim3(256), pad_lds, (hipStream_t)stream, c);
+  return check_launch("conv3x3_wino_chain");
+}

@@ -746,3 +746,36 @@ def conv3x3_wino(x, u_packed, bias, cin, cout, act=ACT_NONE, x2=None, res=None, 
         _ptr(mask), mask.stride(0) if mask is not None else 0, y.data_ptr(), y.stride(0),
         n, cin, cout, h, w, act, _stream()), 'tg_conv3x3_wino_fwd')
     return y
+
+
+class WinoChain:
+    """tg_conv3x3_wino_chain: dependent 3x3 layers in one launch.  `layers` is a list of dicts
+    (x, u, bias, cin, act, x2=None, res=None, y) of device tensors; the flag buffer and the epoch
+    counter live here."""
+
+    def __init__(self, layers, n, cout, h, w):
+        import ctypes
+        self.n, self.cout, self.h, self.w = n, cout, h, w
+        self.keep = layers
+        self.arr = (L.WinoLayer * len(layers))()
+        for i, d in enumerate(layers):
+            a = self.arr[i]
+            x, x2, res, y = d['x'], d.get('x2'), d.get('res'), d['y']
+            a.x, a.x2, a.u_packed = x.data_ptr(), _ptr(x2), d['u'].data_ptr()
+            a.bias, a.res, a.y = _ptr(d.get('bias')), _ptr(res), y.data_ptr()
+            a.x_nstride, a.y_nstride = x.stride(0), y.stride(0)
+            a.x2_nstride = x2.stride(0) if x2 is not None else 0
+            a.res_nstride = res.stride(0) if res is not None else 0
+            a.c1, a.cin, a.act = x.shape[1], d['cin'], d.get('act', ACT_NONE)
+        nints = L.lib().tg_conv3x3_wino_chain_flag_ints(len(layers), n, h, w)
+        self.flags = torch.zeros(nints, dtype=torch.int32, device=layers[0]['x'].device)
+        self.epoch = 0
+
+    def run(self):
+        self.epoch += 1
+        L.check(L.lib().tg_conv3x3_wino_chain(self.arr, len(self.keep), self.n, self.cout, self.h, self.w,
+                                              self.flags.data_ptr(), self.epoch, _stream()),
+                'tg_conv3x3_wino_chain')
+
+    def bailouts(self):
+        return int(self.flags[-16].item())

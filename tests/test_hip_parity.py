@@ -12,7 +12,12 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+import os
+
 from oracle import tecogan_oracle as O
+
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN_DIR = os.path.join(ROOT_DIR, 'tests', 'golden')
 from procedural_weights import generator_state_dict, smooth_clip
 
 T = torch.from_numpy
@@ -217,6 +222,61 @@ def test_winograd_full_size_properties(ops):
 
 def ops_axpby(a, alpha, b, beta):
     return a * alpha + b * beta
+
+
+@pytest.mark.parametrize('n,h,w', [(1, 26, 70), (2, 21, 37), (3, 134, 64)])
+def test_winograd_chained_launch_equals_separate_launches(ops, n, h, w):
+    """tg_conv3x3_wino_chain: SRNet's conv_in + residual blocks (two-source first layer, in-place
+    residual sums, two ping-pong tensors) as ONE launch with per-tile flags must reproduce the
+    separate launches bit for bit, launch after launch (stale data or a lost flag would show)."""
+    g = torch.Generator().manual_seed(17)
+    nb = 4
+    lr, s2d = dev(torch.rand(n, 3, h, w, generator=g)), dev(torch.rand(n, 48, h, w, generator=g))
+    ws = [dev(torch.randn(64, 51, 3, 3, generator=g) * 0.04)] + \
+         [dev(torch.randn(64, 64, 3, 3, generator=g) * 0.03) for _ in range(2 * nb)]
+    bs = [dev(torch.randn(64, generator=g) * 0.1) for _ in range(2 * nb + 1)]
+    us = [ops.pack_conv3x3_wino(x) for x in ws]
+
+    def make(A, B):
+        layers = [dict(x=lr, x2=s2d, u=us[0], bias=bs[0], cin=51, act=1, y=A)]
+        for b in range(nb):
+            layers.append(dict(x=A, u=us[1 + 2 * b], bias=bs[1 + 2 * b], cin=64, act=1, y=B))
+            layers.append(dict(x=B, u=us[2 + 2 * b], bias=bs[2 + 2 * b], cin=64, act=0, res=A, y=A))
+        return layers
+    A1, B1, A2, B2 = (torch.empty(n, 64, h, w, device='cuda') for _ in range(4))
+    seq, chain = make(A1, B1), ops.WinoChain(make(A2, B2), n, 64, h, w)
+    for it in range(8):
+        lr.uniform_(); s2d.uniform_()
+        for d in seq:
+            ops.conv3x3_wino(d['x'], d['u'], d['bias'], d['cin'], 64, d['act'], x2=d.get('x2'), res=d.get('res'),
+                             out=d['y'])
+        chain.run()
+        torch.cuda.synchronize()
+        assert torch.equal(A1, A2) and torch.equal(B1, B2), it
+    assert chain.bailouts() == 0
+
+
+def test_plan_with_chained_srnet_launch(tmp_path):
+    """The frame plan with SRNet as one chained launch (TG_WINO_CHAIN=1) against the plan with one launch
+    per layer: same kernels, so the frames must be bit-identical.  (The switches are read once per
+    process: two subprocesses.)"""
+    import subprocess
+    import sys
+    script = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from tests.test_hip_parity import make_net, smooth_clip\n"
+        "net, _ = make_net('BD', 4)\n"
+        "import numpy as np\n"
+        "x = torch.from_numpy(np.stack([smooth_clip(6, 3, 26, 40, seed=5), smooth_clip(6, 3, 26, 40, seed=6)])).cuda()\n"
+        "y = net.infer_sequence(x, torch.device('cuda'), return_device_tensor=True)\n"
+        "torch.save(y.cpu(), sys.argv[1])\n" % (ROOT_DIR, GOLDEN_DIR))
+    outs = []
+    for chain in ('0', '1'):
+        env = dict(os.environ, TG_CONV_WINO='1', TG_WINO_CHAIN=chain)
+        out = str(tmp_path / ('y%s.pt' % chain))
+        subprocess.run([sys.executable, '-c', script, out], check=True, env=env, timeout=600)
+        outs.append(torch.load(out))
+    assert outs[0].shape == outs[1].shape and torch.equal(outs[0], outs[1])
 
 
 def test_winograd_rule_and_plan_use(ops):
