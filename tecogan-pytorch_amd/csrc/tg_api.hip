@@ -311,18 +311,26 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
   // ---- SRNet (tecogan_nets.py:136-147) ----------------------------------------
   A = p->A; B = p->B;
   const int nf = c.nf;
-  const int nchain = 1 + 2 * c.nb;
-  bool chain = nf <= 64 && nchain <= CHAIN_MAX_LAYERS &&
+  // conv_in joins the chain when it has a Winograd form itself (cin = 3 + 48 at 4x; 3 + 12 at 2x is
+  // below the kernel's 16-channel stage and runs the direct form as its own launch)
+  const bool in_wino = p->L[li].u && tg_conv3x3_prefers_wino(n, c.in_nc + s2dc, nf, h, w);
+  const int skip = in_wino ? 0 : 1;
+  const int nchain = 1 + 2 * c.nb - skip;
+  bool chain = nf <= 64 && nchain >= 2 && nchain <= CHAIN_MAX_LAYERS &&
                chain_wanted((long long)n * tg::cdiv(h, 2) * tg::cdiv(w, 32)) &&
-               tg_conv3x3_prefers_wino(n, c.in_nc + s2dc, nf, h, w) && tg_conv3x3_prefers_wino(n, nf, nf, h, w);
-  for (int i = 0; i < nchain && chain; ++i) chain = p->L[li + i].u != nullptr;
+               tg_conv3x3_prefers_wino(n, nf, nf, h, w);
+  for (int i = skip; i < 1 + 2 * c.nb && chain; ++i) chain = p->L[li + i].u != nullptr;
   if (chain) {
+    if (skip)
+      conv(lr_curr, c.in_nc * hw, c.in_nc, p->S2D, s2dc * hw, c.in_nc + s2dc, nf, h, w, TG_ACT_RELU,
+           nullptr, 0, A, nf * hw);
     tg_wino_layer cl[CHAIN_MAX_LAYERS];
     double fl = 0, by = 0;
     const double px = (double)n * h * w;
-    for (int i = 0; i < nchain; ++i) {
-      const tg_layer_weights lw = p->L[li + i];
-      tg_wino_layer& d = cl[i];
+    for (int k = 0; k < nchain; ++k) {
+      const int i = k + skip;                 // layer index inside SRNet: 0 = conv_in, odd = conv1, even = conv2
+      const tg_layer_weights lw = p->L[li + k];
+      tg_wino_layer& d = cl[k];
       const bool first = i == 0, conv2 = !first && (i % 2 == 0);
       d.x = first ? lr_curr : (conv2 ? B : A);
       d.x2 = first ? p->S2D : nullptr;
