@@ -292,10 +292,15 @@ def test_winograd_rule_and_plan_use(ops):
     plan = net._get_plan(1, 134, 320, torch.device('cuda'))
     import ctypes
     names = [lib.tg_frnet_kind_name(k).decode() for k in range(lib.tg_frnet_plan_kinds())]
-    k = names.index('conv3x3_wino_kernel')
-    nl = ctypes.c_int()
-    _lib.check(lib.tg_frnet_plan_kind_stats(plan.handle, k, ctypes.byref(nl), None, None), 'kind_stats')
-    assert nl.value == 25          # SRNet conv_in + 10 residual blocks, FNet's four 67x160 layers
+    nl, nc = ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.tg_frnet_plan_kind_stats(plan.handle, names.index('conv3x3_wino_kernel'), ctypes.byref(nl),
+                                            None, None), 'kind_stats')
+    _lib.check(lib.tg_frnet_plan_kind_stats(plan.handle, names.index('conv3x3_wino_chain_kernel'),
+                                            ctypes.byref(nc), None, None), 'kind_stats')
+    # SRNet conv_in + 10 residual blocks (21 launches, or one chained launch under TG_WINO_CHAIN=1) and
+    # FNet's four 67x160 layers
+    if 'TG_CONV_WINO' not in os.environ:        # (a forced rule changes the mix)
+        assert nl.value + 21 * nc.value == 25 and nc.value in (0, 1)
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,ks,pool', [
