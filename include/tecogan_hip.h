@@ -526,6 +526,10 @@ size_t tg_frnet_workspace_floats(const tg_frnet_cfg* cfg);
 int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weights* layers,
                          int n_layers, float* workspace, tg_frnet_plan** out);
 void tg_frnet_plan_destroy(tg_frnet_plan* plan);
+/* Float index, inside the plan's workspace, of the int32 error counter of the chained SRNet launch
+ * (tg_conv3x3_wino_chain: workgroups that gave up waiting for a producer flag; never observed), or -1
+ * when this plan's shape does not use the chained launch.  Read it after a synchronisation. */
+int64_t tg_frnet_plan_chain_error_index(const tg_frnet_plan* plan);
 /* hr_out may alias nothing else; lr_curr/lr_prev (n,c,h,w), hr_prev/hr_out (n,c,s*h,s*w).
  * u8_out (optional): (n, s*h, s*w, c) uint8 quantised frames (n > 1 needs the fused HR stage:
  * out_nc <= 3, nf <= 64). */

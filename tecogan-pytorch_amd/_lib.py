@@ -115,6 +115,7 @@ SIGNATURES = {
     'tg_frnet_plan_create': (I, [C.POINTER(FrnetCfg), C.POINTER(LayerWeights), I, P,
                                  C.POINTER(C.c_void_p)]),
     'tg_frnet_plan_destroy': (None, [P]),
+    'tg_frnet_plan_chain_error_index': (I64, [P]),
     'tg_frnet_step': (I, [P, P, P, P, P, P, P]),
     'tg_frnet_step_phase': (I, [P, I, I, P, P, P, P, P, P]),
     'tg_frnet_plan_launches': (I, [P]),

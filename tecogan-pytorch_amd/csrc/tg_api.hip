@@ -32,6 +32,8 @@ struct tg_frnet_plan {
   int32_t* CHAINF;                  // per-tile flags of the chained SRNet launch (tg_conv3x3_wino_chain)
   bool chain_ready;                 // flags zeroed
   int epoch;                        // one per chained launch
+  int chain_layers;                 // layers in the chained launch of this plan's shape (0: none)
+  const float* WS;                  // workspace base (for tg_frnet_plan_chain_error_index)
   int fh, fw, launches;
   int st_launch[16];
   double st_flops[16], st_bytes[16];
@@ -118,7 +120,7 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   size_t off[14];
   carve(cfg, off);
   p->WZ = workspace + off[11]; p->wz_ready = false;
-  p->CHAINF = reinterpret_cast<int32_t*>(workspace + off[12]); p->chain_ready = false; p->epoch = 0;
+  p->CHAINF = reinterpret_cast<int32_t*>(workspace + off[12]); p->chain_ready = false; p->epoch = 0; p->chain_layers = 0; p->WS = workspace;
   p->FA = workspace + off[7]; p->FB = workspace + off[8]; p->FPART = workspace + off[9];
   p->FLOW2 = workspace + off[10];
   p->PART = workspace + off[6];
@@ -347,6 +349,7 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
       by += 4.0 * px * (d.cin + nf + (conv2 ? nf : 0)) + 4.0 * 9 * d.cin * nf;
     }
     li += nchain;
+    p->chain_layers = nchain;
     go(K_WINO_CHAIN, fl, by, [&] {
       if (!p->chain_ready) {
         const size_t ints = (size_t)tg_conv3x3_wino_chain_flag_ints(nchain, n, h, w);
@@ -488,6 +491,16 @@ extern "C" int tg_frnet_replay(tg_frnet_plan* p, const float* lr_curr, const flo
     if (rc != TG_OK) return rc;
   }
   return TG_OK;
+}
+
+// Index (in floats, from the start of the plan's workspace) of the int32 error counter of the chained
+// SRNet launch -- the number of workgroups that gave up waiting for a producer flag -- or -1 when the
+// plan's shape does not use the chained launch.  The host mirror reads it after its per-clip sync.
+extern "C" int64_t tg_frnet_plan_chain_error_index(const tg_frnet_plan* p) {
+  if (!p || p->chain_layers <= 0) return -1;
+  const tg_frnet_cfg& c = p->cfg;
+  const int64_t ntile = (int64_t)c.n * tg::cdiv(c.h, 2) * tg::cdiv(c.w, 32);
+  return (reinterpret_cast<const float*>(p->CHAINF) - p->WS) + (int64_t)p->chain_layers * ntile;
 }
 
 extern "C" int tg_frnet_plan_kinds(void) { return K_COUNT; }

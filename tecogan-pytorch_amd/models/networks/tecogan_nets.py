@@ -230,6 +230,16 @@ class _StepPlan:
                                          self.workspace.data_ptr(), ctypes.byref(self.handle)),
                 'tg_frnet_plan_create')
 
+    def check_chain(self):
+        """Raise if a workgroup of the chained SRNet launch ever gave up waiting for a producer tile
+        (tg_conv3x3_wino_chain's poll limit): the frames would then be built on stale data."""
+        idx = L.lib().tg_frnet_plan_chain_error_index(self.handle)
+        if idx >= 0:
+            lost = int(self.workspace[idx:idx + 1].view(torch.int32).item())
+            if lost:
+                raise L.TecoganHipError(f'chained SRNet launch: {lost} workgroups timed out waiting for a '
+                                        f'producer tile; results are invalid (set TG_WINO_CHAIN=0 and report)')
+
     def __del__(self):
         try:
             if getattr(self, 'handle', None):
@@ -412,6 +422,7 @@ class FRNet(nn.Module):
             out = host_out.numpy()
         else:
             out = u8.cpu().numpy()
+        self._get_plan(k, h, w, dev).check_chain()   # (the clip has been synchronised: a 4-byte read)
         return out.transpose(1, 0, 2, 3, 4) if multi else out[:, 0]
 
     def _copy_stream(self, dev):
