@@ -25,8 +25,6 @@ Extra objects on the same line:
                 bit-checked against the reference in the authoring container)
                 timed on this host's cores on a bounded sample (N == 1 only).
 """
-import os
-os.environ.setdefault('DEBUG_HIP_DYNAMIC_QUEUES', '1')   # before the HIP runtime initialises (see tecogan_pytorch_amd/__init__.py)
 import argparse
 import ctypes
 import json
@@ -474,6 +472,7 @@ def main():
             net.infer_sequence(clip, dev, pipeline=pipe, return_device_tensor=True)  # exactly K steps
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)   # this rank's K steps; MAX over ranks below
+            net.check_faults()                       # fail-safe of chained launches (a host read, after the sync)
             barrier()                                # closing bracket (its own latency is not a step)
             torch.cuda.synchronize()
 
@@ -534,6 +533,7 @@ def main():
                 net.infer_sequence(clips4, dev, return_device_tensor=True)
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t1)
+            net.check_faults()
             sec['fps_4_clips_pipelined'] = nb * args.steps / sorted(ts)[1]
             del clips4
             # reference protocol: synchronise after every frame (main.py:257-259)

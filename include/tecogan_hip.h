@@ -10,7 +10,8 @@
  * Conventions
  *   - all tensors are fp32, contiguous NCHW unless a batch stride is given;
  *     pointers are DEVICE pointers owned by the caller (PyTorch allocates);
- *     the library never retains them past the call and never allocates;
+ *     the library never retains them past the call and never allocates device memory
+ *     (a frame plan owns one 64-byte pinned-host fault counter, see tg_frnet_plan_chain_status);
  *   - `*_nstride` = distance in floats between consecutive batch items, so a
  *     channel-slice of a larger buffer can be read / written in place (this is
  *     how every torch.cat on the path is folded away);
@@ -54,6 +55,12 @@ enum {
   TG_UP_BILINEAR = 2 /* F.interpolate bilinear align_corners=False (BI), :86-89 */
 };
 
+/* ABI version, major * 100 + minor.  The major number changes whenever a struct declared here
+ * changes size or an entry changes its signature (a host compiled against another major must not
+ * call in: check tg_version() / 100 == TG_ABI_MAJOR after dlopen).
+ *   1xx: round-1 ABI.   2xx: tg_layer_weights gained `u` (24 bytes, was 16);
+ *   tg_frnet_plan_chain_error_index replaced by tg_frnet_plan_chain_status. */
+#define TG_ABI_MAJOR 2
 int tg_version(void);
 const char* tg_last_error_string(void);
 
@@ -137,14 +144,17 @@ int tg_conv3x3_wino_fwd(const float* x, int64_t x_nstride, int c1, const float* 
  * blocks, tecogan_nets.py:108-116,141-143) in ONE launch.  Every separate launch of the Winograd
  * kernel pays ~10 us that nothing overlaps (launch, first loads, final stores); here the workgroups
  * of layer i+1 are dispatched behind those of layer i and start as soon as the 3x3 tile
- * neighbourhood they read has been written (per-tile flags, agent-scope loads / stores; a
- * workgroup only waits for workgroups dispatched before it, so the launch cannot deadlock, and a
- * poll limit turns a lost flag into an error count instead of a hang).
+ * neighbourhood they read has been written (per-tile flags, agent-scope loads / stores).  A
+ * workgroup only waits for workgroups with a smaller block index; forward progress relies on the
+ * dispatcher starting workgroups in block order (true of every CDNA part, not promised by HIP), so
+ * the kernel is fail-safe: a poll limit turns a lost flag into a fault count instead of a hang.
  *   layers[i]: as tg_conv3x3_wino_fwd (x2 / bias / res may be NULL; res is added after the
  *              activation; y may alias res: in-place residual sum); cout <= 64 for every layer.
  *   flags:     tg_conv3x3_wino_chain_flag_ints(n_layers, n, h, w) int32, caller owned, zeroed ONCE
- *              before the first call; its last 16 ints are an error counter the caller may read
- *              (non-zero: a workgroup gave up waiting -- never seen; results are then undefined).
+ *              before the first call; its last 16 ints are a fault counter the caller MUST read
+ *              after synchronising (non-zero: a workgroup gave up waiting -- never seen; the
+ *              results are then undefined.  The frame plan does this for its own chain, see
+ *              tg_frnet_plan_chain_status).
  *   epoch:     any non-zero value not used before with these flags (a frame counter).
  * Buffers may be reused along the chain only in the patterns of the reference's SRNet: a layer may
  * overwrite a tensor that the PREVIOUS layer read, or its own residual input. */
@@ -370,6 +380,9 @@ int tg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float beta1, float beta2, float eps, float weight_decay, int step,
                  tg_stream_t stream);
 int tg_axpy(float* y, const float* x, float a, int64_t n, tg_stream_t stream);
+/* y[i] = x[i] / d (y may alias x): the mean of an all-reduced gradient bucket, with the IEEE division
+ * DDP's `bucket / world_size` performs (base_model.py:130-136), exact for any world size. */
+int tg_div_scalar(float* y, const float* x, float d, int64_t n, tg_stream_t stream);
 /* BatchNorm2d (train mode, batch statistics, running stats updated with the unbiased
  * variance) + LeakyReLU(slope), tecogan_nets.py:322-340; and its backward. */
 int tg_bn_lrelu_train_fwd(const float* x, const float* gamma, const float* beta,
@@ -526,10 +539,21 @@ size_t tg_frnet_workspace_floats(const tg_frnet_cfg* cfg);
 int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weights* layers,
                          int n_layers, float* workspace, tg_frnet_plan** out);
 void tg_frnet_plan_destroy(tg_frnet_plan* plan);
-/* Float index, inside the plan's workspace, of the int32 error counter of the chained SRNet launch
- * (tg_conv3x3_wino_chain: workgroups that gave up waiting for a producer flag; never observed), or -1
- * when this plan's shape does not use the chained launch.  Read it after a synchronisation. */
-int64_t tg_frnet_plan_chain_error_index(const tg_frnet_plan* plan);
+/* Fail-safe of the chained SRNet launch (tg_conv3x3_wino_chain inside the plan).  A workgroup that
+ * gives up waiting for a producer tile counts a fault in a pinned-host counter the plan owns (64
+ * bytes of hipHostMalloc memory, the only allocation a plan makes) and carries on, so the launch
+ * always ends.  EVERY later tg_frnet_step* / tg_frnet_replay call on the plan looks at that counter
+ * first (a host read, no synchronisation): the first call that sees it non-zero returns TG_E_HIP
+ * ("frames since the fault are invalid") and switches the plan to one launch per layer for good;
+ * calls after that run normally on the fallback.  tg_frnet_plan_chain_status does the same check
+ * on demand (call it after a synchronisation: it then covers everything enqueued so far):
+ * returns TG_OK / TG_E_HIP as above, *faults_total = faults since creation, *chain_active = 1
+ * while the plan's shape still uses the chained launch.
+ * tg_frnet_plan_set_chain_poll_limit: polls (~64 shader cycles each) a waiter makes before it
+ * gives up; default 2^21 (~0.2 s).  A negative limit makes every waiter fault immediately
+ * (fault injection for tests of the host's error path). */
+int tg_frnet_plan_chain_status(tg_frnet_plan* plan, int* faults_total, int* chain_active);
+int tg_frnet_plan_set_chain_poll_limit(tg_frnet_plan* plan, int poll_limit);
 /* hr_out may alias nothing else; lr_curr/lr_prev (n,c,h,w), hr_prev/hr_out (n,c,s*h,s*w).
  * u8_out (optional): (n, s*h, s*w, c) uint8 quantised frames (n > 1 needs the fused HR stage:
  * out_nc <= 3, nf <= 64). */
@@ -575,6 +599,18 @@ int tg_frnet_replay(tg_frnet_plan* plan, const float* lr_curr, const float* lr_p
 int tg_frnet_step_masked(tg_frnet_plan* plan, const float* lr_curr, const float* lr_prev,
                          const float* hr_prev, float* hr_out, uint8_t* u8_out,
                          unsigned kind_mask, tg_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A stream with a hardware queue of its own.  The HIP runtime multiplexes ordinary streams onto a
+ * small pool of hardware queues (GPU_MAX_HW_QUEUES = 4, static round robin): two streams that land on
+ * the same queue serialise silently, which is what the FNet / SRNet overlap of infer_sequence
+ * (tecogan_nets.py:254-281) and the training step's side stream must not do.  A stream created
+ * with an explicit compute-unit mask is never pooled -- it gets a queue of its own -- so this
+ * entry creates one whose mask names EVERY compute unit of the device (no CU is reserved).
+ * The handle is a hipStream_t: pass it as `stream` to any entry here, wrap it with
+ * torch.cuda.ExternalStream, destroy it with tg_stream_destroy (after synchronising it). */
+int tg_stream_create_dedicated(int device, tg_stream_t* out);
+int tg_stream_destroy(tg_stream_t stream);
 
 #ifdef __cplusplus
 }

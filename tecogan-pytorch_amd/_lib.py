@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TECOGAN_HIP_LIB') or os.path.join(_HERE, 'libtecogan_hip.so')
 
 TG_OK = 0
+ABI_MAJOR = 2            # include/tecogan_hip.h TG_ABI_MAJOR
 ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_TANH24 = 0, 1, 2, 3
 UP_NONE, UP_BICUBIC, UP_BILINEAR = 0, 1, 2
 
@@ -79,6 +80,7 @@ SIGNATURES = {
     'tg_bce_logits': (I, [P, I64, F, F, P, F, P, P]),
     'tg_adam_step': (I, [P, P, P, P, I64, F, F, F, F, F, I, P]),
     'tg_axpy': (I, [P, P, F, I64, P]),
+    'tg_div_scalar': (I, [P, P, F, I64, P]),
     'tg_bn_lrelu_train_fwd': (I, [P, P, P, P, P, F, F, F, P, P, P, I, I, I, P]),
     'tg_bn_lrelu_train_bwd': (I, [P, P, P, P, P, P, F, P, P, P, I, P, I, I, I, P]),
     'tg_bn_local_stats': (I, [P, P, I, I, I, P]),
@@ -115,7 +117,10 @@ SIGNATURES = {
     'tg_frnet_plan_create': (I, [C.POINTER(FrnetCfg), C.POINTER(LayerWeights), I, P,
                                  C.POINTER(C.c_void_p)]),
     'tg_frnet_plan_destroy': (None, [P]),
-    'tg_frnet_plan_chain_error_index': (I64, [P]),
+    'tg_frnet_plan_chain_status': (I, [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'tg_frnet_plan_set_chain_poll_limit': (I, [P, I]),
+    'tg_stream_create_dedicated': (I, [I, C.POINTER(C.c_void_p)]),
+    'tg_stream_destroy': (I, [P]),
     'tg_frnet_step': (I, [P, P, P, P, P, P, P]),
     'tg_frnet_step_phase': (I, [P, I, I, P, P, P, P, P, P]),
     'tg_frnet_plan_launches': (I, [P]),
@@ -150,6 +155,10 @@ def lib():
         # runtimes coexist and ours sees no device.
         import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
+        handle.tg_version.restype = I
+        if handle.tg_version() // 100 != ABI_MAJOR:
+            raise TecoganHipError(f'{LIB_PATH}: ABI {handle.tg_version()} but this binding is written for '
+                                  f'major {ABI_MAJOR} (include/tecogan_hip.h TG_ABI_MAJOR): rebuild the library')
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError if a symbol is missing
             fn.restype = res

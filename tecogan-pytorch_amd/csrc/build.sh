@@ -4,6 +4,12 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=on -Wall -Wno-unused-function"
+# objects are reused only when they were compiled with the same flags
+STAMP=".build_flags"
+if [ ! -f "$STAMP" ] || [ "$(cat $STAMP)" != "$FLAGS ${EXTRA_FLAGS:-}" ]; then
+  rm -f tg_*.o
+  echo "$FLAGS ${EXTRA_FLAGS:-}" > "$STAMP"
+fi
 OBJS=()
 PIDS=()
 for f in tg_*.hip; do

@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace tg
 
-extern "C" int tg_version(void) { return 100; }
+extern "C" int tg_version(void) { return TG_ABI_MAJOR * 100 + 0; }
 extern "C" const char* tg_last_error_string(void) { return tg::g_err; }
 
 // ---------------------------------------------------------------------------
@@ -31,9 +31,14 @@ struct tg_frnet_plan {
   bool wz_ready;
   int32_t* CHAINF;                  // per-tile flags of the chained SRNet launch (tg_conv3x3_wino_chain)
   bool chain_ready;                 // flags zeroed
-  int epoch;                        // one per chained launch
+  unsigned epoch;                   // one per chained launch
   int chain_layers;                 // layers in the chained launch of this plan's shape (0: none)
-  const float* WS;                  // workspace base (for tg_frnet_plan_chain_error_index)
+  // fail-safe of the chained launch: fault counter in pinned host memory (the kernel adds to it
+  // with system scope), looked at by every later call on the plan
+  int32_t* chain_err;               // hipHostMalloc, 64 bytes; null when the allocation failed (chain then off)
+  bool chain_disabled;              // a fault was reported: one launch per layer from then on
+  int chain_faults;                 // faults reported so far
+  int chain_poll_limit;
   int fh, fw, launches;
   int st_launch[16];
   double st_flops[16], st_bytes[16];
@@ -44,6 +49,21 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
                      const float* hr_prev, float* hr_out, uint8_t* u8_out, tg_stream_t st,
                      unsigned mask, bool dry, int phases = 3, int slot = 0,
                      const float* flow_ext = nullptr);
+
+// Fail-safe of the chained launch: a host read of the pinned fault counter.  The first call that
+// sees faults reports them (TG_E_HIP) and turns the chain off for the rest of the plan's life.
+static int chain_poll(tg_frnet_plan* p) {
+  if (!p->chain_err) return TG_OK;
+  const int pending = __atomic_load_n(p->chain_err, __ATOMIC_RELAXED);
+  if (pending == 0) return TG_OK;
+  __atomic_fetch_sub(p->chain_err, pending, __ATOMIC_RELAXED);
+  p->chain_faults += pending;
+  p->chain_disabled = true;
+  tg::set_error("chained SRNet launch: %d workgroup(s) timed out waiting for a producer tile; the frames "
+                "enqueued on this plan since the previous successful check are INVALID.  The plan now runs "
+                "one launch per layer (TG_WINO_CHAIN=0 selects that from the start)", pending);
+  return TG_E_HIP;
+}
 
 static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
 
@@ -120,7 +140,17 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   size_t off[14];
   carve(cfg, off);
   p->WZ = workspace + off[11]; p->wz_ready = false;
-  p->CHAINF = reinterpret_cast<int32_t*>(workspace + off[12]); p->chain_ready = false; p->epoch = 0; p->chain_layers = 0; p->WS = workspace;
+  p->CHAINF = reinterpret_cast<int32_t*>(workspace + off[12]); p->chain_ready = false; p->epoch = 0; p->chain_layers = 0;
+  p->chain_err = nullptr; p->chain_disabled = false; p->chain_faults = 0; p->chain_poll_limit = tg::TG_CHAIN_POLL_LIMIT_DEFAULT;
+  if (!cfg->fnet_only) {
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hp) {
+      p->chain_err = static_cast<int32_t*>(hp);
+      for (int i = 0; i < 16; ++i) p->chain_err[i] = 0;
+    } else {
+      (void)hipGetLastError();      // no fault channel -> no chained launch (per-layer launches are always safe)
+    }
+  }
   p->FA = workspace + off[7]; p->FB = workspace + off[8]; p->FPART = workspace + off[9];
   p->FLOW2 = workspace + off[10];
   p->PART = workspace + off[6];
@@ -140,7 +170,13 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   return TG_OK;
 }
 
-extern "C" void tg_frnet_plan_destroy(tg_frnet_plan* plan) { delete plan; }
+extern "C" void tg_frnet_plan_destroy(tg_frnet_plan* plan) {
+  if (!plan) return;
+  // (a chained launch still in flight may yet add to the counter: the caller synchronises before
+  // destroying a plan, as for the workspace it owns)
+  if (plan->chain_err) (void)hipHostFree(plan->chain_err);
+  delete plan;
+}
 extern "C" int tg_frnet_plan_launches(const tg_frnet_plan* plan) { return plan ? plan->launches : 0; }
 
 // Launch classes = distinct kernel symbols (what rocprofv3 --stats groups by).
@@ -168,7 +204,7 @@ enum {
 // ConvTranspose2d emits the 27 tap planes of conv_out (tecogan_nets.py:119-131), a streaming
 // kernel shift-adds them.  TG_HR_FUSE=0 selects the unfused launches (lab / A-B).
 static bool hr_fuse_enabled() {
-  static const int v = [] { const char* e = getenv("TG_HR_FUSE"); return e ? atoi(e) : 1; }();
+  static const int v = TG_LAB_ENV("TG_HR_FUSE", 1);
   return v != 0;
 }
 // SRNet's 1 + 2*nb full-resolution layers as one chained launch (tg_conv3x3_wino_chain) when a layer
@@ -318,7 +354,7 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
   const bool in_wino = p->L[li].u && tg_conv3x3_prefers_wino(n, c.in_nc + s2dc, nf, h, w);
   const int skip = in_wino ? 0 : 1;
   const int nchain = 1 + 2 * c.nb - skip;
-  bool chain = nf <= 64 && nchain >= 2 && nchain <= CHAIN_MAX_LAYERS &&
+  bool chain = p->chain_err && !p->chain_disabled && nf <= 64 && nchain >= 2 && nchain <= CHAIN_MAX_LAYERS &&
                chain_wanted((long long)n * tg::cdiv(h, 2) * tg::cdiv(w, 32)) &&
                tg_conv3x3_prefers_wino(n, nf, nf, h, w);
   for (int i = skip; i < 1 + 2 * c.nb && chain; ++i) chain = p->L[li + i].u != nullptr;
@@ -358,7 +394,8 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
         p->chain_ready = true;
       }
       if (++p->epoch == 0) p->epoch = 1;
-      return tg_conv3x3_wino_chain(cl, nchain, n, nf, h, w, p->CHAINF, p->epoch, st);
+      return tg::conv3x3_wino_chain_launch(cl, nchain, n, nf, h, w, p->CHAINF, p->chain_err, p->epoch,
+                                           p->chain_poll_limit, st);
     });
   } else {
     conv(lr_curr, c.in_nc * hw, c.in_nc, p->S2D, s2dc * hw, c.in_nc + s2dc, nf, h, w, TG_ACT_RELU,
@@ -448,6 +485,7 @@ extern "C" int tg_frnet_step_masked(tg_frnet_plan* p, const float* lr_curr, cons
   TG_REQUIRE(p && lr_curr && lr_prev && hr_prev && hr_out, TG_E_ARG, "frnet_step: null pointer");
   TG_REQUIRE(!u8_out || plan_u8_ok(p), TG_E_ARG, "frnet_step: u8 output needs n == 1 (or the fused HR stage)");
   TG_REQUIRE(!p->cfg.fnet_only, TG_E_ARG, "frnet_step: the plan was created FNet-only");
+  if (int rc = chain_poll(p)) return rc;
   return step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, u8_out, st, kind_mask, false);
 }
 
@@ -462,6 +500,7 @@ extern "C" int tg_frnet_step_srnet(tg_frnet_plan* p, const float* lr_flow, const
   TG_REQUIRE(p && lr_flow && lr_curr && hr_prev && hr_out, TG_E_ARG, "frnet_step_srnet: null pointer");
   TG_REQUIRE(!p->cfg.fnet_only, TG_E_ARG, "frnet_step_srnet: the plan was created FNet-only");
   TG_REQUIRE(!u8_out || plan_u8_ok(p), TG_E_ARG, "frnet_step_srnet: u8 output needs n == 1 (or the fused HR stage)");
+  if (int rc = chain_poll(p)) return rc;
   return step_impl(p, lr_curr, nullptr, hr_prev, hr_out, u8_out, st, 0xFFFFFFFFu, false, 2, 0, lr_flow);
 }
 
@@ -475,6 +514,7 @@ extern "C" int tg_frnet_step_phase(tg_frnet_plan* p, int phases, int flow_slot, 
   TG_REQUIRE(!(phases & 2) || (hr_prev && hr_out), TG_E_ARG, "frnet_step_phase: phase 2 needs hr_prev/hr_out");
   TG_REQUIRE(!u8_out || plan_u8_ok(p), TG_E_ARG, "frnet_step_phase: u8 output needs n == 1 (or the fused HR stage)");
   TG_REQUIRE(!(phases & 2) || !p->cfg.fnet_only, TG_E_ARG, "frnet_step_phase: the plan was created FNet-only");
+  if (int rc = chain_poll(p)) return rc;
   return step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, u8_out, st, 0xFFFFFFFFu, false, phases,
                    flow_slot);
 }
@@ -486,6 +526,7 @@ extern "C" int tg_frnet_replay(tg_frnet_plan* p, const float* lr_curr, const flo
                                tg_stream_t st) {
   TG_REQUIRE(p && lr_curr && lr_prev && hr_prev && hr_out && reps > 0 && !p->cfg.fnet_only, TG_E_ARG,
              "frnet_replay: bad argument");
+  if (int rc = chain_poll(p)) return rc;
   for (int i = 0; i < reps; ++i) {
     int rc = step_impl(p, lr_curr, lr_prev, hr_prev, hr_out, nullptr, st, kind_mask, false);
     if (rc != TG_OK) return rc;
@@ -493,14 +534,47 @@ extern "C" int tg_frnet_replay(tg_frnet_plan* p, const float* lr_curr, const flo
   return TG_OK;
 }
 
-// Index (in floats, from the start of the plan's workspace) of the int32 error counter of the chained
-// SRNet launch -- the number of workgroups that gave up waiting for a producer flag -- or -1 when the
-// plan's shape does not use the chained launch.  The host mirror reads it after its per-clip sync.
-extern "C" int64_t tg_frnet_plan_chain_error_index(const tg_frnet_plan* p) {
-  if (!p || p->chain_layers <= 0) return -1;
-  const tg_frnet_cfg& c = p->cfg;
-  const int64_t ntile = (int64_t)c.n * tg::cdiv(c.h, 2) * tg::cdiv(c.w, 32);
-  return (reinterpret_cast<const float*>(p->CHAINF) - p->WS) + (int64_t)p->chain_layers * ntile;
+extern "C" int tg_frnet_plan_chain_status(tg_frnet_plan* p, int* faults_total, int* chain_active) {
+  TG_REQUIRE(p, TG_E_ARG, "frnet_plan_chain_status: null plan");
+  const int rc = chain_poll(p);
+  if (faults_total) *faults_total = p->chain_faults;
+  if (chain_active) *chain_active = (p->chain_layers > 0 && !p->chain_disabled) ? 1 : 0;
+  return rc;
+}
+
+extern "C" int tg_frnet_plan_set_chain_poll_limit(tg_frnet_plan* p, int poll_limit) {
+  TG_REQUIRE(p, TG_E_ARG, "frnet_plan_set_chain_poll_limit: null plan");
+  p->chain_poll_limit = poll_limit;
+  return TG_OK;
+}
+
+extern "C" int tg_stream_create_dedicated(int device, tg_stream_t* out) {
+  TG_REQUIRE(out, TG_E_ARG, "stream_create_dedicated: null pointer");
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return tg::check_launch("stream_create_dedicated: hipGetDevice");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return tg::check_launch("stream_create_dedicated: properties");
+  const int ncu = prop.multiProcessorCount;
+  TG_REQUIRE(ncu > 0, TG_E_HIP, "stream_create_dedicated: device %d reports %d compute units", device, ncu);
+  std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+  for (int i = 0; i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+  hipStream_t st = nullptr;
+  if (cur != device && hipSetDevice(device) != hipSuccess) return tg::check_launch("stream_create_dedicated: hipSetDevice");
+  const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data());
+  if (cur != device) (void)hipSetDevice(cur);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    tg::set_error("stream_create_dedicated: hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    return TG_E_HIP;
+  }
+  *out = (tg_stream_t)st;
+  return TG_OK;
+}
+
+extern "C" int tg_stream_destroy(tg_stream_t stream) {
+  TG_REQUIRE(stream, TG_E_ARG, "stream_destroy: null stream");
+  if (hipStreamDestroy((hipStream_t)stream) != hipSuccess) return tg::check_launch("stream_destroy");
+  return TG_OK;
 }
 
 extern "C" int tg_frnet_plan_kinds(void) { return K_COUNT; }

@@ -5,7 +5,22 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <stdlib.h>
+
 #include "../../include/tecogan_hip.h"
+
+// Tuning / ablation switches read from the environment exist only in lab builds
+// (tools/build_lab_libs.sh, -DTG_LAB=1).  The shipped library reads exactly two variables,
+// both documented in INTEGRATION.md: TG_CONV_WINO and TG_WINO_CHAIN (kernel-form selection for
+// A/B runs; every setting produces reference-parity results).
+#ifndef TG_LAB
+#define TG_LAB 0
+#endif
+#if TG_LAB
+#define TG_LAB_ENV(name, dflt) ([] { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#else
+#define TG_LAB_ENV(name, dflt) (dflt)
+#endif
 
 namespace tg {
 
@@ -54,6 +69,12 @@ int conv3x3_wino_launch(const float* x, int64_t x_ns, int c1, const float* x2, i
                         const float* bias, const float* res, int64_t res_ns, const float* mask,
                         int64_t mask_ns, float* y, int64_t y_ns, int n, int cin, int cout, int h, int w,
                         int act, tg_stream_t stream);
+
+// several dependent Winograd layers in one launch (tg_conv3x3_wino.hip); err: int32 fault counter in
+// device or pinned host memory, poll_limit < 0 injects a fault into every waiting workgroup
+constexpr int TG_CHAIN_POLL_LIMIT_DEFAULT = 1 << 21;
+int conv3x3_wino_chain_launch(const tg_wino_layer* layers, int n_layers, int n, int cout, int h, int w,
+                              int32_t* flags, int32_t* err, unsigned epoch, int poll_limit, tg_stream_t stream);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -685,7 +685,7 @@ static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n * a.ksplit;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "conv3x3: grid %lld", blocks);
   // XCD banding pays when a band is many tile rows deep; TG_CONV_XCD=0/1 overrides (lab)
-  static const int xcd_env = [] { const char* e = getenv("TG_CONV_XCD"); return e ? atoi(e) : -1; }();
+  static const int xcd_env = TG_LAB_ENV("TG_CONV_XCD", -1);
   const bool xcd = xcd_env >= 0 ? xcd_env != 0 : blocks >= 512;
   a.nblocks = xcd ? (int)blocks : 0;
   const unsigned grid = xcd ? (unsigned)(8 * ((blocks + 7) / 8)) : (unsigned)blocks;
@@ -735,12 +735,12 @@ __global__ void splitk_finalize_kernel(const float* __restrict__ part, int S, lo
 namespace tg {
 // the one-shot kernel: the K-split variant's shapes with cin <= 64 (<= 8 chunks) and one oc block
 bool conv3x3_uses_oneshot(int n, int cin, int cout, int h, int w) {
-  static const int env = [] { const char* e = getenv("TG_CONV_ONESHOT"); return e ? atoi(e) : 1; }();
+  static const int env = TG_LAB_ENV("TG_CONV_ONESHOT", 1);
   return env && cout <= 64 && cdiv(cin, CK) <= 8 && conv3x3_uses_wg_ksplit(n, cin, cout, h, w);
 }
 
 bool conv3x3_uses_wg_ksplit(int n, int cin, int cout, int h, int w) {
-  static const int ks_env = [] { const char* e = getenv("TG_CONV_WG_KSPLIT"); return e ? atoi(e) : 1; }();
+  static const int ks_env = TG_LAB_ENV("TG_CONV_WG_KSPLIT", 1);
   if (!ks_env || tg_conv3x3_pick_ocb(cout) != 64 || conv3x3_rows_per_wg(64, (long long)n * h * w) != 2)
     return false;
   const long long wgs2 = (long long)cdiv(w, TW) * cdiv(h, 2) * cdiv(cout, 64) * n;
@@ -761,7 +761,7 @@ extern "C" int tg_conv3x3_pick_ksplit(int n, int cin, int cout, int h, int w) {
   int rows = conv3x3_rows_per_wg(ocb, (long long)n * h * w);
   const double wgs = (double)cdiv(w, TW) * cdiv(h, rows) * cdiv(cout, ocb) * n;
   const int nchunk = cdiv(cin, CK);
-  static const int legacy = [] { const char* e = getenv("TG_KSPLIT_LEGACY"); return e ? atoi(e) : 0; }();
+  static const int legacy = TG_LAB_ENV("TG_KSPLIT_LEGACY", 0);
   if (legacy) {   // lab: the round-1 rule (fill ~640 workgroup slots)
     if (wgs >= 400 || nchunk < 4) return 1;
     int ks = 1;

@@ -359,18 +359,28 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
 // ---- several dependent layers in ONE launch ----------------------------------------------------
 // Every launch of the kernel above pays ~10 us that nothing overlaps (launch, first loads, the
 // final stores: all workgroups are resident at once and walk the same timeline).  Here the
-// workgroups of layer k+1 are dispatched right behind those of layer k (same grid, in-order
-// dispatch per XCD) and start as soon as the 3x3 tile neighbourhood they read has been written:
+// workgroups of layer k+1 are dispatched right behind those of layer k (same grid) and start as
+// soon as the 3x3 tile neighbourhood they read has been written:
 //   * flag[layer][tile] = epoch is stored (agent scope) after the tile's stores have left the
-//     workgroup; a consumer polls the <= 9 flags of its neighbourhood (s_sleep between polls, a
-//     poll limit instead of a hang: err[0] counts bail-outs);
+//     workgroup; a consumer polls the <= 9 flags of its neighbourhood (s_sleep between polls);
 //   * that neighbourhood also covers the write-after-read hazards of SRNet's buffers (in-place
 //     residual sum, two ping-pong tensors): whoever still reads the old content of tile T is one
 //     of the tiles T's writer waits for;
-//   * a workgroup only ever waits for workgroups dispatched BEFORE it, so the launch cannot
-//     deadlock however few of them are resident;
 //   * activations use sc1 loads / stores (COH above): no L2 invalidation between layers, the
 //     weights stay cached.
+// Memory model: the producer's data stores are agent-scope write-through (sc1); `s_waitcnt 0`
+// returns once every one of them has been acknowledged at the coherence point, the workgroup
+// barrier extends that to all four waves, and only then is the flag stored -- the flag therefore
+// cannot become visible before the data (release).  The consumer's data loads are sc1 as well:
+// they never hit a stale line of its own XCD's L2 / L1, and they are issued after the flag was
+// seen and a workgroup barrier (acquire).  No cache invalidation is needed on either side.
+// HARDWARE REQUIREMENT (forward progress): a workgroup only ever waits for workgroups with a
+// smaller blockIdx.  The launch relies on the dispatcher starting workgroups in blockIdx order
+// per XCD (what every CDNA part does, but HIP does not promise it).  The kernel is therefore
+// FAIL-SAFE rather than trusting: a poll limit (~0.2 s) ends the wait, the workgroup counts a
+// fault in *err (system scope: the plan points it at pinned host memory) and carries on so the
+// launch always terminates; the owner of the plan sees the fault on its next call, reports
+// TG_E_HIP and falls back to one launch per layer for good (tg_api.hip: chain_poll).
 struct WinoLayer {
   const float *x, *x2, *u, *bias, *res;
   float* y;
@@ -383,8 +393,9 @@ struct WinoChainArgs {
   int nlayer, bpl;           // blocks per layer in the grid (tiles rounded up to a multiple of 8)
   int cout, h, w, tiles_x, tiles_y, ntile, vec_ok;
   int* flags;                // [nlayer][ntile]
-  int* err;
-  int epoch;
+  int* err;                  // fault counter: device memory (flag buffer tail) or pinned host memory (plan)
+  unsigned epoch;
+  int poll_limit;            // polls of ~64 cycles before a waiter gives up; < 0: every waiter faults at once (fault-injection tests)
 };
 
 template <bool COHX>
@@ -412,12 +423,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_chain_kernel(WinoChainArg
     if (t < 9) {
       const int ny = ty - 1 + t / 3, nx = tx - 1 + t % 3;
       if (ny >= 0 && ny < c.tiles_y && nx >= 0 && nx < c.tiles_x) {
-        const int* f = c.flags + (size_t)(layer - 1) * c.ntile + (n * c.tiles_y + ny) * c.tiles_x + nx;
+        const unsigned* f = reinterpret_cast<const unsigned*>(c.flags) + (size_t)(layer - 1) * c.ntile + (n * c.tiles_y + ny) * c.tiles_x + nx;
         int polls = 0;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != c.epoch) {
+        bool fault = c.poll_limit < 0;
+        while (!fault && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != c.epoch) {
           __builtin_amdgcn_s_sleep(4);
-          if (++polls > (1 << 21)) { atomicAdd(c.err, 1); break; }
+          fault = ++polls > c.poll_limit;
         }
+        if (fault) __hip_atomic_fetch_add(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     __syncthreads();
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_chain_kernel(WinoChainArg
   __builtin_amdgcn_s_waitcnt(0);              // this wave's stores have been acknowledged
   __syncthreads();
   if (threadIdx.x == 0)
-    __hip_atomic_store(c.flags + (size_t)layer * c.ntile + tile, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(c.flags) + (size_t)layer * c.ntile + tile, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace tg
@@ -480,10 +493,10 @@ int conv3x3_wino_launch(const float* x, int64_t x_ns, int c1, const float* x2, i
   auto al8 = [](const void* p, int64_t ns) { return ((uintptr_t)p % 8) == 0 && ns % 2 == 0; };
   a.vec_ok = (w % 2 == 0) && ((int64_t)h * w) % 2 == 0 && al8(y, y_ns) && (!res || al8(res, res_ns)) &&
              (!mask || al8(mask, mask_ns));
-  static const int abl_env = [] { const char* e = getenv("TG_WINO_ABL"); return e ? atoi(e) : 0; }();
+  static const int abl_env = TG_LAB_ENV("TG_WINO_ABL", 0);
   a.abl = abl_env;
   const long long blocks = (long long)a.tiles_x * a.tiles_y * a.nocg * n;
-  static const int xcd_env = [] { const char* e = getenv("TG_WINO_XCD"); return e ? atoi(e) : -1; }();   // lab
+  static const int xcd_env = TG_LAB_ENV("TG_WINO_XCD", -1);   // lab
   const bool xcd = xcd_env >= 0 ? xcd_env != 0 : blocks >= 512;
   a.nblocks = xcd ? (int)blocks : 0;
   const unsigned grid = xcd ? (unsigned)(8 * ((blocks + 7) / 8)) : (unsigned)blocks;
@@ -532,9 +545,10 @@ extern "C" int64_t tg_conv3x3_wino_chain_flag_ints(int n_layers, int n, int h, i
   return (int64_t)n_layers * n * cdiv(h, 2) * cdiv(w, 32) + 16;     // + the error counter (last 16 ints)
 }
 
-extern "C" int tg_conv3x3_wino_chain(const tg_wino_layer* layers, int n_layers, int n, int cout, int h, int w,
-                                     int32_t* flags, int epoch, tg_stream_t stream) {
-  TG_REQUIRE(layers && flags, TG_E_ARG, "conv3x3_wino_chain: null pointer");
+namespace tg {
+int conv3x3_wino_chain_launch(const tg_wino_layer* layers, int n_layers, int n, int cout, int h, int w,
+                              int32_t* flags, int32_t* err, unsigned epoch, int poll_limit, tg_stream_t stream) {
+  TG_REQUIRE(layers && flags && err, TG_E_ARG, "conv3x3_wino_chain: null pointer");
   TG_REQUIRE(n_layers >= 1 && n_layers <= W_MAX_CHAIN, TG_E_ARG, "conv3x3_wino_chain: %d layers (1..%d)", n_layers, W_MAX_CHAIN);
   TG_REQUIRE(n > 0 && h > 0 && w > 0 && cout > 0 && cout <= 64, TG_E_SHAPE,
              "conv3x3_wino_chain: n=%d cout=%d (<= 64: one output-channel group) h=%d w=%d", n, cout, h, w);
@@ -546,7 +560,7 @@ extern "C" int tg_conv3x3_wino_chain(const tg_wino_layer* layers, int n_layers, 
   TG_REQUIRE(ntile * n_layers < (1ll << 30), TG_E_SHAPE, "conv3x3_wino_chain: too many tiles");
   c.ntile = (int)ntile;
   c.bpl = (int)(8 * ((ntile + 7) / 8));
-  c.flags = flags; c.err = flags + (size_t)n_layers * ntile; c.epoch = epoch;
+  c.flags = flags; c.err = err; c.epoch = epoch; c.poll_limit = poll_limit;
   bool vec = (w % 2 == 0) && ((int64_t)h * w) % 2 == 0;
   auto al8 = [](const void* p, int64_t ns) { return ((uintptr_t)p % 8) == 0 && ns % 2 == 0; };
   for (int i = 0; i < n_layers; ++i) {
@@ -562,9 +576,26 @@ extern "C" int tg_conv3x3_wino_chain(const tg_wino_layer* layers, int n_layers, 
     vec = vec && al8(l.y, l.y_nstride) && (!l.res || al8(l.res, l.res_nstride));
   }
   c.vec_ok = vec ? 1 : 0;
-  static const int noncoh = [] { const char* e = getenv("TG_WINO_CHAIN_NONCOH"); return e ? atoi(e) : 0; }();   // lab: timing only, results may be stale
-  static const int pad_lds = [] { const char* e = getenv("TG_WINO_CHAIN_LDS"); return e ? atoi(e) : 0; }();   // lab: dynamic LDS to cap residency
-  if (noncoh) hipLaunchKernelGGL(conv3x3_wino_chain_kernel<false>, dim3((unsigned)(c.bpl * n_layers)), dim3(256), pad_lds, (hipStream_t)stream, c);
-  else hipLaunchKernelGGL(conv3x3_wino_chain_kernel<true>, dim3((unsigned)(c.bpl * n_layers)), dim3(256), pad_lds, (hipStream_t)stream, c);
+  const unsigned grid = (unsigned)(c.bpl * n_layers);
+#if TG_LAB
+  static const int noncoh = TG_LAB_ENV("TG_WINO_CHAIN_NONCOH", 0);   // timing only: results may be stale
+  static const int pad_lds = TG_LAB_ENV("TG_WINO_CHAIN_LDS", 0);     // dynamic LDS to cap residency
+  if (noncoh) {
+    hipLaunchKernelGGL(conv3x3_wino_chain_kernel<false>, dim3(grid), dim3(256), pad_lds, (hipStream_t)stream, c);
+    return check_launch("conv3x3_wino_chain");
+  }
+  hipLaunchKernelGGL(conv3x3_wino_chain_kernel<true>, dim3(grid), dim3(256), pad_lds, (hipStream_t)stream, c);
+#else
+  hipLaunchKernelGGL(conv3x3_wino_chain_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, c);
+#endif
   return check_launch("conv3x3_wino_chain");
+}
+}  // namespace tg
+
+extern "C" int tg_conv3x3_wino_chain(const tg_wino_layer* layers, int n_layers, int n, int cout, int h, int w,
+                                     int32_t* flags, int epoch, tg_stream_t stream) {
+  TG_REQUIRE(flags && n_layers >= 1 && n > 0 && h > 0 && w > 0, TG_E_ARG, "conv3x3_wino_chain: bad argument");
+  const long long ntile = (long long)cdiv(w, 32) * cdiv(h, 2) * n;
+  return conv3x3_wino_chain_launch(layers, n_layers, n, cout, h, w, flags, flags + (size_t)n_layers * ntile,
+                                   (unsigned)epoch, TG_CHAIN_POLL_LIMIT_DEFAULT, stream);
 }

@@ -382,7 +382,7 @@ extern "C" int tg_convt3x3s2_fwd(const float* x, int64_t x_nstride, const float*
   // 4-row workgroups (8 waves) unless that leaves fewer than two workgroups per CU: a 134x320
   // input is 340 of them = 1.33 per CU (the CUs with two finish last: 66 % balance); 2-row
   // workgroups (670 = 2.62 per CU, 87 %) take the small frames.  TG_CONVT_ROWS overrides (lab).
-  static const int rows_env = [] { const char* e = getenv("TG_CONVT_ROWS"); return e ? atoi(e) : 0; }();
+  static const int rows_env = TG_LAB_ENV("TG_CONVT_ROWS", 0);
   const long long wg4 = (long long)a.tiles_x * cdiv(h, 4) * a.nocg * n;
   const int rows = rows_env == 2 || rows_env == 4 ? rows_env : (wg4 < 512 ? 2 : 4);
   a.tiles_y = cdiv(h, rows);
@@ -420,7 +420,7 @@ extern "C" int tg_convt3x3s2_z_fwd(const float* x, int64_t x_nstride, const floa
   a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
   a.wz = wz; a.z = z; a.z_ns = z_nstride; a.zrows = 9 * cz;
   constexpr int WN = 2;
-  static const int rows_env = [] { const char* e = getenv("TG_CONVTZ_ROWS"); return e ? atoi(e) : 0; }();
+  static const int rows_env = TG_LAB_ENV("TG_CONVTZ_ROWS", 0);
   a.tiles_x = cdiv(w, TTW); a.nocg = 1; a.nchunk = cdiv(cin, CK);
   // same balance rule as tg_convt3x3s2_fwd (at 268x640, 1340 four-row workgroups, the two-row form
   // measured 153 vs 148 us: more workgroups than slots are balanced by the dispatcher anyway)

@@ -382,6 +382,10 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
   TG_GRID_STRIDE(i, n) y[i] += a * x[i];
 }
 
+__global__ void div_scalar_kernel(float* __restrict__ y, const float* __restrict__ x, float d, long long n) {
+  TG_GRID_STRIDE(i, n) y[i] = x[i] / d;        // IEEE division: what DDP's `grad / world_size` computes
+}
+
 // ---- BatchNorm2d (train) + LeakyReLU(0.2) fused ---------------------------------
 // stats: one block per channel -> mean, invstd (biased var), running stats update
 __global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict__ x, int n, int c,
@@ -646,6 +650,12 @@ extern "C" int tg_adam_step(float* p, const float* g, float* m, float* v, int64_
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, g, m, v, (long long)n, lr,
                      beta1, beta2, eps, weight_decay, bc1, sbc2);
   return check_launch("adam_step");
+}
+
+extern "C" int tg_div_scalar(float* y, const float* x, float d, int64_t n, tg_stream_t stream) {
+  TG_REQUIRE(y && x && n > 0 && d != 0.f, TG_E_ARG, "div_scalar: bad argument");
+  hipLaunchKernelGGL(div_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, ST, y, x, d, (long long)n);
+  return check_launch("div_scalar");
 }
 
 extern "C" int tg_axpy(float* y, const float* x, float a, int64_t n, tg_stream_t stream) {

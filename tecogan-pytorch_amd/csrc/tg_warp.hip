@@ -524,7 +524,7 @@ extern "C" int tg_flowup_warp_s2d_fwd(const float* lr_flow, int fh, int fw, cons
   // is then bound by the per-wave dependency chain: 1 row per thread = twice the waves, half
   // the chain (7.1 vs 8.0 us).  Many clips per launch are throughput-bound and prefer fewer,
   // longer waves (46 vs 49 us at 8 clips).  TG_WARP_RPT overrides (lab).
-  static const int rpt_env = [] { const char* e = getenv("TG_WARP_RPT"); return e ? atoi(e) : 0; }();
+  static const int rpt_env = TG_LAB_ENV("TG_WARP_RPT", 0);
   const int rpt = rpt_env ? rpt_env : (tiles <= 2048 ? 1 : 2);
   if (scale == 4) {
     if (rpt == 2) hipLaunchKernelGGL((flowup_warp_s2d_kernel<4, 3, 4, 2>), dim3(tiles), dim3(256), 0, s, a);

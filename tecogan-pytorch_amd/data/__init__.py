@@ -41,7 +41,10 @@ class TrainSource:
         per = len(self.dataset) if not self.dist else -(-len(self.dataset) // self.world)
         return per // self.batch
 
-    def epoch(self, epoch=0):
+    def epoch(self, epoch=0, first_batch=0):
+        """Batches of one epoch; `first_batch` > 0 skips that many (a resumed run: the geometry of
+        the skipped samples is still drawn, so the random streams stay aligned with an
+        uninterrupted epoch)."""
         n = len(self.dataset)
         g = torch.Generator()
         g.manual_seed(self.seed + epoch)
@@ -51,7 +54,8 @@ class TrainSource:
             order = (order + order[:total - n])[self.rank:total:self.world]
         for b in range(len(order) // self.batch):
             plans = [self.dataset.draw_plan(i) for i in order[b * self.batch:(b + 1) * self.batch]]
-            yield {'gt': self.store.gather(plans)}
+            if b >= first_batch:
+                yield {'gt': self.store.gather(plans)}
 
     def __iter__(self):
         return self.epoch(0)

@@ -20,30 +20,58 @@ class DeviceClipStore:
         self.index = {}            # key -> (byte offset, h, w)
         self.buf = None
 
+    STAGE_BYTES = 64 << 20         # pinned staging buffer of the upload
+
     @classmethod
-    def from_frames(cls, frames, device='cuda'):
-        """frames: iterable of (key, uint8 array-like / bytes of h*w*3) with LMDB key names."""
+    def from_frames(cls, frames, device='cuda', channels=3):
+        """frames: iterable of (key, uint8 array-like / bytes of h*w*channels) with LMDB key names,
+        or a (keys, getter) pair for sources that can be walked twice (from_lmdb).  The device
+        buffer is sized from the key names (they carry the frame size) and filled through one
+        pinned staging buffer -- no second host copy of the data set."""
         self = cls(device)
-        chunks, off = [], 0
-        for key, data in frames:
+        if isinstance(frames, tuple) and len(frames) == 2 and callable(frames[1]):
+            keys, get = frames
+        else:
+            items = list(frames)
+            keys, table = [k for k, _ in items], dict(items)
+            get = table.__getitem__
+        off = 0
+        for key in keys:
             _, (_, h, w), _ = parse_lmdb_key(key)
+            self.index[key] = (off, h, w)
+            off += (h * w * channels + 15) // 16 * 16          # 16-byte aligned frames
+        self.buf = torch.zeros(off, dtype=torch.uint8, device=self.device)
+        pin = self.device.type == 'cuda'
+        stage = torch.empty(max(cls.STAGE_BYTES, max((h * w * channels for _, h, w in self.index.values()),
+                                                     default=0)), dtype=torch.uint8, pin_memory=pin)
+        stage_np = stage.numpy()
+        base, fill = 0, 0                                      # device offset of stage[0], bytes staged
+
+        def flush():
+            nonlocal base, fill
+            if fill:
+                self.buf[base:base + fill].copy_(stage[:fill])     # (synchronous: the stage is reused)
+            base, fill = base + fill, 0
+        for key in keys:
+            o, h, w = self.index[key]
+            data = get(key)
             arr = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else \
                 np.ascontiguousarray(data).reshape(-1)
-            if arr.size != h * w * 3:
-                raise ValueError(f'{key}: {arr.size} bytes, expected {h}x{w}x3')
-            self.index[key] = (off, h, w)
-            chunks.append(arr)
-            off += (arr.size + 15) // 16 * 16          # 16-byte aligned frames
-        host = np.zeros(off, dtype=np.uint8)
-        for (key, _), arr in zip(self.index.items(), chunks):
-            o = self.index[key][0]
-            host[o:o + arr.size] = arr
-        self.buf = torch.from_numpy(host).to(self.device)
+            if arr.size != h * w * channels:
+                raise ValueError(f'{key}: {arr.size} bytes, expected {h}x{w}x{channels}')
+            if o - base + arr.size > stage.numel():
+                flush()
+                base = o
+            stage_np[o - base:o - base + arr.size] = arr
+            fill = o - base + (arr.size + 15) // 16 * 16
+            if fill > stage.numel():
+                fill = stage.numel()
+        flush()
         return self
 
     @classmethod
     def from_lmdb(cls, reader, keys, device='cuda'):
-        return cls.from_frames(((k, reader.get(k)) for k in keys), device)
+        return cls.from_frames((list(keys), reader.get), device)
 
     def nbytes(self):
         return 0 if self.buf is None else self.buf.numel()

@@ -14,6 +14,7 @@ can be passed to `train()` / `test()`.
 """
 import argparse
 import os
+import random
 import time
 
 import numpy as np
@@ -35,7 +36,10 @@ def parse_args(argv=None):
     p.add_argument('--lr_size', type=str, default='3x256x256')
     p.add_argument('--test_speed', action='store_true')
     p.add_argument('--local_rank', default=-1, type=int)
-    p.add_argument('--iters', type=int, default=20, help='synthetic train iterations')
+    p.add_argument('--iters', type=int, default=None,
+                   help='train iterations to run.  Default: with an LMDB training set, up to '
+                        'train.total_iter of the yml (the reference\'s loop, main.py:60-66); with the '
+                        'synthetic source 20')
     p.add_argument('--resume', type=int, default=0,
                    help='iteration to resume from: loads {G,D}_iter<k>.pth and state_iter<k>.pth from '
                         'train.ckpt_dir and continues at k + 1 (the reference leaves this as a TODO, '
@@ -81,12 +85,20 @@ def setup(args):
             raise RuntimeError('an MI355X is required: the path has no CPU fallback')
         torch.cuda.set_device(int(args.gpu_ids.split(',')[0]))
         opt.update({'dist': False, 'device': 'cuda', 'rank': 0, 'world_size': 1})
-    seed = opt.get('manual_seed', 2021) + opt['rank']          # base_utils.py:46
-    torch.manual_seed(seed)
-    np.random.seed(seed)
+    seed_everything(opt.get('manual_seed', 2021) + opt['rank'])          # base_utils.py:46
     if opt['is_train']:      # the reference's test.yml files have no `train` section
         opt['train'].setdefault('ckpt_dir', os.path.join(args.exp_dir, 'train', 'ckpt'))
     return opt
+
+
+def seed_everything(seed):
+    """setup_random_seed, base_utils.py:78-83: the LMDB data set draws its crop / flip / rotation /
+    moving-first-frame geometry from Python's `random`, the degradation from numpy / torch."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
 
 
 def synthetic_train_batches(opt, n_iter, seed):
@@ -149,7 +161,8 @@ def test(opt, sequences):
         # sums come from the HIP kernel (metric_calculator.py:228-244 without the host trip)
         hr_seq = model.infer(device_output=True).contiguous()
         gt = data['gt'].to(hr_seq.device).contiguous()
-        vals[idx] = float(np.mean(compute_psnr_device(gt, hr_seq)))
+        vals[idx] = float(np.mean(compute_psnr_device(gt, hr_seq)))      # (synchronises)
+        model.net_G.check_faults()      # fail-safe of chained launches: the clip above is complete
     red = dist_utils.reduce_sum_to_master(vals, device=opt['device'] if opt['dist'] else 'cpu')
     if rank == 0:
         for d, v in zip(sequences, red.tolist()):
@@ -191,18 +204,26 @@ def main(argv=None):
         from .data import TrainSource
         src = TrainSource(opt)
 
+        total = int(opt['train'].get('total_iter', 0))
+        n_iter = args.iters if args.iters is not None else max(0, total - args.resume)
+        per_epoch = max(1, len(src))
+        # a resumed run continues in the epoch (and at the batch) iteration `resume` had reached:
+        # the sampler order of an epoch is a function of (seed, epoch) alone
+        ep0, skip = divmod(args.resume, per_epoch)
+
         def epochs():
-            ep, left = 0, args.iters
+            ep, left, sk = ep0, n_iter, skip
             while left > 0:
-                for b in src.epoch(ep):
+                for i, b in enumerate(src.epoch(ep, first_batch=sk)):
                     if left <= 0:
                         return
                     left -= 1
                     yield b
-                ep += 1
+                ep, sk = ep + 1, 0
         train(opt, epochs(), start_iter=args.resume)
     elif args.mode == 'train':
-        train(opt, synthetic_train_batches(opt, args.iters, 100 + opt['rank'] + 7919 * args.resume),
+        train(opt, synthetic_train_batches(opt, 20 if args.iters is None else args.iters,
+                                           100 + opt['rank'] + 7919 * args.resume),
               start_iter=args.resume)
     elif args.mode == 'test':
         g = torch.Generator().manual_seed(7)

@@ -219,13 +219,9 @@ class BaseModel:
         if bucket is None:
             return
 
-        def scale(dst, src, a):
-            if src is None:                       # in place: dst += (a - 1) * dst
-                ops.axpy_(dst, dst, a - 1.0)
-            else:
-                dst.zero_()
-                ops.axpy_(dst.view(-1), src.contiguous(), a)
-        bucket.finish(scale_fn=scale)
+        def mean(dst, src, world):                # dst = (src or dst) / world, IEEE division as DDP's
+            ops.div_scalar_(dst.view(-1), world, None if src is None else src.contiguous())
+        bucket.finish(scale_fn=mean)
 
     def allreduce_grads(self, net):
         """Blocking form (reference: DDP's backward hook, base_model.py:130-136)."""

@@ -231,14 +231,19 @@ class _StepPlan:
                 'tg_frnet_plan_create')
 
     def check_chain(self):
-        """Raise if a workgroup of the chained SRNet launch ever gave up waiting for a producer tile
-        (tg_conv3x3_wino_chain's poll limit): the frames would then be built on stale data."""
-        idx = L.lib().tg_frnet_plan_chain_error_index(self.handle)
-        if idx >= 0:
-            lost = int(self.workspace[idx:idx + 1].view(torch.int32).item())
-            if lost:
-                raise L.TecoganHipError(f'chained SRNet launch: {lost} workgroups timed out waiting for a '
-                                        f'producer tile; results are invalid (set TG_WINO_CHAIN=0 and report)')
+        """Raise if a workgroup of the chained SRNet launch gave up waiting for a producer tile since
+        the last check (tg_frnet_plan_chain_status; the frames enqueued on this plan since then were
+        built on stale data).  A host read of a pinned counter -- no synchronisation; after a
+        synchronisation it covers everything enqueued so far.  Every tg_frnet_step* call makes the
+        same check on entry, so a fault also surfaces on the NEXT call of any kind on this plan;
+        the plan then runs one launch per layer for the rest of its life."""
+        L.check(L.lib().tg_frnet_plan_chain_status(self.handle, None, None), 'chained SRNet launch')
+
+    def chain_state(self):
+        """(faults reported so far, chained launch still in use)."""
+        f, a = ctypes.c_int(0), ctypes.c_int(0)
+        L.lib().tg_frnet_plan_chain_status(self.handle, ctypes.byref(f), ctypes.byref(a))
+        return f.value, bool(a.value)
 
     def __del__(self):
         try:
@@ -416,6 +421,10 @@ class FRNet(nn.Module):
                 if stream_io:
                     main.wait_stream(copy)
         if return_device_tensor:
+            # nothing is synchronised here: a fault of the chained launch in THIS clip is caught by
+            # the entry check of the next call on the plan, or by check_faults() after the caller's
+            # own synchronisation; faults of earlier clips are caught now
+            self._get_plan(k, h, w, dev).check_chain()
             return u8.permute(1, 0, 2, 3, 4) if multi else u8[:, 0]
         if host_out is not None:
             torch.cuda.current_stream(dev).synchronize()
@@ -424,6 +433,13 @@ class FRNet(nn.Module):
             out = u8.cpu().numpy()
         self._get_plan(k, h, w, dev).check_chain()   # (the clip has been synchronised: a 4-byte read)
         return out.transpose(1, 0, 2, 3, 4) if multi else out[:, 0]
+
+    def check_faults(self):
+        """Call after synchronising: raises TecoganHipError if any cached frame plan recorded a fault
+        of its chained SRNet launch (see _StepPlan.check_chain).  main.test and bench.py call it
+        after every synchronised clip."""
+        for plan in self._plan.values():
+            plan.check_chain()
 
     def _copy_stream(self, dev):
         st = getattr(self, '_copy', None)
@@ -442,22 +458,12 @@ class FRNet(nn.Module):
     def _side_stream(self, dev):
         st = getattr(self, '_side', None)
         if st is None or st.device != dev:
-            # Default priority class.  Whether this stream really runs beside the main one is
-            # decided by the runtime's stream -> hardware-queue mapping; the package enables
-            # dynamic queue assignment for that (see tecogan_pytorch_amd/__init__.py).  A
-            # high-priority side stream (-1) was measured WORSE: FNet then pre-empts the serial
-            # SRNet chain and every 4th clip drops to 450 frames/s.
-            prio = int(os.environ.get('TG_SIDE_STREAM_PRIORITY', '0'))
-            st = self._side = torch.cuda.Stream(device=dev, priority=prio)
-            from ... import dynamic_queues_active
-            if not dynamic_queues_active():
-                import warnings
-                warnings.warn(
-                    'tecogan_pytorch_amd: DEBUG_HIP_DYNAMIC_QUEUES=1 is not in effect (the HIP runtime '
-                    'was initialised before the package was imported, or the variable is set to another '
-                    'value).  The FNet/SRNet two-stream overlap of infer_sequence then shares a hardware '
-                    'queue on some clips and silently loses ~15 % throughput on those; export '
-                    'DEBUG_HIP_DYNAMIC_QUEUES=1 before the first GPU call.', RuntimeWarning, stacklevel=3)
+            # A stream with a hardware queue of its own (tg_stream_create_dedicated): the runtime
+            # pools ordinary streams on 4 hardware queues by static round robin, and whenever this
+            # stream shared the main stream's queue the FNet / SRNet overlap was silently lost for
+            # that clip.  Default priority: a high-priority side stream was
+            # measured WORSE (FNet then pre-empts the serial SRNet chain).
+            st = self._side = ops.dedicated_stream(dev)
         return st
 
     def forward_sequence(self, lr_data):

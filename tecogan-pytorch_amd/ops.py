@@ -14,6 +14,28 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _DedicatedStream(torch.cuda.ExternalStream):
+    """torch view of a tg_stream_create_dedicated stream (destroyed with the object)."""
+
+    def __del__(self):
+        try:
+            L.lib().tg_stream_destroy(self.cuda_stream)
+        except Exception:
+            pass
+
+
+def dedicated_stream(device):
+    """A HIP stream with a hardware queue of its own (include/tecogan_hip.h
+    tg_stream_create_dedicated), as a torch stream object."""
+    import ctypes
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    torch.cuda.init()
+    h = ctypes.c_void_p()
+    L.check(L.lib().tg_stream_create_dedicated(idx, ctypes.byref(h)), 'tg_stream_create_dedicated')
+    return _DedicatedStream(h.value, device=torch.device('cuda', idx))
+
+
 def _chk(t, name, dtype=torch.float32):
     if not (torch.is_tensor(t) and t.is_cuda):
         raise L.TecoganHipError(f'{name}: expected a CUDA/HIP tensor (no CPU path exists)')
@@ -506,6 +528,14 @@ def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step):
 def axpy_(y, x, a=1.0):
     _chk(y, 'y'); _chk(x, 'x')
     L.check(L.lib().tg_axpy(y.data_ptr(), x.data_ptr(), float(a), y.numel(), _stream()), 'tg_axpy')
+    return y
+
+
+def div_scalar_(y, d, x=None):
+    """y = (x or y) / d, elementwise IEEE division."""
+    _chk(y, 'y')
+    src = y if x is None else _chk(x, 'x')
+    L.check(L.lib().tg_div_scalar(y.data_ptr(), src.data_ptr(), float(d), y.numel(), _stream()), 'tg_div_scalar')
     return y
 
 

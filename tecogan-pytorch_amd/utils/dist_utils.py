@@ -221,30 +221,29 @@ class GradBucket:
             return
         self.work.wait()
         rank, world = get_dist_info()
-        inv = 1.0 / world
         if self.flat is not None:
             if world > 1:
                 if scale_fn is not None:
-                    scale_fn(self.flat, None, inv)       # in-place scale of the bucket
+                    scale_fn(self.flat, None, world)     # in-place mean of the bucket
                 else:
-                    self.flat.mul_(inv)
+                    self.flat.div_(world)
         else:
             off = 0
             for g in self.grads:
                 k = g.numel()
                 src = self._owned[off:off + k]
                 if scale_fn is not None:
-                    scale_fn(g, src, inv)
+                    scale_fn(g, src, world)
                 else:
-                    g.copy_(src.view_as(g)).mul_(inv)
+                    g.copy_(src.view_as(g)).div_(world)
                 off += k
         self.work = self._owned = None
 
 
 def allreduce_mean_(grads, scale_fn=None):
     """DDP gradient exchange for one network, blocking form: GradBucket.start + finish.
-    `scale_fn(dst, src_flat_slice, a)` does dst = a * src on the device (HIP axpy); default =
-    torch ops (CPU tensors in the gloo tests)."""
+    `scale_fn(dst, src_flat_slice_or_None, world)` does dst = src / world on the device
+    (tg_div_scalar: the IEEE division DDP performs); default = torch ops (CPU tensors in the gloo tests)."""
     rank, world = get_dist_info()
     if world == 1 or not grads:
         return

@@ -106,3 +106,23 @@ def test_filter_file_and_plan_geometry(tmp_path):
     with pytest.raises(AssertionError):                    # crop larger than the frame
         UnpairedLMDBDataset({'seq_dir': str(tmp_path), 'filter_file': None, 'data_type': 'rgb'},
                             crop_size=64, tempo_extent=F.TEMPO).draw_plan(0)
+
+
+def test_manual_seed_reproduces_augmentation(tmp_path):
+    """main.seed_everything (setup_random_seed, base_utils.py:78-83) seeds Python's `random` too: the
+    crop / flip / rotation geometry of the LMDB data set is drawn from it, so two runs under one
+    manual_seed must draw identical plans (and a different seed different ones)."""
+    from tecogan_pytorch_amd.main import seed_everything
+    frames = F.all_frames()
+    LMDBWriter(str(tmp_path)).write({k: v.tobytes() for k, v in frames.items()})
+    with open(os.path.join(str(tmp_path), 'meta_info.pkl'), 'wb') as f:
+        pickle.dump({'name': 'fixture', 'color': 'RGB', 'keys': list(frames.keys())}, f)
+    ds = UnpairedLMDBDataset({'seq_dir': str(tmp_path), 'filter_file': None, 'data_type': 'rgb'},
+                             crop_size=F.CROP, tempo_extent=F.TEMPO, moving_first_frame=True, moving_factor=0.7)
+
+    def draw(seed):
+        seed_everything(seed)
+        return [(p.keys, p.row0, p.col0, p.flip_axis, p.flip_t, p.rot_k)
+                for p in (ds.draw_plan(i % len(ds)) for i in range(16))]
+    a, b, c = draw(2021), draw(2021), draw(2022)
+    assert a == b and a != c

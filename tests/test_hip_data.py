@@ -43,6 +43,21 @@ def test_device_gather_equals_reference_samples(tmp_path, golden, tag):
         assert np.array_equal(o, host)
 
 
+def test_chunked_upload_equals_frames(tmp_path, monkeypatch):
+    """The store is filled through a pinned staging buffer (no second host copy of the data set):
+    with a buffer just large enough for one frame every flush path runs; the device bytes must equal the frames."""
+    frames = _env(tmp_path)
+    monkeypatch.setattr(DeviceClipStore, 'STAGE_BYTES', 1)      # -> sized to the largest frame
+    small = DeviceClipStore.from_frames(frames.items())
+    monkeypatch.undo()
+    big = DeviceClipStore.from_frames(frames.items())
+    assert small.index == big.index and small.nbytes() == big.nbytes()
+    host = small.buf.cpu().numpy()
+    for k, v in frames.items():
+        o, h, w = small.index[k]
+        assert np.array_equal(host[o:o + h * w * 3], np.ascontiguousarray(v).reshape(-1)), k
+
+
 def test_every_flip_rotation_combination(tmp_path):
     from tecogan_pytorch_amd.data import ClipPlan
     frames = _env(tmp_path)

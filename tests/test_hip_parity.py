@@ -279,6 +279,62 @@ def test_plan_with_chained_srnet_launch(tmp_path):
     assert outs[0].shape == outs[1].shape and torch.equal(outs[0], outs[1])
 
 
+def test_chained_launch_fault_surfaces_on_every_path(tmp_path):
+    """Fail-safe of the chained SRNet launch: with fault injection (negative poll limit: every waiting
+    workgroup gives up at once) the error must surface (a) at infer_sequence's host-output exit,
+    (b) on the call after a `return_device_tensor=True` clip and in check_faults() after the caller's
+    sync, (c) on the step() after a faulted step() -- and after the report the plan must have fallen
+    back to one launch per layer and produce the frames of a never-chained run, bit for bit."""
+    import subprocess
+    import sys
+    script = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from tests.test_hip_parity import make_net, smooth_clip\n"
+        "from tecogan_pytorch_amd import _lib\n"
+        "E = _lib.TecoganHipError\n"
+        "dev = torch.device('cuda')\n"
+        "x = torch.from_numpy(np.stack([smooth_clip(5, 3, 26, 40, seed=5), smooth_clip(5, 3, 26, 40, seed=6)])).cuda()\n"
+        "def fresh(inject):\n"
+        "    net, _ = make_net('BD', 4)\n"
+        "    plan = net._get_plan(2, 26, 40, dev)\n"
+        "    assert plan.chain_state() == (0, True), plan.chain_state()\n"
+        "    if inject: _lib.check(_lib.lib().tg_frnet_plan_set_chain_poll_limit(plan.handle, -1), 'limit')\n"
+        "    return net, plan\n"
+        "def raises(fn):\n"
+        "    try: fn()\n"
+        "    except E as e: return 'timed out' in str(e)\n"
+        "    return False\n"
+        "ref_net, _ = fresh(False)\n"
+        "ref = ref_net.infer_sequence(x, dev)\n"
+        "# (a) host-output exit\n"
+        "net, plan = fresh(True)\n"
+        "assert raises(lambda: net.infer_sequence(x, dev)), 'a: no error at the host-output exit'\n"
+        "f, active = plan.chain_state(); assert f > 0 and not active, (f, active)\n"
+        "assert np.array_equal(net.infer_sequence(x, dev), ref), 'a: fallback differs'\n"
+        "# (b) device-tensor exit: nothing synchronised inside; the caller's check after its sync, and the next call\n"
+        "net, plan = fresh(True)\n"
+        "y = net.infer_sequence(x, dev, return_device_tensor=True); torch.cuda.synchronize()\n"
+        "assert raises(net.check_faults), 'b: check_faults silent'\n"
+        "net, plan = fresh(True)\n"
+        "y = net.infer_sequence(x, dev, return_device_tensor=True); torch.cuda.synchronize()\n"
+        "assert raises(lambda: net.infer_sequence(x, dev, return_device_tensor=True)), 'b: next call silent'\n"
+        "y = net.infer_sequence(x, dev, return_device_tensor=True); torch.cuda.synchronize(); net.check_faults()\n"
+        "assert np.array_equal(y.cpu().numpy(), ref), 'b: fallback differs'\n"
+        "# (c) step() with n = 2\n"
+        "net, plan = fresh(True)\n"
+        "z = torch.zeros(2, 3, 104, 160, device='cuda')\n"
+        "o = net.step(x[:, 1], x[:, 0], z); torch.cuda.synchronize()\n"
+        "assert raises(lambda: net.step(x[:, 1], x[:, 0], z)), 'c: next step silent'\n"
+        "o2 = net.step(x[:, 1], x[:, 0], z); torch.cuda.synchronize(); net.check_faults()\n"
+        "o3 = ref_net.step(x[:, 1], x[:, 0], z); torch.cuda.synchronize(); ref_net.check_faults()\n"
+        "assert torch.equal(o2, o3), 'c: fallback differs'\n"
+        "print('FAILSAFE-OK')\n" % (ROOT_DIR, GOLDEN_DIR))
+    env = dict(os.environ, TG_CONV_WINO='1', TG_WINO_CHAIN='1')
+    r = subprocess.run([sys.executable, '-c', script], env=env, timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0 and 'FAILSAFE-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_winograd_rule_and_plan_use(ops):
     """The frame plan runs SRNet's full-resolution layers in the Winograd form (and says so in its
     per-class statistics); tiny frames stay on the direct kernels."""
