@@ -600,18 +600,6 @@ int tg_frnet_step_masked(tg_frnet_plan* plan, const float* lr_curr, const float*
                          const float* hr_prev, float* hr_out, uint8_t* u8_out,
                          unsigned kind_mask, tg_stream_t stream);
 
-/* ------------------------------------------------------------------------
- * A stream with a hardware queue of its own.  The HIP runtime multiplexes ordinary streams onto a
- * small pool of hardware queues (GPU_MAX_HW_QUEUES = 4, static round robin): two streams that land on
- * the same queue serialise silently, which is what the FNet / SRNet overlap of infer_sequence
- * (tecogan_nets.py:254-281) and the training step's side stream must not do.  A stream created
- * with an explicit compute-unit mask is never pooled -- it gets a queue of its own -- so this
- * entry creates one whose mask names EVERY compute unit of the device (no CU is reserved).
- * The handle is a hipStream_t: pass it as `stream` to any entry here, wrap it with
- * torch.cuda.ExternalStream, destroy it with tg_stream_destroy (after synchronising it). */
-int tg_stream_create_dedicated(int device, tg_stream_t* out);
-int tg_stream_destroy(tg_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ ATen fallback: every op raises if the HIP library is missing.
 """
 __version__ = '0.1.0'
 
-# (Rounds 1-2 set DEBUG_HIP_DYNAMIC_QUEUES=1 here so that the side stream of the pipelined clip
-# inference would not share a hardware queue with the main stream.  Since round 3 the side
-# streams are created with a queue of their own (tg_stream_create_dedicated)
-# and importing this package no longer touches the environment.)
+# (Rounds 1-2 set DEBUG_HIP_DYNAMIC_QUEUES=1 here.  The problem it papered over was a side stream
+# re-created on every clip; since round 3 there is ONE long-lived side stream per device
+# (models/networks/tecogan_nets.py side_stream) and importing this package
+# no longer touches the environment.)

@@ -119,8 +119,6 @@ SIGNATURES = {
     'tg_frnet_plan_destroy': (None, [P]),
     'tg_frnet_plan_chain_status': (I, [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'tg_frnet_plan_set_chain_poll_limit': (I, [P, I]),
-    'tg_stream_create_dedicated': (I, [I, C.POINTER(C.c_void_p)]),
-    'tg_stream_destroy': (I, [P]),
     'tg_frnet_step': (I, [P, P, P, P, P, P, P]),
     'tg_frnet_step_phase': (I, [P, I, I, P, P, P, P, P, P]),
     'tg_frnet_plan_launches': (I, [P]),

@@ -58,6 +58,10 @@ static int chain_poll(tg_frnet_plan* p) {
   if (pending == 0) return TG_OK;
   __atomic_fetch_sub(p->chain_err, pending, __ATOMIC_RELAXED);
   p->chain_faults += pending;
+  // Faults that arrive after the report come from chained launches that were already enqueued when
+  // the host noticed the first one (the frames of that period were declared invalid then): counted,
+  // not reported again -- everything enqueued since the report uses one launch per layer.
+  if (p->chain_disabled) return TG_OK;
   p->chain_disabled = true;
   tg::set_error("chained SRNet launch: %d workgroup(s) timed out waiting for a producer tile; the frames "
                 "enqueued on this plan since the previous successful check are INVALID.  The plan now runs "
@@ -142,6 +146,7 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   p->WZ = workspace + off[11]; p->wz_ready = false;
   p->CHAINF = reinterpret_cast<int32_t*>(workspace + off[12]); p->chain_ready = false; p->epoch = 0; p->chain_layers = 0;
   p->chain_err = nullptr; p->chain_disabled = false; p->chain_faults = 0; p->chain_poll_limit = tg::TG_CHAIN_POLL_LIMIT_DEFAULT;
+#ifndef TG_EXP_NO_HOSTALLOC
   if (!cfg->fnet_only) {
     void* hp = nullptr;
     if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hp) {
@@ -151,6 +156,7 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
       (void)hipGetLastError();      // no fault channel -> no chained launch (per-layer launches are always safe)
     }
   }
+#endif
   p->FA = workspace + off[7]; p->FB = workspace + off[8]; p->FPART = workspace + off[9];
   p->FLOW2 = workspace + off[10];
   p->PART = workspace + off[6];
@@ -545,35 +551,6 @@ extern "C" int tg_frnet_plan_chain_status(tg_frnet_plan* p, int* faults_total, i
 extern "C" int tg_frnet_plan_set_chain_poll_limit(tg_frnet_plan* p, int poll_limit) {
   TG_REQUIRE(p, TG_E_ARG, "frnet_plan_set_chain_poll_limit: null plan");
   p->chain_poll_limit = poll_limit;
-  return TG_OK;
-}
-
-extern "C" int tg_stream_create_dedicated(int device, tg_stream_t* out) {
-  TG_REQUIRE(out, TG_E_ARG, "stream_create_dedicated: null pointer");
-  int cur = 0;
-  if (hipGetDevice(&cur) != hipSuccess) return tg::check_launch("stream_create_dedicated: hipGetDevice");
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return tg::check_launch("stream_create_dedicated: properties");
-  const int ncu = prop.multiProcessorCount;
-  TG_REQUIRE(ncu > 0, TG_E_HIP, "stream_create_dedicated: device %d reports %d compute units", device, ncu);
-  std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-  for (int i = 0; i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-  hipStream_t st = nullptr;
-  if (cur != device && hipSetDevice(device) != hipSuccess) return tg::check_launch("stream_create_dedicated: hipSetDevice");
-  const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data());
-  if (cur != device) (void)hipSetDevice(cur);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    tg::set_error("stream_create_dedicated: hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
-    return TG_E_HIP;
-  }
-  *out = (tg_stream_t)st;
-  return TG_OK;
-}
-
-extern "C" int tg_stream_destroy(tg_stream_t stream) {
-  TG_REQUIRE(stream, TG_E_ARG, "stream_destroy: null stream");
-  if (hipStreamDestroy((hipStream_t)stream) != hipSuccess) return tg::check_launch("stream_destroy");
   return TG_OK;
 }
 

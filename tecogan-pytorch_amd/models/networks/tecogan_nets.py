@@ -198,6 +198,33 @@ class SRNet(nn.Module):
                                  up_mode=self.up_mode(), up_scale=self.scale)
 
 
+def _norm_device(device):
+    """'cuda' -> cuda:<current>: plans and side streams are cached per device, and torch.device('cuda')
+    != torch.device('cuda', 0) -- rounds 1-2 re-created the side stream on every clip because of it."""
+    dev = torch.device(device)
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    return dev
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(dev, kind='side'):
+    """ONE long-lived side stream per (device, kind) for the whole process.  Handing out a new pool
+    stream per clip (what rounds 1-2 did by accident) walks torch's stream pool across the runtime's
+    four hardware queues, so every few clips the side stream shares the main stream's queue and the
+    overlap is silently lost; a stable stream was measured at the full two-stream rate with and
+    without DEBUG_HIP_DYNAMIC_QUEUES, with HIP initialised before or after the import, and next
+    to an RCCL process group (tools/stream_probe.py).  A stream created with a
+    CU mask (a hardware queue of its own) and a high-priority stream were measured WORSE."""
+    key = (str(_norm_device(dev)), kind)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=_norm_device(dev))
+    return st
+
+
 class _StepPlan:
     """Caller-owned device state behind one tg_frnet_plan: packed weights,
     workspace, and the opaque plan handle."""
@@ -273,6 +300,7 @@ class FRNet(nn.Module):
 
     def _get_plan(self, n, h, w, device, fnet_only=False):
         """Plans are cached per (batch, size, device, kind); a weight update drops them all."""
+        device = _norm_device(device)
         wk = self._weights_key()
         if self._plan_key != wk:
             self._plan, self._plan_key = {}, wk
@@ -345,7 +373,7 @@ class FRNet(nn.Module):
             lr_data = lr_data.unsqueeze(1)
         tot_frm, k, c, h, w = lr_data.size()
         s = self.scale
-        dev = torch.device(device) if device is not None else lr_data.device
+        dev = _norm_device(device if device is not None else lr_data.device)
         host_in = not lr_data.is_cuda
         stream_io = pipeline and tot_frm >= 2 and not return_device_tensor
         if host_in and stream_io:
@@ -442,10 +470,7 @@ class FRNet(nn.Module):
             plan.check_chain()
 
     def _copy_stream(self, dev):
-        st = getattr(self, '_copy', None)
-        if st is None or st.device != dev:
-            st = self._copy = torch.cuda.Stream(device=dev)
-        return st
+        return side_stream(dev, 'copy')
 
     def _events(self, n):
         """Two event rings, created once and re-recorded by every clip."""
@@ -456,14 +481,9 @@ class FRNet(nn.Module):
         return ev
 
     def _side_stream(self, dev):
-        st = getattr(self, '_side', None)
-        if st is None or st.device != dev:
-            # A stream with a hardware queue of its own (tg_stream_create_dedicated): the runtime
-            # pools ordinary streams on 4 hardware queues by static round robin, and whenever this
-            # stream shared the main stream's queue the FNet / SRNet overlap was silently lost for
-            # that clip.  Default priority: a high-priority side stream was
-            # measured WORSE (FNet then pre-empts the serial SRNet chain).
-            st = self._side = ops.dedicated_stream(dev)
+        st = getattr(self, '_side', None)        # (tools/stream_probe.py plants other kinds of stream here)
+        if st is None or st.device != _norm_device(dev):
+            st = self._side = side_stream(dev)
         return st
 
     def forward_sequence(self, lr_data):

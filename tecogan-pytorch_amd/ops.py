@@ -14,28 +14,6 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-class _DedicatedStream(torch.cuda.ExternalStream):
-    """torch view of a tg_stream_create_dedicated stream (destroyed with the object)."""
-
-    def __del__(self):
-        try:
-            L.lib().tg_stream_destroy(self.cuda_stream)
-        except Exception:
-            pass
-
-
-def dedicated_stream(device):
-    """A HIP stream with a hardware queue of its own (include/tecogan_hip.h
-    tg_stream_create_dedicated), as a torch stream object."""
-    import ctypes
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    torch.cuda.init()
-    h = ctypes.c_void_p()
-    L.check(L.lib().tg_stream_create_dedicated(idx, ctypes.byref(h)), 'tg_stream_create_dedicated')
-    return _DedicatedStream(h.value, device=torch.device('cuda', idx))
-
-
 def _chk(t, name, dtype=torch.float32):
     if not (torch.is_tensor(t) and t.is_cuda):
         raise L.TecoganHipError(f'{name}: expected a CUDA/HIP tensor (no CPU path exists)')

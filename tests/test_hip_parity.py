@@ -293,7 +293,7 @@ def test_chained_launch_fault_surfaces_on_every_path(tmp_path):
         "from tests.test_hip_parity import make_net, smooth_clip\n"
         "from tecogan_pytorch_amd import _lib\n"
         "E = _lib.TecoganHipError\n"
-        "dev = torch.device('cuda')\n"
+        "dev = torch.device('cuda', 0)\n"
         "x = torch.from_numpy(np.stack([smooth_clip(5, 3, 26, 40, seed=5), smooth_clip(5, 3, 26, 40, seed=6)])).cuda()\n"
         "def fresh(inject):\n"
         "    net, _ = make_net('BD', 4)\n"
@@ -307,26 +307,32 @@ def test_chained_launch_fault_surfaces_on_every_path(tmp_path):
         "    return False\n"
         "ref_net, _ = fresh(False)\n"
         "ref = ref_net.infer_sequence(x, dev)\n"
-        "# (a) host-output exit\n"
+        "def synced(fn):\n"
+        "    def go():\n"
+        "        r = fn(); torch.cuda.synchronize(); net.check_faults(); return r\n"
+        "    return go\n"
+        "# (a) host-output exit (the entry check of a later frame's call may fire first: same error)\n"
         "net, plan = fresh(True)\n"
-        "assert raises(lambda: net.infer_sequence(x, dev)), 'a: no error at the host-output exit'\n"
+        "assert raises(lambda: net.infer_sequence(x, dev)), 'a: no error on the host-output path'\n"
+        "torch.cuda.synchronize()\n"
         "f, active = plan.chain_state(); assert f > 0 and not active, (f, active)\n"
         "assert np.array_equal(net.infer_sequence(x, dev), ref), 'a: fallback differs'\n"
-        "# (b) device-tensor exit: nothing synchronised inside; the caller's check after its sync, and the next call\n"
+        "# (b) device-tensor exit: nothing is synchronised inside -> the caller's check after its own sync\n"
         "net, plan = fresh(True)\n"
-        "y = net.infer_sequence(x, dev, return_device_tensor=True); torch.cuda.synchronize()\n"
-        "assert raises(net.check_faults), 'b: check_faults silent'\n"
-        "net, plan = fresh(True)\n"
-        "y = net.infer_sequence(x, dev, return_device_tensor=True); torch.cuda.synchronize()\n"
-        "assert raises(lambda: net.infer_sequence(x, dev, return_device_tensor=True)), 'b: next call silent'\n"
-        "y = net.infer_sequence(x, dev, return_device_tensor=True); torch.cuda.synchronize(); net.check_faults()\n"
+        "assert raises(synced(lambda: net.infer_sequence(x, dev, return_device_tensor=True))), 'b: check_faults silent'\n"
+        "torch.cuda.synchronize()\n"
+        "y = synced(lambda: net.infer_sequence(x, dev, return_device_tensor=True))()\n"
         "assert np.array_equal(y.cpu().numpy(), ref), 'b: fallback differs'\n"
-        "# (c) step() with n = 2\n"
+        "# (b') ONE chained launch (a 1-frame clip), then a sync: the NEXT call must refuse at its entry\n"
+        "net, plan = fresh(True)\n"
+        "y = net.infer_sequence(x[:, :1], dev, return_device_tensor=True); torch.cuda.synchronize()\n"
+        "assert raises(lambda: net.infer_sequence(x[:, :1], dev, return_device_tensor=True)), 'b2: next call silent'\n"
+        "# (c) step() with n = 2: same, through FRNet.step\n"
         "net, plan = fresh(True)\n"
         "z = torch.zeros(2, 3, 104, 160, device='cuda')\n"
         "o = net.step(x[:, 1], x[:, 0], z); torch.cuda.synchronize()\n"
         "assert raises(lambda: net.step(x[:, 1], x[:, 0], z)), 'c: next step silent'\n"
-        "o2 = net.step(x[:, 1], x[:, 0], z); torch.cuda.synchronize(); net.check_faults()\n"
+        "o2 = synced(lambda: net.step(x[:, 1], x[:, 0], z))()\n"
         "o3 = ref_net.step(x[:, 1], x[:, 0], z); torch.cuda.synchronize(); ref_net.check_faults()\n"
         "assert torch.equal(o2, o3), 'c: fallback differs'\n"
         "print('FAILSAFE-OK')\n" % (ROOT_DIR, GOLDEN_DIR))
