@@ -168,6 +168,50 @@ int64_t tg_conv3x3_wino_chain_flag_ints(int n_layers, int n, int h, int w);
 int tg_conv3x3_wino_chain(const tg_wino_layer* layers, int n_layers, int n, int cout, int h, int w,
                           int32_t* flags, int epoch, tg_stream_t stream);
 
+/* Dependent 3x3 layers of SMALL frames (the training unroll: 2 x 32 x 32 / 2 x 64 x 64 LR pixels per
+ * frame, tecogan_nets.py:174-225) in ONE launch: one persistent workgroup per (image row, 32-pixel
+ * segment[, 32-channel half]) walks all the layers and exchanges halo rows with its neighbours
+ * through agent-scope memory + per-tile flags (tg_conv3x3_chain.hip).  Direct fp32-MFMA form, weights
+ * packed by tg_conv3x3_pack with ocb = 64 (forward) or transposed = 2 (data gradient).
+ *   layers[i]: x (+ x2: channels [c1, cin)) -> y = relu_mask > 0 ? act(conv + bias) + res : 0;
+ *              cin, cout <= 64; bias / res / relu_mask / x2 may be NULL; buffers may be reused along the
+ *              chain in SRNet's patterns only (ping-pong, in-place residual sum).
+ *   flags:     tg_conv3x3_chain_flag_ints(n_layers, n, h, w) int32, caller owned, zeroed ONCE.
+ *   err:       int32 fault counter, device OR pinned host memory (the kernel adds with system scope):
+ *              a workgroup that exhausts poll_limit polls (~32 cycles each; < 0: at once = fault
+ *              injection) counts a fault and carries on -- the launch always ends; a non-zero count
+ *              after synchronisation means the output is undefined and the caller must fall back to
+ *              one launch per layer.
+ *   epoch:     non-zero, different from the previous call on these flags.
+ * Every workgroup must be resident at once: tg_conv3x3_chain_supported returns 0 when the grid would
+ * exceed half of what the device holds (the call then fails with TG_E_SHAPE), else the number of
+ * workgroups per tile it will use (1 or 2). */
+typedef struct {
+  const float* x; const float* x2; const float* w_packed; const float* bias; const float* res;
+  const float* relu_mask;
+  float* y;
+  int64_t x_nstride, x2_nstride, res_nstride, mask_nstride, y_nstride;
+  int c1, cin, cout, act;
+} tg_chain_layer;
+int64_t tg_conv3x3_chain_flag_ints(int n_layers, int n, int h, int w);
+int tg_conv3x3_chain_supported(int n, int h, int w, int cmax);
+int tg_conv3x3_chain(const tg_chain_layer* layers, int n_layers, int n, int h, int w, int32_t* flags,
+                     int32_t* err, uint32_t epoch, int poll_limit, tg_stream_t stream);
+/* SRNet's conv_in + nb residual blocks on one training frame (tecogan_nets.py:108-116, :141-143) and
+ * the matching reverse sweep, each as one tg_conv3x3_chain launch.  acts / dz: 1 + 2*nb tensors
+ * (n, nf, h, w) back to back, acts[0] = conv_in's output, acts[1+2b] / acts[2+2b] = block b's inner
+ * activation / output; dz[i] = gradient w.r.t. the pre-activation of layer i (dz[2nb] is not written:
+ * it is g_out), d_tran = gradient w.r.t. the warped-frame input channels (n, c_tran, h, w).
+ * layers[i] / dgrad[i]: forward / data-gradient packs of layer i (dgrad[0]: conv_in restricted to
+ * input channels [c_lr, c_lr + c_tran), bias unused). */
+typedef struct { const float* w; const float* b; } tg_packed_layer;
+int tg_srnet_body_fwd(const tg_packed_layer* layers, int nb, const float* lr, int c_lr, const float* tran,
+                      int c_tran, float* acts, int n, int nf, int h, int w, int32_t* flags, int32_t* err,
+                      uint32_t epoch, int poll_limit, tg_stream_t stream);
+int tg_srnet_body_bwd(const tg_packed_layer* dgrad, int nb, const float* g_out, const float* acts, float* dz,
+                      float* d_tran, int c_tran, int n, int nf, int h, int w, int32_t* flags, int32_t* err,
+                      uint32_t epoch, int poll_limit, tg_stream_t stream);
+
 /* Split-K variant for layers whose output tile count cannot fill the GPU (FNet's
  * low-resolution many-channel middle, tecogan_nets.py:37-60): `ksplit` groups of
  * input channels are reduced by different workgroups into `partials`

@@ -30,6 +30,18 @@ class WinoLayer(C.Structure):
                 ('act', C.c_int)]
 
 
+class ChainLayer(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('x2', C.c_void_p), ('w_packed', C.c_void_p), ('bias', C.c_void_p),
+                ('res', C.c_void_p), ('relu_mask', C.c_void_p), ('y', C.c_void_p),
+                ('x_nstride', C.c_int64), ('x2_nstride', C.c_int64), ('res_nstride', C.c_int64),
+                ('mask_nstride', C.c_int64), ('y_nstride', C.c_int64),
+                ('c1', C.c_int), ('cin', C.c_int), ('cout', C.c_int), ('act', C.c_int)]
+
+
+class PackedLayer(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('b', C.c_void_p)]
+
+
 class LayerWeights(C.Structure):
     _fields_ = [('w', C.c_void_p), ('b', C.c_void_p), ('u', C.c_void_p)]
 
@@ -94,6 +106,11 @@ SIGNATURES = {
     'tg_conv3x3_wino_packed_floats': (I64, [I, I]),
     'tg_conv3x3_wino_chain_flag_ints': (I64, [I, I, I, I]),
     'tg_conv3x3_wino_chain': (I, [C.POINTER(WinoLayer), I, I, I, I, I, P, I, P]),
+    'tg_conv3x3_chain_flag_ints': (I64, [I, I, I, I]),
+    'tg_conv3x3_chain_supported': (I, [I, I, I, I]),
+    'tg_conv3x3_chain': (I, [C.POINTER(ChainLayer), I, I, I, I, P, P, C.c_uint32, I, P]),
+    'tg_srnet_body_fwd': (I, [C.POINTER(PackedLayer), I, P, I, P, I, P, I, I, I, I, P, P, C.c_uint32, I, P]),
+    'tg_srnet_body_bwd': (I, [C.POINTER(PackedLayer), I, P, P, P, P, I, I, I, I, I, P, P, C.c_uint32, I, P]),
     'tg_conv3x3_prefers_wino': (I, [I, I, I, I, I]),
     'tg_pack_conv3x3_wino': (I, [P, P, I, I, I, P]),
     'tg_conv3x3_wino_fwd': (I, [P, I64, I, P, I64, P, P, P, I64, P, I64, P, I64, I, I, I, I, I, I, P]),

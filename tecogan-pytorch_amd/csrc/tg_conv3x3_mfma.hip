@@ -761,6 +761,9 @@ extern "C" int tg_conv3x3_pick_ksplit(int n, int cin, int cout, int h, int w) {
   int rows = conv3x3_rows_per_wg(ocb, (long long)n * h * w);
   const double wgs = (double)cdiv(w, TW) * cdiv(h, rows) * cdiv(cout, ocb) * n;
   const int nchunk = cdiv(cin, CK);
+  // the one-shot kernel already has the whole K range in flight inside ONE launch: 10.8 us against
+  // 9.0 + 4.2 us for a 4-way split + finalize on the 2 x 32 x 32 training frames (rocprofv3, round 3)
+  if (conv3x3_uses_oneshot(n, cin, cout, h, w)) return 1;
   static const int legacy = TG_LAB_ENV("TG_KSPLIT_LEGACY", 0);
   if (legacy) {   // lab: the round-1 rule (fill ~640 workgroup slots)
     if (wgs >= 400 || nchunk < 4) return 1;

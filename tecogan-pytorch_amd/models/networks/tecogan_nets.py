@@ -159,6 +159,7 @@ class SRNet(nn.Module):
         self.conv_up = _block(ups)
         self.conv_out = _Conv(nf, out_nc)
         self.upsample_func = upsample_func
+        self.chain_body = True     # training: conv_in + residual blocks of a frame as one chained launch when the shape allows
 
     def layers(self):
         out = [self.conv_in['0']]
@@ -174,15 +175,16 @@ class SRNet(nn.Module):
     def forward(self, lr_curr, hr_prev_tran, tape=None):
         lr_curr, hr_prev_tran = lr_curr.contiguous(), hr_prev_tran.contiguous()
         if tape is not None:
-            out = TG.conv3x3(tape, self.conv_in['0'], lr_curr, TG.RELU, x2=hr_prev_tran,
-                             need_dx=False, need_dx2=True)
-            fused = os.environ.get('TG_FUSED_RESBLOCK', '1') != '0'       # lab switch
-            for rb in self.resblocks:
-                if fused:
+            n_, _, h_, w_ = lr_curr.shape
+            if self.chain_body and len(self.resblocks) >= 1 and TG._ChainState.usable(
+                    n_, self.conv_in['0'].cout, self.conv_in['0'].cin, h_, w_):
+                # conv_in + the residual blocks as ONE launch (and one for their reverse sweep)
+                out = TG.srnet_body(tape, self, lr_curr, hr_prev_tran)
+            else:
+                out = TG.conv3x3(tape, self.conv_in['0'], lr_curr, TG.RELU, x2=hr_prev_tran,
+                                 need_dx=False, need_dx2=True)
+                for rb in self.resblocks:
                     out = TG.resblock(tape, rb.conv['0'], rb.conv['2'], out)
-                else:
-                    t = TG.conv3x3(tape, rb.conv['0'], out, TG.RELU)
-                    out = TG.conv3x3(tape, rb.conv['2'], t, TG.NONE, res=out)
             for k in self.conv_up:
                 out = TG.convt3x3s2(tape, self.conv_up[k], out, TG.RELU)
             return TG.conv3x3_small(tape, self.conv_out, out, TG.NONE, up_src=lr_curr,
@@ -293,6 +295,9 @@ class FRNet(nn.Module):
         self.srnet = SRNet(in_nc, out_nc, nf, nb, self.upsample_func, self.scale)
         self._plan = {}
         self._plan_key = None
+        # training: weight gradients of the swept half of the unroll run on a side stream under the
+        # rest of the sweep (train_graph.Tape.flush_deferred_async); False = everything on one stream
+        self.wgrad_side_stream = True
 
     # -- plan cache ---------------------------------------------------------
     def _weights_key(self):
@@ -495,6 +500,7 @@ class FRNet(nn.Module):
         n, t, c, h, w = lr_data.shape
         s = self.scale
         tape = TG.Tape()
+        tape.side = side_stream(lr_data.device, 'wgrad') if self.wgrad_side_stream else None
         lr_prev = ops.time_gather(lr_data, list(range(t - 1))).view(n * (t - 1), c, h, w)
         lr_curr = ops.time_gather(lr_data, list(range(1, t))).view(n * (t - 1), c, h, w)
         lr_flow = self.fnet(lr_curr, lr_prev, tape=tape)
@@ -523,6 +529,10 @@ class FRNet(nn.Module):
         hr_prev = self.srnet(lr_fm[0], zeros, tape=tape)
         frames.append(hr_prev)
         for i in range(1, t):
+            if tape.side is not None and i == (t + 1) // 2:
+                # recorded BEFORE frame i's nodes => runs right after frames t-1 .. i have been swept:
+                # their weight gradients start on the side stream under the sweep of frames i-1 .. 0
+                tape.record(tape.flush_deferred_async)
             warped = TG.backward_warp(tape, hr_prev, flow_fm[i - 1],
                                       dflow_out=functools.partial(flow_grad_slice, i - 1))
             tran = TG.space_to_depth(tape, warped, s)

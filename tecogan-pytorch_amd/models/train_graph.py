@@ -25,6 +25,8 @@ class Tape:
         self.keep = []          # tensors that must outlive backward (id() stability)
         self.deferred = {}
         self.deferred_bias = {}
+        self.side = None        # side stream of the asynchronous weight-gradient flushes
+        self._inflight = []     # tensors the side stream still reads (kept alive until the join)
 
     # -- gradient bookkeeping -------------------------------------------------
     def add_grad(self, t, g):
@@ -50,7 +52,37 @@ class Tape:
         for fn in reversed(self.nodes):
             fn()
         self.nodes = []
-        self.flush_deferred()
+        if self.side is not None and (self.deferred or self.deferred_bias):
+            self.flush_deferred_async()      # the tail goes behind the earlier chunks on the side stream
+        else:
+            self.flush_deferred()
+        self.join()
+
+    # -- weight gradients beside the reverse sweep ------------------------------------------------
+    # The reverse sweep over the unrolled frames is a serial chain of small, latency-bound launches
+    # (one 64-channel layer of a 2 x 64 x 64 frame = 256 workgroups for ~11 us); the weight gradients
+    # are large, MFMA-bound launches that depend only on tensors the sweep has already produced.
+    # A checkpoint node (FRNet.forward_sequence places one in the middle of the unroll) hands the
+    # (dZ, X) pairs collected so far to ONE long-lived side stream; the rest follows at the end of
+    # backward(), behind the first chunk (both accumulate into the same gradient buffers: stream
+    # order makes that a fixed summation order, run to run).  join() orders the main stream after
+    # the side stream before anything reads the gradients.
+    def flush_deferred_async(self):
+        if self.side is None:
+            return self.flush_deferred()
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)                      # everything deferred so far has been enqueued
+        for ent in self.deferred.values():
+            self._inflight += ent['p'] + ent['q']
+        for _, dzs in self.deferred_bias.values():
+            self._inflight += dzs
+        with torch.cuda.stream(self.side):
+            self.flush_deferred()
+
+    def join(self):
+        if self.side is not None and self._inflight:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self._inflight = []
 
     # -- deferred parameter gradients -------------------------------------------
     # A layer is applied once per unrolled frame (19x for SRNet), each time on a small
@@ -229,6 +261,133 @@ def resblock(tape, conv1, conv2, x):
         pk1 = _CACHE.get(conv1, ('dg', 0), _ver(w1), lambda: ops.pack_conv3x3_dgrad(w1.detach().contiguous()))
         tape.add_grad(x, ops.conv3x3(dz1, pk1[0], None, c, w1.shape[1], pk1[3], res=g))
     tape.record(bwd)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# SRNet's conv_in + residual blocks of one unrolled frame as ONE chained launch
+# (tg_srnet_body_fwd / _bwd, csrc/tg_conv3x3_chain.hip), forward and reverse sweep.
+# ---------------------------------------------------------------------------
+class _ChainState:
+    """Process-wide state of the chained launches: flag buffers per shape, the epoch counter, the
+    pinned-host fault counter (the kernel adds to it with system scope when a workgroup gives up
+    waiting for a neighbour) and the permanent fallback switch."""
+    disabled = False
+    poll_limit = 1 << 21
+    epoch = 0
+    flags = {}
+    err = None
+    supported = {}
+
+    @classmethod
+    def buffers(cls, nlayer, n, h, w, device):
+        from .. import _lib as L
+        key = (n, h, w, str(device))
+        fl = cls.flags.get(key)
+        need = L.lib().tg_conv3x3_chain_flag_ints(24, n, h, w)
+        if fl is None or fl.numel() < need:
+            fl = cls.flags[key] = torch.zeros(need, dtype=torch.int32, device=device)
+        if cls.err is None:
+            cls.err = torch.zeros(16, dtype=torch.int32).pin_memory()
+        cls.epoch = cls.epoch + 1 if cls.epoch < 0x7fffffff else 1
+        return fl, cls.err, cls.epoch
+
+    @classmethod
+    def usable(cls, n, nf, cin0, h, w):
+        if cls.disabled or nf > 64 or cin0 > 64:
+            return False
+        key = (n, h, w)
+        r = cls.supported.get(key)
+        if r is None:
+            from .. import _lib as L
+            r = cls.supported[key] = L.lib().tg_conv3x3_chain_supported(n, h, w, 64) > 0
+        return r
+
+
+def chain_check():
+    """Call after a host synchronisation (the training step's scalar read): raises if a chained
+    launch recorded a fault since the last check -- the step's results are then invalid -- and
+    switches every later step to one launch per layer."""
+    err = _ChainState.err
+    if err is not None and int(err[0]) != 0:
+        from .. import _lib as L
+        lost = int(err[0])
+        err.zero_()
+        _ChainState.disabled = True
+        raise L.TecoganHipError(f'chained SRNet launch (training): {lost} workgroup(s) timed out waiting for a '
+                                'neighbour tile; the results of this step are INVALID.  Later steps run one '
+                                'launch per layer.')
+
+
+def srnet_body(tape, srnet, lr, tran):
+    """conv_in + nb residual blocks (tecogan_nets.py:108-116, :141-143) of one frame: one launch
+    forward, one launch for the whole reverse sweep of these 1 + 2*nb layers; the (dZ, X) pairs of
+    the weight gradients are deferred exactly as the per-layer nodes defer them."""
+    import ctypes
+    from .. import _lib as L
+    conv_in = srnet.conv_in['0']
+    blocks = [(rb.conv['0'], rb.conv['2']) for rb in srnet.resblocks]
+    layers = [conv_in] + [c for pair in blocks for c in pair]
+    nb, nl = len(blocks), 1 + 2 * len(blocks)
+    n, c_lr, h, w = lr.shape
+    c_tran, nf = tran.shape[1], conv_in.cout
+    fw = (L.PackedLayer * nl)()
+    keep = []
+    for i, m in enumerate(layers):
+        pk, _ = m.packed()
+        keep.append(pk)
+        fw[i].w, fw[i].b = pk.data_ptr(), m.bias.data_ptr()
+    acts = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=lr.device)
+    flags, err, epoch = _ChainState.buffers(nl + 1, n, h, w, lr.device)
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(L.lib().tg_srnet_body_fwd(fw, nb, lr.data_ptr(), c_lr, tran.data_ptr(), c_tran, acts.data_ptr(),
+                                      n, nf, h, w, flags.data_ptr(), err.data_ptr(), epoch,
+                                      _ChainState.poll_limit, st), 'tg_srnet_body_fwd')
+    out = acts[nl - 1]
+    if tape is None:
+        return out
+
+    def bwd():
+        g = tape.pop_grad(out)
+        if g is None:
+            return
+        g = g.contiguous()
+        dg = (L.PackedLayer * nl)()
+        hold = []
+        w_in = conv_in.weight
+        pk0 = _CACHE.get(conv_in, ('dg', 1), _ver(w_in), lambda: ops.pack_conv3x3_dgrad(
+            w_in.detach()[:, c_lr:].contiguous()))
+        hold.append(pk0)
+        dg[0].w = pk0[0].data_ptr()
+        for i, m in enumerate(layers[1:], 1):
+            wm = m.weight
+            pk = _CACHE.get(m, ('dg', 0), _ver(wm), lambda wm=wm: ops.pack_conv3x3_dgrad(wm.detach().contiguous()))
+            hold.append(pk)
+            dg[i].w = pk[0].data_ptr()
+        dz = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=g.device)
+        d_tran = torch.empty(n, c_tran, h, w, dtype=torch.float32, device=g.device)
+        fl, er, ep = _ChainState.buffers(nl + 1, n, h, w, g.device)
+        L.check(L.lib().tg_srnet_body_bwd(dg, nb, g.data_ptr(), acts.data_ptr(), dz.data_ptr(), d_tran.data_ptr(),
+                                          c_tran, n, nf, h, w, fl.data_ptr(), er.data_ptr(), ep,
+                                          _ChainState.poll_limit, torch.cuda.current_stream().cuda_stream),
+                'tg_srnet_body_bwd')
+        tape.keep.append(hold)
+        if conv_in.weight.requires_grad:
+            gw = _grad_buf(conv_in.weight)
+            tape.defer_wgrad(('w', id(conv_in), 0), dz[0], lr, gw, 0)
+            tape.defer_wgrad(('w', id(conv_in), 1), dz[0], tran, gw, c_lr)
+            tape.defer_bias(_grad_buf(conv_in.bias), dz[0])
+        for b, (c1, c2) in enumerate(blocks):
+            if c2.weight.requires_grad:
+                gb = g if b == nb - 1 else dz[2 + 2 * b]
+                tape.defer_wgrad(('w', id(c2), 0), gb, acts[1 + 2 * b], _grad_buf(c2.weight), 0)
+                tape.defer_bias(_grad_buf(c2.bias), gb)
+            if c1.weight.requires_grad:
+                tape.defer_wgrad(('w', id(c1), 0), dz[1 + 2 * b], acts[2 * b], _grad_buf(c1.weight), 0)
+                tape.defer_bias(_grad_buf(c1.bias), dz[1 + 2 * b])
+        tape.add_grad(tran, d_tran)
+    tape.record(bwd)
+    tape.keep.append(keep)
     return out
 
 

@@ -60,6 +60,7 @@ class VSRModel(BaseModel):
         self.allreduce_grads(self.net_G)
         self.optim_G.step()
         vals = losses.tolist()                       # the iteration's only host sync
+        TG.chain_check()        # fail-safe of the chained launches (a host read of a pinned counter)
         self.log_dict = OrderedDict(l_pix_G=vals[0])
         if self.warp_crit is not None:
             self.log_dict['l_warp_G'] = vals[1]

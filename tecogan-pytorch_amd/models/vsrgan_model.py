@@ -187,6 +187,7 @@ class VSRGANModel(VSRModel):
 
         # === logging: one host read of all scalars ===
         sc_ = scal.tolist()
+        TG.chain_check()        # fail-safe of the chained launches (a host read of a pinned counter)
         sr, sf, sg, ls = sc_[0:3], sc_[3:6], sc_[6:9], sc_[9:14]
         self.log_dict = OrderedDict()
         self.log_dict['l_gan_D'] = (sr[0] + sf[0]) if upd_D else 0.0

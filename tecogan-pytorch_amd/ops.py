@@ -287,7 +287,9 @@ _WGRAD_WS = {}
 
 
 def _wgrad_workspace(device, nfloats):
-    key = str(device)
+    # one scratch buffer per (device, stream): weight-gradient launches of the training step run on
+    # the main stream and on a side stream at the same time (Tape.flush_deferred_async)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < nfloats:
         ws = torch.empty(int(nfloats), dtype=torch.float32, device=device)

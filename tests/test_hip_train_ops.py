@@ -406,3 +406,166 @@ def test_index_gather_applies_the_embedding_tables(ops):
         want_acc = acc + want.reshape(-1).index_select(0, inv).view(shape)
         ops.index_gather(want, inv, out=acc, accumulate=True)
         assert torch.equal(acc, want_acc) and torch.equal(want.reshape(-1).index_select(0, inv).view(shape), w)
+
+
+# ---------------------------------------------------------------------------
+# SRNet's conv_in + residual blocks of a training frame as ONE chained launch
+# (tg_srnet_body_fwd / _bwd) against the per-layer tape nodes.
+# ---------------------------------------------------------------------------
+def _srnet(nb=3, scale=4, seed=5):
+    from tecogan_pytorch_amd.models.networks.tecogan_nets import SRNet
+    from tecogan_pytorch_amd.utils.net_utils import get_upsampling_func
+    torch.manual_seed(seed)
+    net = SRNet(3, 3, 64, nb, get_upsampling_func(scale, 'BD'), scale).cuda()
+    for p in net.parameters():                       # O(1) activations through the residual chain
+        if p.dim() == 4:
+            p.data.mul_(1.5)
+    return net
+
+
+def _body_both_ways(net, lr, tran, g_out):
+    """(out, d_tran, {param: grad}) through the chained launches and through one launch per layer."""
+    from tecogan_pytorch_amd.models import train_graph as TG
+    res = []
+    for chained in (True, False):
+        for p in net.parameters():
+            p.grad = None
+        tape = TG.Tape()
+        if chained:
+            out = TG.srnet_body(tape, net, lr, tran)
+        else:
+            out = TG.conv3x3(tape, net.conv_in['0'], lr, TG.RELU, x2=tran, need_dx=False, need_dx2=True)
+            for rb in net.resblocks:
+                out = TG.resblock(tape, rb.conv['0'], rb.conv['2'], out)
+        tape.add_grad(out, g_out.clone())
+        tape.backward()
+        torch.cuda.synchronize()
+        TG.chain_check()
+        grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        res.append((out.clone(), tape.grad(tran).clone(), grads))
+    return res
+
+
+@pytest.mark.parametrize('n,h,w,nb', [(2, 32, 32, 10), (2, 64, 64, 3), (1, 20, 37, 2), (3, 9, 70, 1)])
+def test_srnet_body_chain_equals_layer_launches(ops, n, h, w, nb):
+    from tecogan_pytorch_amd import _lib as L
+    parts = L.lib().tg_conv3x3_chain_supported(n, h, w, 64)
+    assert parts in (1, 2)
+    net = _srnet(nb)
+    lr, tran, g = dev(rs(1, (n, 3, h, w), 0, 1)), dev(rs(2, (n, 48, h, w), 0, 1)), dev(rs(3, (n, 64, h, w)))
+    (o1, t1, g1), (o2, t2, g2) = _body_both_ways(net, lr, tran, g)
+    # same MFMA order and the same fixed-order K reduction as the one-shot kernel when a workgroup
+    # owns all 64 channels of a tile; the 32-channel form reduces 8 single-chunk groups instead of
+    # 4 groups of 2 chunks: summation order only
+    assert relerr(o1, o2) <= 2e-5, relerr(o1, o2)
+    # The gradients are NOT continuous in the forward values: where a pre-activation lies within
+    # rounding of zero the two forms may disagree about relu'(x) (one such pixel at 2 x 32 x 32:
+    # conv_in, image 1, (31, 21)), and that pixel's 3x3 footprint then differs by O(1).  So: equal
+    # up to summation order on all but a handful of elements, and close in the L2 sense.
+    def mostly_equal(x, y, what, max_bad=1.0):
+        x, y = x.double().cpu(), y.double().cpu()
+        d = (x - y).abs()
+        bad = (d > 2e-5 * y.abs().max()).double().mean().item()
+        l2 = (d.norm() / (y.norm() + 1e-30)).item()
+        assert bad <= max_bad and l2 <= 3e-2, (what, bad, l2)
+    mostly_equal(t1, t2, 'd_tran', 4e-3)      # (a flipped pixel touches a whole filter slice of a weight gradient)
+    assert g1.keys() == g2.keys() and len(g1) == 2 * (1 + 2 * nb)
+    for k in g1:
+        mostly_equal(g1[k], g2[k], k)
+    # An exact check of the sweep's algebra: torch fp64 ops driven by the ReLU masks of the chained
+    # forward pass itself (so no sign decision is taken twice).
+    from tecogan_pytorch_amd.models import train_graph as TG
+    import ctypes
+    tape = TG.Tape()
+    for p in net.parameters():
+        p.grad = None
+    out = TG.srnet_body(tape, net, lr, tran)
+    acts = out._base if out._base is not None else None
+    assert acts is not None and acts.shape[0] == 1 + 2 * nb
+    tape.add_grad(out, g.clone())
+    tape.backward()
+    torch.cuda.synchronize()
+    TG.chain_check()
+    A = acts.double().cpu()
+    W = {k: p.detach().double().cpu() for k, p in net.named_parameters()}
+    x_in = torch.cat([lr, tran], 1).double().cpu()
+
+    def dgrad(dz, wt):
+        return F.conv_transpose2d(dz, wt, padding=1)
+
+    def wgrad(dz, x, wt):
+        return torch.nn.grad.conv2d_weight(x, wt.shape, dz, padding=1)
+    ref = {}
+    gg = g.double().cpu()
+    for b in reversed(range(nb)):
+        w1, w2 = W[f'resblocks.{b}.conv.0.weight'], W[f'resblocks.{b}.conv.2.weight']
+        ref[f'resblocks.{b}.conv.2.weight'] = wgrad(gg, A[1 + 2 * b], w2)
+        ref[f'resblocks.{b}.conv.2.bias'] = gg.sum((0, 2, 3))
+        dz1 = dgrad(gg, w2) * (A[1 + 2 * b] > 0)
+        ref[f'resblocks.{b}.conv.0.weight'] = wgrad(dz1, A[2 * b], w1)
+        ref[f'resblocks.{b}.conv.0.bias'] = dz1.sum((0, 2, 3))
+        gg = dgrad(dz1, w1) + gg
+    dz0 = gg * (A[0] > 0)
+    ref['conv_in.0.weight'] = wgrad(dz0, x_in, W['conv_in.0.weight'])
+    ref['conv_in.0.bias'] = dz0.sum((0, 2, 3))
+    d_tran_ref = dgrad(dz0, W['conv_in.0.weight'])[:, 3:]
+    assert relerr(tape.grad(tran), d_tran_ref) <= 2e-5, relerr(tape.grad(tran), d_tran_ref)
+    assert {k for k, p in net.named_parameters() if p.grad is not None} == set(ref)
+    for k, p in net.named_parameters():
+        if k in ref:
+            assert relerr(p.grad, ref[k]) <= 1e-4, (k, relerr(p.grad, ref[k]))
+    # and the forward pass against the fp32 reference ops
+    xr = F.relu(F.conv2d(x_in, W['conv_in.0.weight'], W['conv_in.0.bias'], padding=1))
+    for b in range(nb):
+        t = F.relu(F.conv2d(xr, W[f'resblocks.{b}.conv.0.weight'], W[f'resblocks.{b}.conv.0.bias'], padding=1))
+        xr = F.conv2d(t, W[f'resblocks.{b}.conv.2.weight'], W[f'resblocks.{b}.conv.2.bias'], padding=1) + xr
+    assert relerr(o1, xr) <= 2e-5, relerr(o1, xr)
+
+
+def test_srnet_body_chain_is_deterministic_and_repeatable(ops):
+    """40 consecutive chained launches (forward + sweep) on the same buffers: bit-identical results
+    every time (fixed-order reductions; flags re-armed by the epoch, never cleared)."""
+    net = _srnet(10)
+    lr, tran, g = dev(rs(1, (2, 3, 32, 32), 0, 1)), dev(rs(2, (2, 48, 32, 32), 0, 1)), dev(rs(3, (2, 64, 32, 32)))
+    from tecogan_pytorch_amd.models import train_graph as TG
+    first = None
+    for it in range(40):
+        tape = TG.Tape()
+        out = TG.srnet_body(tape, net, lr, tran)
+        tape.add_grad(out, g.clone())
+        tape.backward()
+        cur = (out.clone(), tape.grad(tran).clone())
+        if first is None:
+            first = cur
+        assert torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1]), it
+    torch.cuda.synchronize()
+    TG.chain_check()
+
+
+def test_srnet_body_chain_fault_is_reported_and_falls_back(ops):
+    """Fault injection (negative poll limit): chain_check() raises after the synchronisation and the
+    chained launch is off for the rest of the process (run in a subprocess for that reason)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from tests.test_hip_train_ops import _srnet, dev, rs\n"
+        "from tecogan_pytorch_amd.models import train_graph as TG\n"
+        "from tecogan_pytorch_amd import _lib\n"
+        "net = _srnet(2)\n"
+        "lr, tran = dev(rs(1, (2, 3, 32, 32), 0, 1)), dev(rs(2, (2, 48, 32, 32), 0, 1))\n"
+        "assert TG._ChainState.usable(2, 64, 51, 32, 32)\n"
+        "ref = TG.srnet_body(None, net, lr, tran).clone(); torch.cuda.synchronize(); TG.chain_check()\n"
+        "TG._ChainState.poll_limit = -1\n"
+        "bad = TG.srnet_body(None, net, lr, tran); torch.cuda.synchronize()\n"
+        "try:\n"
+        "    TG.chain_check(); raise SystemExit('no error reported')\n"
+        "except _lib.TecoganHipError as e:\n"
+        "    assert 'timed out' in str(e)\n"
+        "assert not TG._ChainState.usable(2, 64, 51, 32, 32)\n"
+        "out = net(lr, tran, tape=TG.Tape()); torch.cuda.synchronize(); TG.chain_check()\n"
+        "print('BODY-FAILSAFE-OK')\n" % root)
+    r = subprocess.run([sys.executable, '-c', script], timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0 and 'BODY-FAILSAFE-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
