@@ -200,17 +200,31 @@ int tg_conv3x3_chain(const tg_chain_layer* layers, int n_layers, int n, int h, i
 /* SRNet's conv_in + nb residual blocks on one training frame (tecogan_nets.py:108-116, :141-143) and
  * the matching reverse sweep, each as one tg_conv3x3_chain launch.  acts / dz: 1 + 2*nb tensors
  * (n, nf, h, w) back to back, acts[0] = conv_in's output, acts[1+2b] / acts[2+2b] = block b's inner
- * activation / output; dz[i] = gradient w.r.t. the pre-activation of layer i (dz[2nb] is not written:
- * it is g_out), d_tran = gradient w.r.t. the warped-frame input channels (n, c_tran, h, w).
+ * activation / output; dz[i] = gradient w.r.t. the pre-activation of layer i -- dz[2nb], the gradient of
+ * the body's output, is the INPUT the caller fills before the call -- d_tran = gradient w.r.t. the
+ * warped-frame input channels (n, c_tran, h, w).
  * layers[i] / dgrad[i]: forward / data-gradient packs of layer i (dgrad[0]: conv_in restricted to
  * input channels [c_lr, c_lr + c_tran), bias unused). */
 typedef struct { const float* w; const float* b; } tg_packed_layer;
 int tg_srnet_body_fwd(const tg_packed_layer* layers, int nb, const float* lr, int c_lr, const float* tran,
                       int c_tran, float* acts, int n, int nf, int h, int w, int32_t* flags, int32_t* err,
                       uint32_t epoch, int poll_limit, tg_stream_t stream);
-int tg_srnet_body_bwd(const tg_packed_layer* dgrad, int nb, const float* g_out, const float* acts, float* dz,
+int tg_srnet_body_bwd(const tg_packed_layer* dgrad, int nb, const float* acts, float* dz,
                       float* d_tran, int c_tran, int n, int nf, int h, int w, int32_t* flags, int32_t* err,
                       uint32_t epoch, int poll_limit, tg_stream_t stream);
+
+/* Weight / bias gradients of the chained body's layers for ALL unrolled frames in one launch each.
+ * dz_bases[f] / act_bases[f]: the dz / acts blocks of frame f (tg_srnet_body_bwd / _fwd),
+ * layer_stride = n_per_frame * c * h * w.
+ *   tg_wgrad3x3_body: grads[L - 1] (+)= dW of layer L = 1 .. nlayers (= 2 * nb; conv_in, whose input has
+ *     other channel counts, goes through tg_wgrad3x3_multi); workspace: tg_wgrad3x3_body_workspace_floats.
+ *   tg_bias_grad_body: dbs[L] += db of layer L = 0 .. nlayers - 1 (= 1 + 2 * nb layers, conv_in included). */
+size_t tg_wgrad3x3_body_workspace_floats(int nframes, int n_per_frame, int nlayers, int c, int h, int w);
+int tg_wgrad3x3_body(const float* const* dz_bases, const float* const* act_bases, int nframes, int64_t layer_stride, int nlayers, float* const* grads, float* workspace,
+                     int n_per_frame, int c, int h, int w, int accumulate, tg_stream_t stream);
+int tg_bias_grad_body(const float* const* dz_bases, int nframes,
+                      int64_t layer_stride, int nlayers, float* const* dbs, int n_per_frame, int c, int hw,
+                      tg_stream_t stream);
 
 /* Split-K variant for layers whose output tile count cannot fill the GPU (FNet's
  * low-resolution many-channel middle, tecogan_nets.py:37-60): `ksplit` groups of

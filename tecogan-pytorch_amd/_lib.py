@@ -110,7 +110,10 @@ SIGNATURES = {
     'tg_conv3x3_chain_supported': (I, [I, I, I, I]),
     'tg_conv3x3_chain': (I, [C.POINTER(ChainLayer), I, I, I, I, P, P, C.c_uint32, I, P]),
     'tg_srnet_body_fwd': (I, [C.POINTER(PackedLayer), I, P, I, P, I, P, I, I, I, I, P, P, C.c_uint32, I, P]),
-    'tg_srnet_body_bwd': (I, [C.POINTER(PackedLayer), I, P, P, P, P, I, I, I, I, I, P, P, C.c_uint32, I, P]),
+    'tg_srnet_body_bwd': (I, [C.POINTER(PackedLayer), I, P, P, P, I, I, I, I, I, P, P, C.c_uint32, I, P]),
+    'tg_wgrad3x3_body_workspace_floats': (SZ, [I, I, I, I, I, I]),
+    'tg_wgrad3x3_body': (I, [P, P, I, I64, I, P, P, I, I, I, I, I, P]),
+    'tg_bias_grad_body': (I, [P, I, I64, I, P, I, I, I, P]),
     'tg_conv3x3_prefers_wino': (I, [I, I, I, I, I]),
     'tg_pack_conv3x3_wino': (I, [P, P, I, I, I, P]),
     'tg_conv3x3_wino_fwd': (I, [P, I64, I, P, I64, P, P, P, I64, P, I64, P, I64, I, I, I, I, I, I, P]),

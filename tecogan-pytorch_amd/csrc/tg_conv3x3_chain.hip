@@ -350,8 +350,9 @@ extern "C" int tg_conv3x3_chain(const tg_chain_layer* layers, int n_layers, int 
 // tensors (n, nf, h, w) back to back:
 //   acts[0] = relu(conv_in(cat[lr, tran]));  acts[1+2b] = relu(conv1_b(acts[2b]));
 //   acts[2+2b] = conv2_b(acts[1+2b]) + acts[2b]                      (block b's output)
-//   dz[2nb]   is NOT written (the gradient of the body's output is the caller's g_out);
-//   dz[1+2b]  = relu'(acts[1+2b]) . dgrad(conv2_b)(g_b)             g_b = dz[2+2b] (g_out for b = nb-1)
+//   dz[2nb]   is the INPUT: the caller places the gradient of the body's output there (so that every
+//             (dZ, X) operand pair of the weight gradients lies in the two blocks, tg_wgrad3x3_body);
+//   dz[1+2b]  = relu'(acts[1+2b]) . dgrad(conv2_b)(g_b)             g_b = dz[2+2b]
 //   dz[2b]    = dgrad(conv1_b)(dz[1+2b]) + g_b                        for b >= 1: gradient of block b-1's output
 //   dz[0]     = relu'(acts[0]) . (dgrad(conv1_0)(dz[1]) + g_0)        dZ of conv_in
 //   d_tran    = dgrad(conv_in, channels [c_lr, c_lr + c_tran))(dz[0])
@@ -388,16 +389,16 @@ extern "C" int tg_srnet_body_fwd(const tg_packed_layer* layers, int nb, const fl
   return tg_conv3x3_chain(cl, 1 + 2 * nb, n, h, w, flags, err, epoch, poll_limit, stream);
 }
 
-extern "C" int tg_srnet_body_bwd(const tg_packed_layer* dgrad, int nb, const float* g_out, const float* acts, float* dz,
+extern "C" int tg_srnet_body_bwd(const tg_packed_layer* dgrad, int nb, const float* acts, float* dz,
                                  float* d_tran, int c_tran, int n, int nf, int h, int w, int32_t* flags, int32_t* err,
                                  uint32_t epoch, int poll_limit, tg_stream_t stream) {
-  if (int rc = body_common(nb, n, nf, h, w, dgrad, g_out, acts)) return rc;
-  TG_REQUIRE(dz && d_tran && c_tran > 0 && c_tran <= 64, TG_E_ARG, "srnet_body_bwd: null pointer / c_tran=%d", c_tran);
+  if (int rc = body_common(nb, n, nf, h, w, dgrad, dz, acts)) return rc;
+  TG_REQUIRE(d_tran && c_tran > 0 && c_tran <= 64, TG_E_ARG, "srnet_body_bwd: null pointer / c_tran=%d", c_tran);
   const int64_t hw = (int64_t)h * w, ns = (int64_t)nf * hw, ts = (int64_t)n * ns;
   tg_chain_layer cl[RC_MAXL];
   int k = 0;
   for (int b = nb - 1; b >= 0; --b) {
-    const float* g = (b == nb - 1) ? g_out : dz + (size_t)(2 + 2 * b) * ts;
+    const float* g = dz + (size_t)(2 + 2 * b) * ts;
     TG_REQUIRE(dgrad[1 + 2 * b].w && dgrad[2 + 2 * b].w, TG_E_ARG, "srnet_body_bwd: block %d null", b);
     {   // dz[1+2b] = relu'(acts[1+2b]) . dgrad(conv2_b)(g)
       tg_chain_layer& d = cl[k++];

@@ -673,10 +673,10 @@ static int launch_conv(const Conv3x3Args& a0, int n, hipStream_t stream) {
   if (KS > 1) {
     static bool attr_set = false;
     if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(
                               conv3x3_mfma_kernel<WM, WN, NT, true, 0, TG_CONV_OPT, 12, KS>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(
                               conv3x3_mfma_kernel<WM, WN, NT, false, 0, TG_CONV_OPT, 12, KS>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;

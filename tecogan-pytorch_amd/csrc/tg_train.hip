@@ -88,6 +88,37 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(BiasGradSegs dy, int n_p
   if (threadIdx.x == 0) atomicAdd(db + ch, r);
 }
 
+// The bias gradients of all the layers of the chained SRNet body in one launch: layer L = 0..nlayer-1
+// reads base[f] + L * lstride for every frame f; grid = (channel, slice, layer).
+struct BiasBodyArgs { const float* base[64]; float* db[25]; };
+__global__ __launch_bounds__(256) void bias_grad_body_kernel(BiasBodyArgs a, int nlayer, long long lstride,
+                                                             int nframes, int n_per, int c, int hw, int nslice) {
+  __shared__ float sm[4];
+  const int ch = blockIdx.x, sl = blockIdx.y, L = blockIdx.z;
+  const long long total = (long long)nframes * n_per * hw;
+  const long long per = ((total + nslice - 1) / nslice + 3) & ~3ll;
+  const long long lo = (long long)sl * per;
+  long long hi = lo + per; if (hi > total) hi = total;
+  float s = 0.f;
+  int b = (int)(lo / hw);
+  long long r0 = lo - (long long)b * hw;
+  for (long long left = hi - lo; left > 0; ++b, r0 = 0) {
+    const int f = b / n_per, lb = b - f * n_per;
+    const float* src = a.base[f] + (long long)L * lstride;
+    const float* __restrict__ pl = src + ((long long)lb * c + ch) * hw;
+    const long long cnt = (hw - r0 < left) ? hw - r0 : left;
+    if (((hw | r0 | cnt) & 3) == 0 && (((uintptr_t)pl) & 15) == 0) {
+      const f32x4* p4 = reinterpret_cast<const f32x4*>(pl + r0);
+      for (long long r = threadIdx.x; r < (cnt >> 2); r += 256) { const f32x4 v = p4[r]; s += (v[0] + v[1]) + (v[2] + v[3]); }
+    } else {
+      for (long long r = threadIdx.x; r < cnt; r += 256) s += pl[r0 + r];
+    }
+    left -= cnt;
+  }
+  float r = block_sum(s, sm);
+  if (threadIdx.x == 0) atomicAdd(a.db[L] + ch, r);
+}
+
 // gradient of MaxPool2d(2,2) floor mode: goes to the FIRST maximal element of the window
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                     float* __restrict__ dx, int nc, int h, int w) {
@@ -543,6 +574,29 @@ static int bias_grad_launch(const float* const* dy_list, int nseg, float* db, in
   hipLaunchKernelGGL(bias_grad_kernel, dim3(c, nslice), dim3(256), 0, ST, segs, n_per_seg, db, n, c, hw,
                      nslice);
   return check_launch("bias_grad");
+}
+
+extern "C" int tg_bias_grad_body(const float* const* dz_bases, int nframes,
+                                 int64_t layer_stride, int nlayers, float* const* dbs, int n_per_frame, int c,
+                                 int hw, tg_stream_t stream) {
+  TG_REQUIRE(dz_bases && dbs && nframes >= 1 && nframes <= 64 && nlayers >= 1 && nlayers <= 25 &&
+                 n_per_frame > 0 && c > 0 && hw > 0, TG_E_ARG, "bias_grad_body: bad argument");
+  BiasBodyArgs a{};
+  for (int i = 0; i < nframes; ++i) {
+    TG_REQUIRE(dz_bases[i], TG_E_ARG, "bias_grad_body: null frame %d", i);
+    a.base[i] = dz_bases[i];
+  }
+  for (int i = 0; i < nlayers; ++i) {
+    TG_REQUIRE(dbs[i], TG_E_ARG, "bias_grad_body: null gradient %d", i);
+    a.db[i] = dbs[i];
+  }
+  const long long total = (long long)nframes * n_per_frame * hw;
+  int nslice = (int)((total + 4095) / 4096);
+  if (nslice < 1) nslice = 1;
+  if ((long long)nslice * c * nlayers > 16384) nslice = (int)(16384 / ((long long)c * nlayers)) > 0 ? (int)(16384 / ((long long)c * nlayers)) : 1;
+  hipLaunchKernelGGL(bias_grad_body_kernel, dim3(c, nslice, nlayers), dim3(256), 0, ST, a, nlayers,
+                     (long long)layer_stride, nframes, n_per_frame, c, hw, nslice);
+  return check_launch("bias_grad_body");
 }
 
 extern "C" int tg_bias_grad(const float* dy, float* db, int n, int c, int hw, int accumulate,

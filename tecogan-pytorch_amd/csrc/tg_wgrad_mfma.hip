@@ -44,11 +44,22 @@ struct WgradArgs {
   int ca, cb, cb_total, cb_off;   // G is written at columns [cb_off, cb_off+cb) of a cb_total-wide matrix
   int n, h, w;
   int tiles_x, tiles_y, ntiles, nsplit, nab, nbb;
+  // (ablation builds, -DWG_ABL=bits: 1 no global loads after the first tile, 2 no LDS stores after the
+  //  first, 4 no MFMAs, 8 no LDS operand reads)
   // phase-restricted taps (see tg_conv3x3_mfma.hip): the b channels come in 4 sub-pixel phases
   // of cphase channels; phase coordinate v along an axis uses tap set rowsets[v].  Taps outside
   // the set are not computed (their gradient entries are written as 0; the embedding drops them).
   int cphase;
   unsigned char rowsets[2];
+  // Layered mode (nlayer > 0; tg_wgrad3x3_body): ONE launch computes the gradients of nlayer
+  // consecutive equally shaped layers whose operands lie in per-frame blocks of tensors `lstride`
+  // floats apart (the chained SRNet body keeps a frame's activations / gradients that way):
+  //   layer L = 1..nlayer:  P = pseg[seg] + L * lstride,  Q = qseg[seg] + (L - 1) * lstride
+  // blockIdx also enumerates the layers; partial sums of layer L start at part + (L - 1) * nsplit * ca * cb_total * 9.
+  // (Kept to two scalars: a larger argument struct is no longer promoted out of private memory by
+  //  the compiler and every access turns into a scratch load -- measured 4x slower.)
+  int nlayer;
+  long long lstride;
 };
 
 enum { WTAPS_ALL = 0, WTAPS_01 = 1, WTAPS_12 = 2, WTAPS_1 = 3 };
@@ -67,8 +78,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   const int cot = wave & 1, cit = wave >> 1;
   int b = blockIdx.x;
   const int split = b % a.nsplit; b /= a.nsplit;
-  const int bb = b % a.nbb;
-  const int ab = b / a.nbb;
+  const int bb = b % a.nbb; b /= a.nbb;
+  const int ab = b % a.nab;
+  const int li = b / a.nab;                  // layer index (0 outside the layered mode)
   const int a0 = ab * 64, b0 = bb * 64;
   const int hw = a.h * a.w;
   const unsigned plane = (unsigned)hw * 4u;
@@ -95,10 +107,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     int x0 = tx * WG_TW, y0 = ty * WG_R;
     const int seg = __builtin_amdgcn_readfirstlane(n / a.n_per_seg);
     const int ln = __builtin_amdgcn_readfirstlane(n - seg * a.n_per_seg);
+    const float* pbase = a.pseg[seg];
+    const float* qbase = a.qseg[seg];
+    if (a.nlayer) {
+      pbase += (long long)(li + 1) * a.lstride;
+      qbase += (long long)li * a.lstride;
+    }
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.pseg[seg] + (long long)ln * a.p_ns), 0, a.ca * hw * 4, 0x00020000);
+        const_cast<float*>(pbase + (long long)ln * a.p_ns), 0, a.ca * hw * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.qseg[seg] + (long long)ln * a.q_ns), 0, a.cb * hw * 4, 0x00020000);
+        const_cast<float*>(qbase + (long long)ln * a.q_ns), 0, a.cb * hw * 4, 0x00020000);
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
       int idx = tid + i * 256;
@@ -146,40 +164,55 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     store_tile(0);
   }
   __syncthreads();
+#ifndef WG_ABL
+#define WG_ABL 0      // compile-time ablation bits (tools/build_lab_libs.sh builds one library per value)
+#endif
+#define WGABL(bit) ((WG_ABL & (bit)) != 0)
   for (; tile < a.ntiles; tile += a.nsplit, ++it) {
     const int buf = it & 1;
     const bool more = tile + a.nsplit < a.ntiles;
-    if (more) load_tile(tile + a.nsplit);
+    if (more && !WGABL(1)) load_tile(tile + a.nsplit);
     const float* pa = sA + buf * WG_A_FLOATS + a_rd;
     const float* pb = sB + buf * WG_B_FLOATS + b_rd;
 #pragma unroll
     for (int r = 0; r < WG_R; ++r) {
 #pragma unroll
       for (int g = 0; g < WG_TW / 8; ++g) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(pa + r * WG_TW + 8 * g);
+        f32x4 av = {1.f, 2.f, 3.f, 4.f};
         float bv[3][6];
+        if (!WGABL(8)) {
+          av = *reinterpret_cast<const f32x4*>(pa + r * WG_TW + 8 * g);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+          for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-          for (int c6 = 0; c6 < 6; ++c6) bv[ky][c6] = pb[(r + ky) * WG_RSB + 8 * g + c6];
+            for (int c6 = 0; c6 < 6; ++c6) bv[ky][c6] = pb[(r + ky) * WG_RSB + 8 * g + c6];
+        } else {
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int c6 = 0; c6 < 6; ++c6) bv[ky][c6] = (float)(ky + c6 + r + g);
+        }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx)
             if (wtap_on(RY, ky) && wtap_on(RX, kx)) {
 #pragma unroll
-              for (int kk = 0; kk < 4; ++kk)
+              for (int kk = 0; kk < 4; ++kk) {
+                if (WGABL(4)) acc[ky * 3 + kx][kk] += av[kk] * bv[ky][kk + kx];
+                else
                 acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[ky][kk + kx],
                                                                         acc[ky * 3 + kx], 0, 0, 0);
+              }
             }
       }
     }
-    if (more) store_tile(buf ^ 1);
+    if (more && !WGABL(2)) store_tile(buf ^ 1);
     __syncthreads();
   }
 
   // D[i = a-channel][j = b-channel]: lane holds j = ll, registers walk i
-  float* out = a.part + (long long)split * a.ca * a.cb_total * 9;
+  float* out = a.part + ((long long)li * a.nsplit + split) * a.ca * a.cb_total * 9;
   const int bj = b0 + cit * 32 + ll;
   if (bj < a.cb) {
 #pragma unroll
@@ -197,7 +230,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
 __global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) {
   if (a.cphase == 0) { wgrad_body<WTAPS_ALL, WTAPS_ALL>(a); return; }
   // block-uniform: the 64 b channels of this block belong to one sub-pixel phase
-  const int bb = ((int)blockIdx.x / a.nsplit) % a.nbb;
+  const int bb = ((int)blockIdx.x / a.nsplit) % a.nbb;      // (phased launches are never layered)
   const int ph = (bb * 64) / a.cphase;
   const int ry = a.rowsets[(ph >> 1) & 1], rx = a.rowsets[ph & 1];
   switch (ry * 4 + rx) {
@@ -249,6 +282,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// the same reduction for every layer of a layered launch: blockIdx.y = layer
+struct WgradLayerGrads { float* g[24]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_layers_kernel(const float* __restrict__ part, WgradLayerGrads gl,
+                                                                  int nsplit, int ca, int cb, int accumulate) {
+  __shared__ float sm[4][64];
+  const long long stride = (long long)ca * cb * 9;
+  const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + o;
+  const float* p = part + (long long)blockIdx.y * nsplit * stride + i;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < stride) {
+    int k = sg;
+    for (; k + 12 < nsplit; k += 16) {
+      s0 += p[(long long)k * stride];
+      s1 += p[(long long)(k + 4) * stride];
+      s2 += p[(long long)(k + 8) * stride];
+      s3 += p[(long long)(k + 12) * stride];
+    }
+    for (; k < nsplit; k += 4) s0 += p[(long long)k * stride];
+  }
+  sm[sg][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sg == 0 && i < stride) {
+    float s = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
+    float* g = gl.g[blockIdx.y];
+    g[i] = accumulate ? g[i] + s : s;
+  }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -294,6 +356,8 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
   a.ntiles = n * a.tiles_x * a.tiles_y;
   a.nab = cdiv(ca, 64); a.nbb = cdiv(cb, 64);
   a.nsplit = wgrad_nsplit(n, h, w, ca, cb_total);   // same value the workspace was sized with
+  static const int maxwg = TG_LAB_ENV("TG_WGRAD_MAXWG", 0);     // lab: cap the K split (workgroups per channel block)
+  if (maxwg > 0 && a.nsplit > maxwg) a.nsplit = maxwg;
   a.cphase = cphase; a.rowsets[0] = (unsigned char)set_p0; a.rowsets[1] = (unsigned char)set_p1;
   if (cphase) {
     TG_REQUIRE(cphase % 64 == 0 && cb == 4 * cphase && cb_off == 0 && set_p0 >= 0 && set_p0 <= 3 &&
@@ -304,7 +368,7 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
   size_t lds = 2 * (size_t)(WG_A_FLOATS + WG_B_FLOATS) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_mfma_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_mfma_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -317,6 +381,68 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace,
                      grad, a.nsplit, ca, cb, cb_total, cb_off, accumulate);
   return check_launch("wgrad_reduce");
+}
+
+// K split of a layered launch: ~5 rounds of workgroups over the device, whole tiles per workgroup
+static int body_nsplit(int nframes, int n_per_frame, int nlayers, int c, int h, int w) {
+  const int ntiles = nframes * n_per_frame * cdiv(h, WG_R) * cdiv(w, WG_TW);
+  const int blocks_ch = cdiv(c, 64) * cdiv(c, 64);
+  int s = 1280 / (nlayers * blocks_ch);
+  if (s < 1) s = 1;
+  if (s > ntiles) s = ntiles;
+  if (s > 256) s = 256;
+  return s;
+}
+
+extern "C" size_t tg_wgrad3x3_body_workspace_floats(int nframes, int n_per_frame, int nlayers, int c, int h, int w) {
+  if (nframes <= 0 || n_per_frame <= 0 || nlayers <= 0 || c <= 0 || h <= 0 || w <= 0) return 0;
+  return (size_t)nlayers * body_nsplit(nframes, n_per_frame, nlayers, c, h, w) * c * c * 9;
+}
+
+extern "C" int tg_wgrad3x3_body(const float* const* dz_bases, const float* const* act_bases,
+                                int nframes, int64_t layer_stride, int nlayers,
+                                float* const* grads, float* workspace, int n_per_frame, int c, int h, int w,
+                                int accumulate, tg_stream_t stream) {
+  TG_REQUIRE(dz_bases && act_bases && grads && workspace, TG_E_ARG, "wgrad3x3_body: null pointer");
+  TG_REQUIRE(nframes >= 1 && nframes <= WG_MAXSEG && nlayers >= 1 && nlayers <= 24, TG_E_ARG,
+             "wgrad3x3_body: %d frames (1..%d), %d layers (1..24)", nframes, WG_MAXSEG, nlayers);
+  TG_REQUIRE(n_per_frame > 0 && c > 0 && h > 0 && w > 0 && layer_stride >= (int64_t)n_per_frame * c * h * w,
+             TG_E_SHAPE, "wgrad3x3_body: n=%d c=%d h=%d w=%d stride=%lld", n_per_frame, c, h, w, (long long)layer_stride);
+  TG_REQUIRE((long long)c * h * w * 4 < (1ll << 31), TG_E_SHAPE, "wgrad3x3_body: one batch item must be < 2 GiB");
+  WgradArgs a{};
+  WgradLayerGrads gl{};
+  for (int i = 0; i < nframes; ++i) {
+    TG_REQUIRE(dz_bases[i] && act_bases[i], TG_E_ARG, "wgrad3x3_body: null frame %d", i);
+    a.pseg[i] = dz_bases[i]; a.qseg[i] = act_bases[i];
+  }
+  for (int i = 0; i < nlayers; ++i) {
+    TG_REQUIRE(grads[i], TG_E_ARG, "wgrad3x3_body: null gradient %d", i);
+    gl.g[i] = grads[i];
+  }
+  const int n = nframes * n_per_frame;
+  a.n_per_seg = n_per_frame; a.part = workspace;
+  a.p_ns = a.q_ns = (long long)c * h * w;
+  a.ca = a.cb = a.cb_total = c; a.cb_off = 0; a.n = n; a.h = h; a.w = w;
+  a.tiles_x = cdiv(w, WG_TW); a.tiles_y = cdiv(h, WG_R);
+  a.ntiles = n * a.tiles_x * a.tiles_y;
+  a.nab = a.nbb = cdiv(c, 64);
+  a.nsplit = body_nsplit(nframes, n_per_frame, nlayers, c, h, w);
+  a.nlayer = nlayers; a.lstride = layer_stride;
+  size_t lds = 2 * (size_t)(WG_A_FLOATS + WG_B_FLOATS) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_mfma_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad3x3_mfma_kernel, dim3((unsigned)(nlayers * a.nab * a.nbb * a.nsplit)), dim3(256), lds, s, a);
+  int rc = check_launch("wgrad3x3_body");
+  if (rc != TG_OK) return rc;
+  const long long total = (long long)c * c * 9;
+  hipLaunchKernelGGL(wgrad_reduce_layers_kernel, dim3((unsigned)((total + 63) / 64), (unsigned)nlayers), dim3(256), 0, s,
+                     workspace, gl, a.nsplit, c, c, accumulate);
+  return check_launch("wgrad_reduce_layers");
 }
 
 extern "C" int tg_wgrad3x3(const float* p, int64_t p_nstride, const float* q, int64_t q_nstride,

@@ -295,9 +295,11 @@ class FRNet(nn.Module):
         self.srnet = SRNet(in_nc, out_nc, nf, nb, self.upsample_func, self.scale)
         self._plan = {}
         self._plan_key = None
-        # training: weight gradients of the swept half of the unroll run on a side stream under the
-        # rest of the sweep (train_graph.Tape.flush_deferred_async); False = everything on one stream
-        self.wgrad_side_stream = True
+        # training: True = the weight gradients of the swept half of the unroll go to a side stream
+        # under the rest of the sweep (train_graph.Tape.flush_deferred_async).  Off: the weight-gradient
+        # kernel holds a whole CU per workgroup (464 registers, 107 KB LDS), so on one GPU nothing of
+        # the sweep runs beside it and the second flush only adds launches (measured: 24.5 vs 24.8 ms).
+        self.wgrad_side_stream = False
 
     # -- plan cache ---------------------------------------------------------
     def _weights_key(self):

@@ -25,6 +25,7 @@ class Tape:
         self.keep = []          # tensors that must outlive backward (id() stability)
         self.deferred = {}
         self.deferred_bias = {}
+        self.deferred_body = {}  # chained SRNet bodies: per network, the (acts, dz, g_out) blocks of every swept frame
         self.side = None        # side stream of the asynchronous weight-gradient flushes
         self._inflight = []     # tensors the side stream still reads (kept alive until the join)
 
@@ -52,7 +53,7 @@ class Tape:
         for fn in reversed(self.nodes):
             fn()
         self.nodes = []
-        if self.side is not None and (self.deferred or self.deferred_bias):
+        if self.side is not None and (self.deferred or self.deferred_bias or self.deferred_body):
             self.flush_deferred_async()      # the tail goes behind the earlier chunks on the side stream
         else:
             self.flush_deferred()
@@ -76,6 +77,8 @@ class Tape:
             self._inflight += ent['p'] + ent['q']
         for _, dzs in self.deferred_bias.values():
             self._inflight += dzs
+        for ent in self.deferred_body.values():
+            self._inflight += ent['acts'] + ent['dz']
         with torch.cuda.stream(self.side):
             self.flush_deferred()
 
@@ -98,6 +101,11 @@ class Tape:
 
     def defer_bias(self, buf, dz):
         self.deferred_bias.setdefault(id(buf), (buf, []))[1].append(dz)
+
+    def defer_body(self, key, layers, acts, dz):
+        ent = self.deferred_body.setdefault(key, {'layers': layers, 'acts': [], 'dz': []})
+        ent['acts'].append(acts)
+        ent['dz'].append(dz)
 
     def flush_deferred(self):
         def same(ts):
@@ -128,6 +136,15 @@ class Tape:
                     Q = q0 if len(ent['q']) == 1 else torch.cat(ent['q'], 0)
                     ops.wgrad3x3(P, Q, ge, accumulate=False)
                 ent['post'](ge)
+        for ent in self.deferred_body.values():
+            # the 2*nb residual-block convs of every swept frame: ONE weight-gradient launch (+ one
+            # reduce) and one bias-gradient launch instead of 2*nb of each per flush
+            layers = ent['layers']
+            if not layers[1].weight.requires_grad:
+                continue
+            ops.wgrad3x3_body(ent['dz'], ent['acts'], [_grad_buf(m.weight) for m in layers[1:]])
+            ops.bias_grad_body(ent['dz'], [_grad_buf(m.bias) for m in layers])
+        self.deferred_body = {}
         for buf, dzs in self.deferred_bias.values():
             if len(dzs) > 1 and same(dzs):
                 ops.bias_grad_multi(dzs, buf, accumulate=True)
@@ -351,7 +368,6 @@ def srnet_body(tape, srnet, lr, tran):
         g = tape.pop_grad(out)
         if g is None:
             return
-        g = g.contiguous()
         dg = (L.PackedLayer * nl)()
         hold = []
         w_in = conv_in.weight
@@ -365,9 +381,10 @@ def srnet_body(tape, srnet, lr, tran):
             hold.append(pk)
             dg[i].w = pk[0].data_ptr()
         dz = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=g.device)
+        dz[nl - 1].copy_(g)       # the gradient of the body's output lives in the block's last slot
         d_tran = torch.empty(n, c_tran, h, w, dtype=torch.float32, device=g.device)
         fl, er, ep = _ChainState.buffers(nl + 1, n, h, w, g.device)
-        L.check(L.lib().tg_srnet_body_bwd(dg, nb, g.data_ptr(), acts.data_ptr(), dz.data_ptr(), d_tran.data_ptr(),
+        L.check(L.lib().tg_srnet_body_bwd(dg, nb, acts.data_ptr(), dz.data_ptr(), d_tran.data_ptr(),
                                           c_tran, n, nf, h, w, fl.data_ptr(), er.data_ptr(), ep,
                                           _ChainState.poll_limit, torch.cuda.current_stream().cuda_stream),
                 'tg_srnet_body_bwd')
@@ -376,15 +393,9 @@ def srnet_body(tape, srnet, lr, tran):
             gw = _grad_buf(conv_in.weight)
             tape.defer_wgrad(('w', id(conv_in), 0), dz[0], lr, gw, 0)
             tape.defer_wgrad(('w', id(conv_in), 1), dz[0], tran, gw, c_lr)
-            tape.defer_bias(_grad_buf(conv_in.bias), dz[0])
-        for b, (c1, c2) in enumerate(blocks):
-            if c2.weight.requires_grad:
-                gb = g if b == nb - 1 else dz[2 + 2 * b]
-                tape.defer_wgrad(('w', id(c2), 0), gb, acts[1 + 2 * b], _grad_buf(c2.weight), 0)
-                tape.defer_bias(_grad_buf(c2.bias), gb)
-            if c1.weight.requires_grad:
-                tape.defer_wgrad(('w', id(c1), 0), dz[1 + 2 * b], acts[2 * b], _grad_buf(c1.weight), 0)
-                tape.defer_bias(_grad_buf(c1.bias), dz[1 + 2 * b])
+            # the residual-block convs' weight gradients and ALL the bias gradients (conv_in's too)
+            # are taken from the per-frame blocks by one launch each when the tape is flushed
+            tape.defer_body(id(srnet), layers, acts, dz)
         tape.add_grad(tran, d_tran)
     tape.record(bwd)
     tape.keep.append(keep)

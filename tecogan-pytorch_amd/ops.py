@@ -360,6 +360,43 @@ def wgrad3x3_multi(p_list, q_list, grad, cb_off=0, accumulate=True, phased=None)
     return grad
 
 
+def wgrad3x3_body(dz_list, acts_list, grads, accumulate=True):
+    """tg_wgrad3x3_body: weight gradients of the chained SRNet body's 2*nb residual-block convs over ALL
+    unrolled frames in one launch.  dz_list[f] / acts_list[f]: (1 + 2nb, n, c, h, w) blocks of frame f
+    (dz[2nb] = gradient of the body's output); grads: the 2nb weight-gradient tensors."""
+    nl, n, c, h, w = dz_list[0].shape
+    for t in list(dz_list) + list(acts_list):
+        _chk(t, 'block')
+        if t.shape != dz_list[0].shape:
+            raise L.TecoganHipError('wgrad3x3_body: frames must share one shape')
+    if len(grads) != nl - 1 or len(dz_list) != len(acts_list):
+        raise L.TecoganHipError('wgrad3x3_body: mismatched lists')
+    for g in grads:
+        _chk(g, 'grad')
+        if tuple(g.shape) != (c, c, 3, 3):
+            raise L.TecoganHipError(f'wgrad3x3_body: grad {tuple(g.shape)}')
+    lib = L.lib()
+    for i in range(0, len(dz_list), MAX_SEGS):
+        dzs, acs = dz_list[i:i + MAX_SEGS], acts_list[i:i + MAX_SEGS]
+        ws = _wgrad_workspace(grads[0].device, lib.tg_wgrad3x3_body_workspace_floats(len(dzs), n, nl - 1, c, h, w))
+        L.check(lib.tg_wgrad3x3_body(_ptr_array(dzs), _ptr_array(acs), len(dzs), n * c * h * w,
+                                     nl - 1, _ptr_array(grads), ws.data_ptr(), n, c, h, w,
+                                     1 if (accumulate or i > 0) else 0, _stream()), 'tg_wgrad3x3_body')
+
+
+def bias_grad_body(dz_list, dbs):
+    """tg_bias_grad_body: dbs[L] += bias gradient of layer L = 0 .. 2nb of the chained body, all frames."""
+    nl, n, c, h, w = dz_list[0].shape
+    if len(dbs) != nl:
+        raise L.TecoganHipError('bias_grad_body: mismatched lists')
+    for t in list(dz_list) + list(dbs):
+        _chk(t, 'tensor')
+    for i in range(0, len(dz_list), MAX_SEGS):
+        dzs = dz_list[i:i + MAX_SEGS]
+        L.check(L.lib().tg_bias_grad_body(_ptr_array(dzs), len(dzs), n * c * h * w, nl,
+                                          _ptr_array(dbs), n, c, h * w, _stream()), 'tg_bias_grad_body')
+
+
 def bias_grad_multi(dy_list, db, accumulate=True):
     if not dy_list:
         raise L.TecoganHipError('bias_grad_multi: empty list')

@@ -20,3 +20,7 @@ ls -la $OUT/*.so
 /opt/rocm/bin/hipcc $FLAGS -DTG_WINO_LAB=1 -c tg_conv3x3_wino.hip -o $OUT/tg_conv3x3_wino_lab.o
 OBJS=$(ls tg_*.o | grep -v tg_conv3x3_wino.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libtecogan_wino_lab.so $OBJS $OUT/tg_conv3x3_wino_lab.o -ldl
+# whole library with every lab switch compiled in (TG_LAB=1): TECOGAN_HIP_LIB=tools/_lab_libs/libtecogan_lab.so
+mkdir -p $OUT/lab_objs
+for f in tg_*.hip; do /opt/rocm/bin/hipcc $FLAGS -DTG_LAB=1 -c $f -o $OUT/lab_objs/${f%.hip}.o & done; wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libtecogan_lab.so $OUT/lab_objs/*.o -ldl
