@@ -58,7 +58,7 @@ enum {
 /* ABI version, major * 100 + minor.  The major number changes whenever a struct declared here
  * changes size or an entry changes its signature (a host compiled against another major must not
  * call in: check tg_version() / 100 == TG_ABI_MAJOR after dlopen).
- *   1xx: round-1 ABI.   2xx: tg_layer_weights gained `u` (24 bytes, was 16);
+ *   1xx: round-1 ABI.   2xx (minor 1: + chained training launches, phased_masked): tg_layer_weights gained `u` (24 bytes, was 16);
  *   tg_frnet_plan_chain_error_index replaced by tg_frnet_plan_chain_status. */
 #define TG_ABI_MAJOR 2
 int tg_version(void);
@@ -109,6 +109,13 @@ int tg_conv3x3_fwd_phased(const float* x, int64_t x_nstride, const float* w_pack
                           const float* bias, float* y, int64_t y_nstride, int n, int cin,
                           int cout, int h, int w, int act, int tapsel, int cphase,
                           int taps_phase0, int taps_phase1, tg_stream_t stream);
+/* the same with a ReLU-backward mask in the epilogue (see tg_conv3x3_fwd_masked): the data gradient
+ * of a transposed conv delivers dZ of the ReLU layer below it directly (relu_mask may be NULL) */
+int tg_conv3x3_fwd_phased_masked(const float* x, int64_t x_nstride, const float* w_packed, int ocb,
+                                 const float* bias, const float* relu_mask, int64_t mask_nstride,
+                                 float* y, int64_t y_nstride, int n, int cin, int cout, int h, int w,
+                                 int act, int tapsel, int cphase, int taps_phase0, int taps_phase1,
+                                 tg_stream_t stream);
 /* tg_conv3x3_fwd followed by a ReLU-backward mask in the same epilogue:
  *   y = relu_mask > 0 ? y : 0      (relu_mask: (n,cout,h,w) fp32, e.g. a ReLU layer's output)
  * Used by the training tape: the data-gradient conv of a layer (weights packed with

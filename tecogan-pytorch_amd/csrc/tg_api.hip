@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace tg
 
-extern "C" int tg_version(void) { return TG_ABI_MAJOR * 100 + 0; }
+extern "C" int tg_version(void) { return TG_ABI_MAJOR * 100 + 1; }
 extern "C" const char* tg_last_error_string(void) { return tg::g_err; }
 
 // ---------------------------------------------------------------------------

@@ -885,6 +885,17 @@ extern "C" int tg_conv3x3_fwd_phased(const float* x, int64_t x_nstride, const fl
                       taps_phase1);
 }
 
+extern "C" int tg_conv3x3_fwd_phased_masked(const float* x, int64_t x_nstride, const float* w_packed, int ocb,
+                                            const float* bias, const float* relu_mask, int64_t mask_nstride,
+                                            float* y, int64_t y_nstride, int n, int cin, int cout, int h,
+                                            int w, int act, int tapsel, int cphase, int taps_phase0,
+                                            int taps_phase1, tg_stream_t stream) {
+  TG_REQUIRE(tapsel == 1 || tapsel == 2, TG_E_ARG, "conv3x3_fwd_phased: tapsel=%d (1 input | 2 output phases)", tapsel);
+  return conv3x3_impl(x, x_nstride, cin, nullptr, 0, w_packed, ocb, bias, nullptr, 0, y, y_nstride, n, cin,
+                      cout, h, w, act, 1, nullptr, stream, relu_mask, mask_nstride, tapsel, cphase, taps_phase0,
+                      taps_phase1);
+}
+
 extern "C" int tg_conv3x3_fwd_masked(const float* x, int64_t x_nstride, int c1, const float* x2,
                                      int64_t x2_nstride, const float* w_packed, int ocb,
                                      const float* bias, const float* res, int64_t res_nstride,

@@ -282,6 +282,137 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// ---- ca <= 4: the weight gradient of an OUTPUT conv (conv_out 64 -> 3, tecogan_nets.py:131; flow[2]
+// 32 -> 2, :65).  On the MFMA kernel the 3 gradient channels are padded to a 64-row tile: 95 % of the
+// matrix work multiplies zeros, and on the HR frames of the unroll (19 x 2 x 256 x 256 pixels) that
+// was the single most expensive launch of the training step (1.75 ms).  Here: plain FMAs.
+//   block = 64 b-channels x 4 rows; tile = 4 rows x 32 columns of one image; the Q tile (64 x 6 x 34)
+//   sits in LDS with an odd channel stride (conflict-free across the 64 lanes of a wave), the P
+//   tile is read as LDS broadcasts; a thread walks its row with a sliding 3x3 window of Q and keeps
+//   ca x 9 sums in registers across ALL the tiles its block visits (persistent blocks), the 4 row
+//   groups meet in LDS at the end and the block writes ONE partial [ca][cb][9]; wgrad_reduce_kernel
+//   adds the blocks' partials in a fixed order.
+constexpr int SC_TW = 32, SC_TR = 4;
+constexpr int SC_QRS = SC_TW + 2;                   // 34
+constexpr int SC_QCS = (SC_TR + 2) * SC_QRS + 1;    // 205 (odd)
+struct WgradSmallArgs {
+  const float* pseg[WG_MAXSEG];
+  const float* qseg[WG_MAXSEG];
+  int n_per_seg;
+  float* part;           // [nblk][ca][cb_total][9]
+  long long p_ns, q_ns;
+  int ca, cb, cb_total, cb_off, n, h, w, tiles_x, tiles_y, ntiles, nblk, nbb;
+};
+__global__ __launch_bounds__(256) void wgrad3x3_smallca_kernel(WgradSmallArgs a) {
+  __shared__ float sQ[64 * SC_QCS];                 // 52.5 KB
+  __shared__ float sP[4 * SC_TR * SC_TW];
+  const int tid = threadIdx.x, bl = tid & 63, g = tid >> 6;
+  const int bb = blockIdx.x % a.nbb, blk = blockIdx.x / a.nbb;
+  const int b0 = bb * 64;
+  const int hw = a.h * a.w;
+  float acc[4][9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[i][t] = 0.f;
+  // staging through registers: ALL loads of a tile are issued before the first LDS store, and the
+  // loads of the block's NEXT tile are in flight while this one is being accumulated
+  constexpr int QN = 64 * (SC_TR + 2) * SC_QRS, QPT = (QN + 255) / 256;      // 51 per thread
+  constexpr int PN = 4 * SC_TR * SC_TW, PPT = PN / 256;                      // 2 per thread
+  float rqv[QPT], rpv[PPT];
+  auto issue = [&](int tile) {
+    const int n = tile / (a.tiles_x * a.tiles_y);
+    const int rem = tile - n * (a.tiles_x * a.tiles_y);
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int x0 = tx * SC_TW, y0 = ty * SC_TR;
+    const int seg = n / a.n_per_seg, ln = n - seg * a.n_per_seg;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.qseg[seg] + (long long)ln * a.q_ns), 0, a.cb * hw * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.pseg[seg] + (long long)ln * a.p_ns), 0, a.ca * hw * 4, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      const int i = tid + k * 256;
+      const int c = i % SC_QRS, r = (i / SC_QRS) % (SC_TR + 2), ch = i / (SC_QRS * (SC_TR + 2));
+      const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+      const bool ok = i < QN && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      const unsigned off = ok ? (unsigned)(((b0 + ch) * hw + gy * a.w + gx) * 4) : WG_OOB;
+      rqv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, (int)off, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int i = tid + k * 256;
+      const int c = i % SC_TW, r = (i / SC_TW) % SC_TR, ch = i / (SC_TW * SC_TR);
+      const int gy = y0 + r, gx = x0 + c;
+      const bool ok = gy < a.h && gx < a.w;          // channels >= ca are past num_records: 0
+      const unsigned off = ok ? (unsigned)((ch * hw + gy * a.w + gx) * 4) : WG_OOB;
+      rpv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp, (int)off, 0, 0));
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      const int i = tid + k * 256;
+      const int c = i % SC_QRS, r = (i / SC_QRS) % (SC_TR + 2), ch = i / (SC_QRS * (SC_TR + 2));
+      if (i < QN) sQ[ch * SC_QCS + r * SC_QRS + c] = rqv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) sP[tid + k * 256] = rpv[k];
+  };
+  if (blk < a.ntiles) issue(blk);
+  for (int tile = blk; tile < a.ntiles; tile += a.nblk) {
+    __syncthreads();                                 // the previous tile's reads are done
+    commit();
+    __syncthreads();
+    if (tile + a.nblk < a.ntiles) issue(tile + a.nblk);
+    const float* q = sQ + bl * SC_QCS + g * SC_QRS;  // window rows g, g+1, g+2 of the tile (image rows y-1, y, y+1)
+    float w0[3], w1[3], w2[3];                        // columns x-1, x, x+1
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { w0[k] = q[k * SC_QRS]; w1[k] = q[k * SC_QRS + 1]; }
+#pragma unroll 4
+    for (int x = 0; x < SC_TW; ++x) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w2[k] = q[k * SC_QRS + x + 2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float p = sP[(i * SC_TR + g) * SC_TW + x];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          acc[i][k * 3 + 0] = __builtin_fmaf(p, w0[k], acc[i][k * 3 + 0]);
+          acc[i][k * 3 + 1] = __builtin_fmaf(p, w1[k], acc[i][k * 3 + 1]);
+          acc[i][k * 3 + 2] = __builtin_fmaf(p, w2[k], acc[i][k * 3 + 2]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { w0[k] = w1[k]; w1[k] = w2[k]; }
+    }
+  }
+  // the 4 row groups -> group 0 (fixed order), then the block's partial
+  __syncthreads();
+  float* red = sQ;                                    // [3][64][36]
+  if (g > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) red[((g - 1) * 64 + bl) * 36 + i * 9 + t] = acc[i][t];
+  }
+  __syncthreads();
+  if (g == 0 && b0 + bl < a.cb) {
+    float* out = a.part + (long long)blk * a.ca * a.cb_total * 9;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i >= a.ca) break;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        float v = acc[i][t];
+#pragma unroll
+        for (int gg = 0; gg < 3; ++gg) v += red[(gg * 64 + bl) * 36 + i * 9 + t];
+        out[((long long)i * a.cb_total + a.cb_off + b0 + bl) * 9 + t] = v;
+      }
+    }
+  }
+}
+
 // the same reduction for every layer of a layered launch: blockIdx.y = layer
 struct WgradLayerGrads { float* g[24]; };
 __global__ __launch_bounds__(256) void wgrad_reduce_layers_kernel(const float* __restrict__ part, WgradLayerGrads gl,
@@ -315,7 +446,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_layers_kernel(const float* _
 
 using namespace tg;
 
+constexpr int SC_MAXBLK = 768;      // persistent blocks of the small-ca kernel (3 per CU)
 static int wgrad_nsplit(int n, int h, int w, int ca, int cb) {
+  if (ca <= 4) {
+    const int nt = n * cdiv(h, SC_TR) * cdiv(w, SC_TW), per_b = SC_MAXBLK / cdiv(cb, 64);
+    return nt < per_b ? nt : (per_b > 0 ? per_b : 1);
+  }
   int ntiles = n * cdiv(h, WG_R) * cdiv(w, WG_TW);
   int blocks_ch = cdiv(ca, 64) * cdiv(cb, 64);
   int s = 512 / blocks_ch;
@@ -343,6 +479,27 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
              cb_total, h, w);
   TG_REQUIRE((long long)(ca > cb ? ca : cb) * h * w * 4 < (1ll << 31), TG_E_SHAPE,
              "wgrad3x3: one batch item must be < 2 GiB");
+  if (ca <= 4 && !cphase) {
+    WgradSmallArgs sa{};
+    for (int i = 0; i < nseg; ++i) {
+      TG_REQUIRE(p_list[i] && q_list[i], TG_E_ARG, "wgrad3x3: null segment %d", i);
+      sa.pseg[i] = p_list[i]; sa.qseg[i] = q_list[i];
+    }
+    const int n = nseg * n_per_seg;
+    sa.n_per_seg = n_per_seg; sa.part = workspace; sa.p_ns = p_nstride; sa.q_ns = q_nstride;
+    sa.ca = ca; sa.cb = cb; sa.cb_total = cb_total; sa.cb_off = cb_off; sa.n = n; sa.h = h; sa.w = w;
+    sa.tiles_x = cdiv(w, SC_TW); sa.tiles_y = cdiv(h, SC_TR); sa.ntiles = n * sa.tiles_x * sa.tiles_y;
+    sa.nbb = cdiv(cb, 64);
+    sa.nblk = wgrad_nsplit(n, h, w, ca, cb_total);        // = what the workspace was sized with (cb <= cb_total)
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad3x3_smallca_kernel, dim3((unsigned)(sa.nblk * sa.nbb)), dim3(256), 0, s, sa);
+    int rc = check_launch("wgrad3x3_smallca");
+    if (rc != TG_OK) return rc;
+    const long long total = (long long)ca * cb * 9;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, grad,
+                       sa.nblk, ca, cb, cb_total, cb_off, accumulate);
+    return check_launch("wgrad_reduce");
+  }
   WgradArgs a{};
   for (int i = 0; i < nseg; ++i) {
     TG_REQUIRE(p_list[i] && q_list[i], TG_E_ARG, "wgrad3x3: null segment %d", i);

@@ -26,13 +26,22 @@ class Tape:
         self.deferred = {}
         self.deferred_bias = {}
         self.deferred_body = {}  # chained SRNet bodies: per network, the (acts, dz, g_out) blocks of every swept frame
+        # ReLU-backward fused into the producer of a gradient: a ReLU layer registers its output in
+        # `relu_outputs`; a node that delivers the gradient w.r.t. such a tensor may apply the mask in
+        # its own epilogue and say so (add_grad(..., masked=True)); the ReLU layer then skips its
+        # act_bwd pass unless some other contribution arrived unmasked.
+        self.relu_outputs = set()
+        self.unmasked = set()
         self.side = None        # side stream of the asynchronous weight-gradient flushes
         self._inflight = []     # tensors the side stream still reads (kept alive until the join)
 
     # -- gradient bookkeeping -------------------------------------------------
-    def add_grad(self, t, g):
-        """Accumulate g into the gradient of t.  Takes ownership of g."""
+    def add_grad(self, t, g, masked=False):
+        """Accumulate g into the gradient of t.  Takes ownership of g.  masked: g already carries
+        the ReLU-backward mask of t (t is in relu_outputs)."""
         k = id(t)
+        if not masked:
+            self.unmasked.add(k)
         cur = self.grads.get(k)
         if cur is None:
             self.grads[k] = g
@@ -420,7 +429,9 @@ def conv3x3_small(tape, layer, x, act=NONE, up_src=None, up_mode=ops.UP_NONE, up
             tape.defer_bias(_grad_buf(b), dz)
         pkd = _CACHE.get(layer, ('dg', 0), _ver(w),
                          lambda: ops.pack_conv3x3_dgrad(w.detach().contiguous()))
-        tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, cin, pkd[3], ksplit=1))
+        fuse = id(x) in tape.relu_outputs        # x = relu(...): deliver dZ of that layer directly
+        tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, cin, pkd[3], ksplit=1,
+                                     relu_mask=x if fuse else None), masked=fuse)
     tape.record(bwd)
     return y
 
@@ -478,18 +489,24 @@ def convt3x3s2(tape, layer, x, act=RELU):
     y = ops.convt3x3s2(x, pk, b, co, act)
     if tape is None:
         return y
+    if act == RELU:
+        tape.relu_outputs.add(id(y))
 
     def bwd():
         g = tape.pop_grad(y)
         if g is None:
             return
-        dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
+        premasked = act == RELU and id(y) not in tape.unmasked       # every contribution came masked
+        dz = ops.act_bwd(g, y, act, out=g) if (act != NONE and not premasked) else g
         s = ops.space_to_depth(dz, 2)                              # (n, 4co, h, w)
         we = _CACHE.get(layer, ('cte',), _ver(w), lambda: ops.pack_conv3x3(_convt_embed(w.detach())))
+        fuse = id(x) in tape.relu_outputs
         if co % 8 == 0:      # phase py = 1 owns tap rows {0, 1}, py = 0 only {1}: 9 of 36 taps are non-zero
-            tape.add_grad(x, ops.conv3x3_phased(s, we[0], 4 * co, ci, we[3], 1, co, ops.TAPS_1, ops.TAPS_01))
+            tape.add_grad(x, ops.conv3x3_phased(s, we[0], 4 * co, ci, we[3], 1, co, ops.TAPS_1, ops.TAPS_01,
+                                                relu_mask=x if fuse else None), masked=fuse)
         else:
-            tape.add_grad(x, ops.conv3x3(s, we[0], None, 4 * co, ci, we[3], ksplit=1))
+            tape.add_grad(x, ops.conv3x3(s, we[0], None, 4 * co, ci, we[3], ksplit=1,
+                                         relu_mask=x if fuse else None), masked=fuse)
         if w.requires_grad:
             def post(ge):                                          # G[ci][(ph,co)][ty][tx]
                 _, inv = _embed_index('convt', ci, co, ge.device)

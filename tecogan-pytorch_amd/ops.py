@@ -122,7 +122,7 @@ def conv3x3(x, wpk, bias, cin, cout, ocb, act=ACT_NONE, x2=None, res=None, out=N
 TAPS_ALL, TAPS_01, TAPS_12, TAPS_1 = 0, 1, 2, 3
 
 
-def conv3x3_phased(x, wpk, cin, cout, ocb, tapsel, cphase, taps_phase0, taps_phase1, out=None):
+def conv3x3_phased(x, wpk, cin, cout, ocb, tapsel, cphase, taps_phase0, taps_phase1, out=None, relu_mask=None):
     """conv3x3 (no bias / activation) of a space-to-depth embedded strided conv, skipping the
     taps a sub-pixel phase does not own (include/tecogan_hip.h: tg_conv3x3_fwd_phased)."""
     _chk(x, 'x')
@@ -131,10 +131,15 @@ def conv3x3_phased(x, wpk, cin, cout, ocb, tapsel, cphase, taps_phase0, taps_pha
         raise L.TecoganHipError(f'conv3x3_phased: x has {c1} channels, weights expect {cin}')
     if out is None:
         out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
-    L.check(L.lib().tg_conv3x3_fwd_phased(x.data_ptr(), cin * h * w, wpk.data_ptr(), ocb, None,
-                                          out.data_ptr(), cout * h * w, n, cin, cout, h, w, ACT_NONE,
-                                          int(tapsel), int(cphase), int(taps_phase0), int(taps_phase1),
-                                          _stream()), 'tg_conv3x3_fwd_phased')
+    if relu_mask is not None:
+        _chk(relu_mask, 'relu_mask')
+        if relu_mask.shape != out.shape:
+            raise L.TecoganHipError('conv3x3_phased: relu_mask shape mismatch')
+    L.check(L.lib().tg_conv3x3_fwd_phased_masked(x.data_ptr(), cin * h * w, wpk.data_ptr(), ocb, None,
+                                                 _ptr(relu_mask), cout * h * w, out.data_ptr(), cout * h * w,
+                                                 n, cin, cout, h, w, ACT_NONE, int(tapsel), int(cphase),
+                                                 int(taps_phase0), int(taps_phase1), _stream()),
+            'tg_conv3x3_fwd_phased_masked')
     return out
 
 
