@@ -293,6 +293,60 @@ def warp_batched_roofline(dev, h, w, scale, deg, clips=8, reps=48):
                     'events; same kernel as roofline_warp' % nsets}
 
 
+def config5_leg(dev, gen, frames):
+    """BASELINE configs[4]: TecoGAN 2x BI generator-only inference of a 3x268x640 LR clip (same HR
+    size as the headline): clip rate (median of 3 clips) and the dominant conv class -- SRNet's 21
+    full-resolution layers as ONE chained Winograd launch -- against the fp32-MFMA peak and against
+    the Winograd form's own ceiling."""
+    from tecogan_pytorch_amd.models.networks import FRNet
+    from tecogan_pytorch_amd import _lib as L
+    c, h, w, s = 3, 268, 640, 2
+    torch.manual_seed(0)
+    net = FRNet(c, c, 64, 10, 'BI', s).to(dev).eval()
+    clip = torch.rand(frames, c, h, w, generator=gen).to(dev)
+    with torch.no_grad():
+        for _ in range(2):
+            net.infer_sequence(clip, dev, return_device_tensor=True)
+            torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            net.infer_sequence(clip, dev, return_device_tensor=True)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        net.check_faults()
+        plan = net._get_plan(1, h, w, dev)
+        bufs = (torch.rand(1, c, h, w, generator=gen).to(dev), torch.rand(1, c, h, w, generator=gen).to(dev),
+                torch.rand(1, c, s * h, s * w, generator=gen).to(dev), torch.empty(1, c, s * h, s * w, device=dev))
+        rows = kernel_table(net, plan, bufs, reps=10)
+        net.check_faults()
+    gf, _ = net.profile((c, h, w))
+    out = {'workload': f'TecoGAN 2xSR BI generator-only inference, synthetic {frames}-frame 3x268x640 LR clip -> '
+                       f'3x536x1280 uint8 (BASELINE configs[4])',
+           'value': frames / sorted(ts)[1], 'unit': 'frames/s', 'ms_per_step': 1e3 * sorted(ts)[1] / frames,
+           'steps': frames, 'algorithmic_gflop_per_frame': gf['FNet'] + gf['SRNet'],
+           'launches_per_frame': L.lib().tg_frnet_plan_launches(plan.handle)}
+    mf = [r for r in rows if r['kernel'].startswith(('conv3x3_mfma', 'conv3x3_wino'))]
+    if mf:
+        dom = max(mf, key=lambda r: r['ms_per_frame'])
+        ach = dom['tflops']
+        wino = dom['kernel'].startswith('conv3x3_wino')
+        out['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS,
+                           'unit': 'TFLOP/s', 'launches_per_frame': dom['launches'],
+                           'avg_launch_us': 1e3 * dom['ms_per_frame'] / dom['launches'],
+                           'algorithmic_gflop_per_launch': dom['gflop'] / dom['launches'],
+                           'traffic': pmc_traffic(dom['kernel'])}
+        if wino:     # algorithmic FLOPs may exceed the pipe's peak in this form: the statement about the
+            #          matrix pipe is the executed fraction, the one about the form its own ceiling
+            out['roofline']['frac_vs_winograd_ceiling'] = ach / (MFMA_F32_PEAK_TFLOPS * 2.25)
+            out['roofline']['frac'] = ach * 16.0 / 36.0 / MFMA_F32_PEAK_TFLOPS
+            out['roofline']['frac_is'] = ('executed MFMA FLOPs (16/36 of the algorithmic ones) / peak; the '
+                                          'algorithmic rate `achieved` may exceed `peak` in the Winograd form')
+        else:
+            out['roofline']['frac'] = ach / MFMA_F32_PEAK_TFLOPS
+    return out
+
+
 def _barrier(dist, local_rank):
     if dist.get_backend() == 'nccl':
         dist.barrier(device_ids=[local_rank])
@@ -335,10 +389,14 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
     def run(crop, steps, warm=3):
         torch.manual_seed(0 + rank)                       # base_utils.py:46
         m = define_model(opt_for(crop))                   # broadcasts rank 0's weights under DDP
+        if dist_on and world > 1:
+            m.exchange_timing = {}                        # events around the waits for both gradient exchanges
         gen = torch.Generator().manual_seed(1 + rank)
         data = [{'gt': torch.rand(2, 10, 3, crop + 8, crop + 8, generator=gen).to(dev)} for _ in range(2)]
         for i in range(warm):
             m.prepare_training_data(data[i % 2]); m.train()
+        if getattr(m, 'exchange_timing', None) is not None:
+            m.exchange_timing.clear()
         if dist_on:
             _barrier(dist, local_rank)
         torch.cuda.synchronize()
@@ -357,6 +415,24 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
 
     out = {}
     m, dt, nupd = run(128, args.train_steps)
+    if dist_on:
+        # readiness checks of the first real multi-GPU run: every rank must see the world the driver asked for
+        seen = dist.get_world_size()
+        assert seen == world == args.gpus or os.environ.get('TG_BENCH_REHEARSAL') == '1' and seen == world, \
+            f'rank {rank}: process group of {seen} ranks, --gpus {args.gpus}, WORLD_SIZE {world}'
+        out['process_group'] = {'world_seen_by_rank0': seen, 'backend': dist.get_backend(),
+                                'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version())
+                                if dist.get_backend() == 'nccl' else None,
+                                'transport': os.environ.get('TECOGAN_COMM', 'torch.distributed')}
+        et = getattr(m, 'exchange_timing', None)
+        if et:
+            torch.cuda.synchronize()
+            out['exchange_wait_ms_per_step'] = {
+                k: sum(a.elapsed_time(b) for a, b in v) / max(1, len(v)) for k, v in et.items()}
+            out['exchange_wait_note'] = ('time the COMPUTE stream stalled for a gradient exchange (events around the '
+                                         'wait + mean kernel): D\'s all-reduce is launched before the D-independent '
+                                         'generator losses and should be ~0 when it hides under them; G\'s is '
+                                         'blocking by construction (nothing is left to overlap it with)')
     out.update({
         'workload': 'BASELINE configs[3]: TecoGAN 4xSR BD GAN training step, per-GPU batch 2 x 10 -> 19 '
                     'frames, crop 128 (REDS yml shape), synthetic U[0,1) GT, random-init weights, fp32; '
@@ -536,6 +612,19 @@ def main():
             net.check_faults()
             sec['fps_4_clips_pipelined'] = nb * args.steps / sorted(ts)[1]
             del clips4
+            for kc in (2, 8):                    # the other serving points DESIGN.md quotes
+                ck = torch.rand(kc, args.steps, c, h, w, generator=gen).to(dev)
+                net.infer_sequence(ck, dev, return_device_tensor=True)
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    net.infer_sequence(ck, dev, return_device_tensor=True)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t1)
+                net.check_faults()
+                sec[f'fps_{kc}_clips_pipelined'] = kc * args.steps / sorted(ts)[1]
+                del ck
             # reference protocol: synchronise after every frame (main.py:257-259)
             tsync = 0.0
             nsync = min(args.steps, 30)
@@ -546,6 +635,14 @@ def main():
                 tsync += time.perf_counter() - t1
             sec['fps_step_protocol_sync_every_frame'] = nsync / tsync
 
+    # ---- BASELINE configs[4]: 2x BI at 3x268x640 (the other up-sampler, warp stride 2, and the shape
+    # whose SRNet runs as ONE chained Winograd launch), under the same clock as the headline ------
+    cfg5 = None
+    if rank == 0 and not args.no_secondary and (s, deg, (c, h, w)) == (4, 'BD', (3, 134, 320)):
+        try:
+            cfg5 = config5_leg(dev, gen, min(args.steps, 60))
+        except Exception as e:          # a context leg: never lose the headline line to it
+            cfg5 = {'error': repr(e)[:300]}
     if dist_on:
         t = torch.tensor(times, device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)     # per region: the slowest rank
@@ -590,6 +687,8 @@ def main():
         result.update(sec)
         if train_leg is not None:
             result['train_ddp'] = train_leg
+        if cfg5 is not None:
+            result['config5_2xBI'] = cfg5
         if not args.no_roofline:
             with torch.no_grad():
                 rows = kernel_table(net, plan, (*pool[0], outs[0]))
@@ -615,6 +714,8 @@ def main():
                                               'multiplies are executed')
                 result['roofline']['mfma_executed_tflops'] = ach * 16.0 / 36.0
                 result['roofline']['mfma_executed_frac'] = ach * 16.0 / 36.0 / MFMA_F32_PEAK_TFLOPS
+                # against the form's own ceiling (every MFMA issue slot busy = 157.3 x 36/16 algorithmic)
+                result['roofline']['frac_vs_winograd_ceiling'] = ach / (MFMA_F32_PEAK_TFLOPS * 2.25)
             warp = [r for r in rows if r['kernel'].startswith('flowup_warp')]
             if warp:
                 wk = warp[0]

@@ -215,14 +215,26 @@ class BaseModel:
                 [p.grad for p in net.parameters() if p.requires_grad and p.grad is not None])
         return bucket.start()
 
-    def finish_grad_exchange(self, bucket):
+    def finish_grad_exchange(self, bucket, tag=None):
+        """Order the compute stream after the collective and turn the sum into the mean.  When
+        `self.exchange_timing` is a dict (bench.py --gpus N sets it), two events bracket the wait on
+        the COMPUTE stream: their distance is how long the step actually stalled for the exchange
+        (0 when the collective finished under the work that was enqueued in between)."""
         if bucket is None:
             return
+        timing = getattr(self, 'exchange_timing', None)
+        ev = None
+        if timing is not None and tag is not None and torch.cuda.is_available():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
 
         def mean(dst, src, world):                # dst = (src or dst) / world, IEEE division as DDP's
             ops.div_scalar_(dst.view(-1), world, None if src is None else src.contiguous())
         bucket.finish(scale_fn=mean)
+        if ev is not None:
+            ev[1].record()
+            timing.setdefault(tag, []).append(ev)
 
-    def allreduce_grads(self, net):
+    def allreduce_grads(self, net, tag=None):
         """Blocking form (reference: DDP's backward hook, base_model.py:130-136)."""
-        self.finish_grad_exchange(self.start_grad_exchange(net))
+        self.finish_grad_exchange(self.start_grad_exchange(net), tag)

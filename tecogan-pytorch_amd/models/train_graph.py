@@ -360,7 +360,10 @@ def srnet_body(tape, srnet, lr, tran):
     fw = (L.PackedLayer * nl)()
     keep = []
     for i, m in enumerate(layers):
-        pk, _ = m.packed()
+        pk, ocb = m.packed()
+        if ocb != 64:         # the chained kernel reads the 64-channel-block layout whatever cout is
+            pk = _CACHE.get(m, ('fw64',), _ver(m.weight),
+                            lambda m=m: ops.pack_conv3x3(m.weight.detach().contiguous(), ocb=64)[0])
         keep.append(pk)
         fw[i].w, fw[i].b = pk.data_ptr(), m.bias.data_ptr()
     acts = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=lr.device)
@@ -380,13 +383,16 @@ def srnet_body(tape, srnet, lr, tran):
         dg = (L.PackedLayer * nl)()
         hold = []
         w_in = conv_in.weight
-        pk0 = _CACHE.get(conv_in, ('dg', 1), _ver(w_in), lambda: ops.pack_conv3x3_dgrad(
-            w_in.detach()[:, c_lr:].contiguous()))
+        # (ocb = 64 explicitly: pack_conv3x3_dgrad would pick the 32-channel layout for c_tran <= 32,
+        #  e.g. the 12 warped-frame channels of a 2x model)
+        pk0 = _CACHE.get(conv_in, ('dg64', 1), _ver(w_in), lambda: ops.pack_conv3x3_dgrad(
+            w_in.detach()[:, c_lr:].contiguous(), ocb=64))
         hold.append(pk0)
         dg[0].w = pk0[0].data_ptr()
         for i, m in enumerate(layers[1:], 1):
             wm = m.weight
-            pk = _CACHE.get(m, ('dg', 0), _ver(wm), lambda wm=wm: ops.pack_conv3x3_dgrad(wm.detach().contiguous()))
+            pk = _CACHE.get(m, ('dg64', 0), _ver(wm),
+                            lambda wm=wm: ops.pack_conv3x3_dgrad(wm.detach().contiguous(), ocb=64))
             hold.append(pk)
             dg[i].w = pk[0].data_ptr()
         dz = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=g.device)

@@ -57,7 +57,7 @@ class VSRModel(BaseModel):
             tape.add_grad(lr_warp, self._crit(self.warp_crit, lr_warp, out['lr_curr'], warp_w,
                                               losses[1:2]))
         tape.backward()
-        self.allreduce_grads(self.net_G)
+        self.allreduce_grads(self.net_G, 'G')
         self.optim_G.step()
         vals = losses.tolist()                       # the iteration's only host sync
         TG.chain_check()        # fail-safe of the chained launches (a host read of a pinned counter)

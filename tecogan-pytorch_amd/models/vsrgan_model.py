@@ -164,7 +164,7 @@ class VSRGANModel(VSRModel):
         # D's update lands here: the third D pass sees the UPDATED, frozen critic
         # (:201-202 after :188)
         if upd_D:
-            self.finish_grad_exchange(bucket_D)
+            self.finish_grad_exchange(bucket_D, 'D')
             self.optim_D.step()
         for p in self.net_D.parameters():
             p.requires_grad = False
@@ -182,7 +182,7 @@ class VSRGANModel(VSRModel):
         tape_G.add_grad(fake_pred_G, ops.bce_logits(fake_pred_G, 1.0, st_g, 1.0 / n_clip,
                                                     grad_scale=gan_w * gsc))
         tape_G.backward()
-        self.allreduce_grads(self.net_G)
+        self.allreduce_grads(self.net_G, 'G')
         self.optim_G.step()
 
         # === logging: one host read of all scalars ===

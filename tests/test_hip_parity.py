@@ -256,6 +256,52 @@ def test_winograd_chained_launch_equals_separate_launches(ops, n, h, w):
     assert chain.bailouts() == 0
 
 
+def test_winograd_chain_numerics_at_trained_activation_scale(ops):
+    """SRNet's 20 residual-block layers at the activation magnitudes of a TRAINED model (|x| grows
+    from ~10^2 to ~10^3 along the residual chain; the procedural parity weights stay O(1)): the
+    Winograd form -- layer by layer and as the chained launch -- must be as close to an fp64 chain
+    as the direct fp32-MFMA form is (the transforms only add, but they add BEFORE the products)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    nf, nb, h, w = 64, 10, 66, 80
+    x = 100.0 * torch.rand(1, nf, h, w, generator=g)
+    ws = [torch.randn(nf, nf, 3, 3, generator=g) * (2.0 / (nf * 9)) ** 0.5 for _ in range(2 * nb)]
+    a = x.double()
+    for b in range(nb):
+        a = a + F.conv2d(torch.relu(F.conv2d(a, ws[2 * b].double(), padding=1)), ws[2 * b + 1].double(), padding=1)
+    ref = a
+    assert 50 < ref.abs().mean() and 500 < ref.abs().max() < 1e5, (ref.abs().mean(), ref.abs().max())
+    wd = [dev(t) for t in ws]
+    us = [ops.pack_conv3x3_wino(t) for t in wd]
+    pk = [ops.pack_conv3x3(t) for t in wd]
+
+    def run(conv):
+        A = dev(x).clone()
+        for b in range(nb):
+            B = conv(A, 2 * b, 1, None)
+            A = conv(B, 2 * b + 1, 0, A)
+        return A
+    direct = run(lambda t, i, act, res: ops.conv3x3(t, pk[i][0], None, nf, nf, pk[i][3], act, res=res, ksplit=1))
+    wino = run(lambda t, i, act, res: ops.conv3x3_wino(t, us[i], None, nf, nf, act, res=res))
+    A, B = dev(x).clone(), torch.empty(1, nf, h, w, device='cuda')
+    layers = []
+    for b in range(nb):
+        layers.append(dict(x=A, u=us[2 * b], cin=nf, act=1, y=B))
+        layers.append(dict(x=B, u=us[2 * b + 1], cin=nf, act=0, res=A, y=A))
+    chain = ops.WinoChain(layers, 1, nf, h, w)
+    chain.run()
+    torch.cuda.synchronize()
+    assert chain.bailouts() == 0
+    e = {k: (v.double().cpu() - ref).abs() for k, v in (('direct', direct), ('wino', wino), ('chain', A))}
+    scale = ref.abs().max().item()
+    for k in e:
+        assert e[k].max().item() <= 2e-6 * scale, (k, e[k].max().item(), scale)      # fp32 through 20 layers
+    assert torch.equal(wino, A)                                   # chained launch == separate launches
+    # no worse than the direct form (max and mean error, 25 % slack for run-to-run tile-order noise)
+    assert e['wino'].max() <= 1.25 * e['direct'].max() + 1e-7 * scale, (e['wino'].max(), e['direct'].max())
+    assert e['wino'].mean() <= 1.25 * e['direct'].mean() + 1e-8 * scale, (e['wino'].mean(), e['direct'].mean())
+
+
 def test_plan_with_chained_srnet_launch(tmp_path):
     """The frame plan with SRNet as one chained launch (TG_WINO_CHAIN=1) against the plan with one launch
     per layer: same kernels, so the frames must be bit-identical.  (The switches are read once per

@@ -412,11 +412,11 @@ def test_index_gather_applies_the_embedding_tables(ops):
 # SRNet's conv_in + residual blocks of a training frame as ONE chained launch
 # (tg_srnet_body_fwd / _bwd) against the per-layer tape nodes.
 # ---------------------------------------------------------------------------
-def _srnet(nb=3, scale=4, seed=5):
+def _srnet(nb=3, scale=4, seed=5, nf=64):
     from tecogan_pytorch_amd.models.networks.tecogan_nets import SRNet
     from tecogan_pytorch_amd.utils.net_utils import get_upsampling_func
     torch.manual_seed(seed)
-    net = SRNet(3, 3, 64, nb, get_upsampling_func(scale, 'BD'), scale).cuda()
+    net = SRNet(3, 3, nf, nb, get_upsampling_func(scale, 'BD'), scale).cuda()
     for p in net.parameters():                       # O(1) activations through the residual chain
         if p.dim() == 4:
             p.data.mul_(1.5)
@@ -446,13 +446,17 @@ def _body_both_ways(net, lr, tran, g_out):
     return res
 
 
-@pytest.mark.parametrize('n,h,w,nb', [(2, 32, 32, 10), (2, 64, 64, 3), (1, 20, 37, 2), (3, 9, 70, 1)])
-def test_srnet_body_chain_equals_layer_launches(ops, n, h, w, nb):
+@pytest.mark.parametrize('n,h,w,nb,scale,nf', [(2, 32, 32, 10, 4, 64), (2, 64, 64, 3, 4, 64), (1, 20, 37, 2, 4, 64),
+                                               (3, 9, 70, 1, 4, 64), (2, 16, 16, 2, 2, 64), (2, 24, 40, 2, 2, 32)])
+def test_srnet_body_chain_equals_layer_launches(ops, n, h, w, nb, scale, nf):
+    """(scale 2: 12 warped-frame channels -- the data-gradient pack of conv_in would default to the
+    32-channel-block layout; nf = 32: so would every forward pack.)"""
     from tecogan_pytorch_amd import _lib as L
     parts = L.lib().tg_conv3x3_chain_supported(n, h, w, 64)
     assert parts in (1, 2)
-    net = _srnet(nb)
-    lr, tran, g = dev(rs(1, (n, 3, h, w), 0, 1)), dev(rs(2, (n, 48, h, w), 0, 1)), dev(rs(3, (n, 64, h, w)))
+    net = _srnet(nb, scale=scale, nf=nf)
+    ct = 3 * scale * scale
+    lr, tran, g = dev(rs(1, (n, 3, h, w), 0, 1)), dev(rs(2, (n, ct, h, w), 0, 1)), dev(rs(3, (n, nf, h, w)))
     (o1, t1, g1), (o2, t2, g2) = _body_both_ways(net, lr, tran, g)
     # same MFMA order and the same fixed-order K reduction as the one-shot kernel when a workgroup
     # owns all 64 channels of a tile; the 32-channel form reduces 8 single-chunk groups instead of
