@@ -280,6 +280,31 @@ __global__ void depth_to_space_kernel(const float* __restrict__ x, float* __rest
   }
 }
 
+// vector form (S in {2, 4}, output rows of 4 S pixels, 16-byte aligned): S 16-byte loads (one from
+// each sub-pixel plane) -> 4 S consecutive output pixels as S 16-byte stores
+template <int S>
+__global__ __launch_bounds__(256) void depth_to_space_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                int n, int c, int h, int w) {
+  const int oh = h * S, ow = w * S, groups = w / 4;
+  const long long total = (long long)n * c * oh * groups;
+  TG_GRID_STRIDE(i, total) {
+    const int gq = (int)(i % groups); long long t = i / groups;
+    const int oy = (int)(t % oh); t /= oh;
+    const int ch = (int)(t % c); const int b = (int)(t / c);
+    const int iy = oy / S, sy = oy - iy * S;
+    float v[4 * S];
+#pragma unroll
+    for (int sx = 0; sx < S; ++sx) {
+      const f32x4 q = *reinterpret_cast<const f32x4*>(
+          x + (((long long)b * S * S * c + (sy * S + sx) * c + ch) * h + iy) * w + gq * 4);
+      v[sx] = q[0]; v[S + sx] = q[1]; v[2 * S + sx] = q[2]; v[3 * S + sx] = q[3];
+    }
+    f32x4* dst = reinterpret_cast<f32x4*>(y + (((long long)b * c + ch) * oh + oy) * ow + (long long)gq * 4 * S);
+#pragma unroll
+    for (int k = 0; k < S; ++k) dst[k] = f32x4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+  }
+}
+
 // Charbonnier: loss += scale * sum sqrt(d^2+eps); dx = gscale * d / sqrt(d^2+eps)
 __global__ __launch_bounds__(256) void charbonnier_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ y,
@@ -644,6 +669,14 @@ extern "C" int tg_depth_to_space(const float* x, float* y, int n, int c, int h, 
                                  tg_stream_t stream) {
   TG_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0 && scale >= 1, TG_E_ARG, "depth_to_space");
   long long total = (long long)n * c * h * scale * w * scale;
+  if ((scale == 2 || scale == 4) && w % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    const long long items = (long long)n * c * h * scale * (w / 4);
+    if (scale == 2)
+      hipLaunchKernelGGL(depth_to_space_vec_kernel<2>, dim3(grid_for(items, 8192)), dim3(256), 0, ST, x, y, n, c, h, w);
+    else
+      hipLaunchKernelGGL(depth_to_space_vec_kernel<4>, dim3(grid_for(items, 8192)), dim3(256), 0, ST, x, y, n, c, h, w);
+    return check_launch("depth_to_space");
+  }
   hipLaunchKernelGGL(depth_to_space_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, ST, x, y, n, c,
                      h, w, scale);
   return check_launch("depth_to_space");

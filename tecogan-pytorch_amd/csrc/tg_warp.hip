@@ -366,6 +366,37 @@ __global__ void space_to_depth_kernel(const float* __restrict__ x, float* __rest
   }
 }
 
+// Vector form for S in {2, 4}, w % (4 S) == 0 and 16-byte aligned rows: a thread reads 4 S
+// consecutive pixels of one input row (S 16-byte loads) and writes one 16-byte vector into each
+// of the S sub-pixel planes of that row -- every byte moves once in full sectors (the scalar
+// form above reads with stride S: 67 MB of an HR training frame took 215 us, this takes ~15).
+template <int S>
+__global__ __launch_bounds__(256) void space_to_depth_vec_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                long long y_ns, int n, int c, int h, int w) {
+  const int oh = h / S, ow = w / S, groups = w / (4 * S);
+  const long long total = (long long)n * c * h * groups;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int gq = (int)(i % groups); long long t = i / groups;
+    const int iy = (int)(t % h); t /= h;
+    const int ch = (int)(t % c); const int b = (int)(t / c);
+    const int oy = iy / S, sy = iy - oy * S;
+    const f32x4* src = reinterpret_cast<const f32x4*>(x + (((long long)b * c + ch) * h + iy) * w + (long long)gq * 4 * S);
+    float v[4 * S];
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+      const f32x4 q = src[k];
+      v[4 * k] = q[0]; v[4 * k + 1] = q[1]; v[4 * k + 2] = q[2]; v[4 * k + 3] = q[3];
+    }
+#pragma unroll
+    for (int sx = 0; sx < S; ++sx) {
+      const f32x4 o = {v[sx], v[S + sx], v[2 * S + sx], v[3 * S + sx]};
+      float* dst = y + (long long)b * y_ns + ((long long)((sy * S + sx) * c + ch) * oh + oy) * ow + gq * 4;
+      *reinterpret_cast<f32x4*>(dst) = o;
+    }
+  }
+}
+
 __global__ void upsample_kernel(const float* __restrict__ x, float* __restrict__ y, int nc, int h,
                                 int w, int s, int mode, float mul) {
   const int oh = h * s, ow = w * s;
@@ -551,6 +582,18 @@ extern "C" int tg_space_to_depth(const float* x, float* y, int64_t y_nstride, in
   TG_REQUIRE(n > 0 && c > 0 && scale >= 1 && h >= scale && w >= scale, TG_E_SHAPE,
              "space_to_depth: n=%d c=%d h=%d w=%d s=%d", n, c, h, w, scale);
   long long total = (long long)n * scale * scale * c * (h / scale) * (w / scale);
+  const bool vec = (scale == 2 || scale == 4) && h % scale == 0 && w % (4 * scale) == 0 &&
+                   (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && y_nstride % 4 == 0;
+  if (vec) {
+    const long long items = (long long)n * c * h * (w / (4 * scale));
+    if (scale == 2)
+      hipLaunchKernelGGL(space_to_depth_vec_kernel<2>, dim3(grid1d(items)), dim3(256), 0, (hipStream_t)stream, x, y,
+                         (long long)y_nstride, n, c, h, w);
+    else
+      hipLaunchKernelGGL(space_to_depth_vec_kernel<4>, dim3(grid1d(items)), dim3(256), 0, (hipStream_t)stream, x, y,
+                         (long long)y_nstride, n, c, h, w);
+    return check_launch("space_to_depth");
+  }
   hipLaunchKernelGGL(space_to_depth_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream,
                      x, y, (long long)y_nstride, n, c, h, w, scale);
   return check_launch("space_to_depth");

@@ -573,3 +573,16 @@ def test_srnet_body_chain_fault_is_reported_and_falls_back(ops):
         "print('BODY-FAILSAFE-OK')\n" % root)
     r = subprocess.run([sys.executable, '-c', script], timeout=600, capture_output=True, text=True)
     assert r.returncode == 0 and 'BODY-FAILSAFE-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize('n,c,h,w,s', [(2, 5, 8, 16, 2), (1, 64, 12, 32, 4), (2, 3, 16, 48, 4), (1, 7, 6, 24, 2),
+                                       (1, 3, 8, 12, 2), (2, 4, 8, 20, 4)])
+def test_space_to_depth_vector_path_is_a_permutation(ops, n, c, h, w, s):
+    """The 16-byte vector forms of space_to_depth / depth_to_space (w % (4 s) == 0) and the scalar
+    forms (other widths) against the reference's view / permute chain (net_utils.py:36-47), bit for
+    bit, and as exact inverses of each other."""
+    x = rs(1, (n, c, h, w))
+    ref = x.view(n, c, h // s, s, w // s, s).permute(0, 3, 5, 1, 2, 4).reshape(n, s * s * c, h // s, w // s)
+    y = ops.space_to_depth(dev(x), s)
+    assert torch.equal(y.cpu(), ref)
+    assert torch.equal(ops.depth_to_space(y, s).cpu(), x)
