@@ -56,7 +56,14 @@ struct RowChainArgs {
   int* err;
   unsigned epoch;
   int poll_limit;
+  long long* dbg;       // lab builds (TG_LAB): 8 s_memtime stamps per (layer) of workgroup 0
 };
+#if TG_LAB
+#define RC_STAMP(k) do { if (a.dbg && blockIdx.x == RC_DBG_BLOCK && tid == 0) a.dbg[l * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define RC_DBG_BLOCK 37
+#else
+#define RC_STAMP(k) do { } while (0)
+#endif
 
 template <bool COH> __device__ __forceinline__ float rc_ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, COH ? RC_SC1 : 0));
@@ -65,12 +72,13 @@ template <bool COH> __device__ __forceinline__ float rc_ld(__amdgpu_buffer_rsrc_
 // KG = K groups per workgroup (8 waves): 4 -> 2 oc halves of 32 (one workgroup per tile),
 //                                        8 -> 1 oc half (two workgroups per tile).
 template <int KG>
-__global__ __launch_bounds__(512, 2) void conv3x3_rowchain_kernel(RowChainArgs a) {
+__global__ __launch_bounds__(512, 4) void conv3x3_rowchain_kernel(RowChainArgs a) {
   constexpr int NOH = 8 / KG;            // oc halves per workgroup
   constexpr int PARTS = 2 / NOH;         // workgroups per tile
   constexpr int CPW = 8 / KG;            // channel chunks per wave (<= 8 chunks = 64 input channels)
   constexpr int OUTS = NOH * 32 * RC_TW; // outputs of the workgroup's tile
   constexpr int PER = OUTS / 512;        // per thread: 2 or 4 consecutive pixels of one channel
+  constexpr int INFLIGHT = KG == 8 ? 4 : 2;   // patch items (16 bytes x 4 channel planes) in flight per thread (register budget)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_in = smem;                               // [8][RC_IN_FLOATS]
   float* red = smem + 8 * RC_IN_FLOATS;             // [KG][NOH * 32][32]
@@ -99,6 +107,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rowchain_kernel(RowChainArgs a
   for (int l = 0; l < a.nlayer; ++l) {
     const RCLayer& L = a.L[l];
     const int nchunk = (L.cin + CK - 1) / CK;
+    RC_STAMP(0);
     // ---- this wave's weights -> registers (before the wait: independent of the previous layer)
     const int c0 = wk * CPW;
     const f32x4* wlane = reinterpret_cast<const f32x4*>(L.wpk) + (lh * 64 + ochalf * 32 + ll);
@@ -113,6 +122,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rowchain_kernel(RowChainArgs a
         aw[ci][tap] = v;
       }
     }
+    // (the bias of this thread's output channel too: a global load in the epilogue would sit on the
+    //  layer's critical path)
+    const float bb = (L.bias && g_oc < L.cout) ? L.bias[g_oc] : 0.f;
     // ---- wait for the producers of the 3x3 tile neighbourhood of the previous layer
     if (l > 0) {
       if (tid < 9 * PARTS) {
@@ -131,6 +143,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rowchain_kernel(RowChainArgs a
       }
       __syncthreads();
     }
+    RC_STAMP(1);
     // ---- the input patch of every chunk -> LDS (layer 0 reads tensors of earlier launches:
     // ordinary loads; later layers read what other workgroups of THIS launch wrote: sc1)
     {
@@ -141,24 +154,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rowchain_kernel(RowChainArgs a
           const_cast<float*>(dual ? L.x2 + (long long)n * L.x2_ns : L.x), 0,
           dual ? (L.cin - L.c1) * hw * 4 : 0, 0x00020000);
       const int total = nchunk * RC_ITEMS;
+      // all the loads of a batch of items are issued before the first LDS store (a loop of
+      // load -> store iterations pays the memory latency once per iteration: 2.2 us per layer)
       auto stage = [&](auto coh) {
         constexpr bool COH = decltype(coh)::value;
-        for (int q = tid; q < total; q += 512) {
-          const int ch = q / RC_ITEMS, rem = q - ch * RC_ITEMS;
-          const int r = rem / (2 * RC_PW), rem2 = rem - r * (2 * RC_PW);
-          const int hf = rem2 / RC_PW, col = rem2 - hf * RC_PW;
-          const int gy = y0 - 1 + r, px = x0 - 1 + col;
-          const bool ok = gy >= 0 && gy < a.h && px >= 0 && px < a.w;
-          const unsigned base = ok ? (unsigned)(((ch * CK + 4 * hf) * hw + gy * a.w + px) * 4) : RC_OOB;
-          f32x4 v;
+        constexpr int MAXQ = (8 * RC_ITEMS + 511) / 512;       // 4 items per thread at 64 input channels
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const unsigned o1 = base + (unsigned)j * plane;
-            float t = rc_ld<COH>(rs1, o1);
-            if (dual) t += rc_ld<COH>(rs2, o1 - (unsigned)L.c1 * plane);
-            v[j] = t;
+        for (int k0 = 0; k0 < MAXQ; k0 += INFLIGHT) {
+          f32x4 v[INFLIGHT];
+#pragma unroll
+          for (int k = 0; k < INFLIGHT; ++k) {
+            const int q = tid + (k0 + k) * 512;
+            const int ch = q / RC_ITEMS, rem = q - ch * RC_ITEMS;
+            const int r = rem / (2 * RC_PW), rem2 = rem - r * (2 * RC_PW);
+            const int hf = rem2 / RC_PW, col = rem2 - hf * RC_PW;
+            const int gy = y0 - 1 + r, px = x0 - 1 + col;
+            const bool ok = q < total && gy >= 0 && gy < a.h && px >= 0 && px < a.w;
+            const unsigned base = ok ? (unsigned)(((ch * CK + 4 * hf) * hw + gy * a.w + px) * 4) : RC_OOB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned o1 = base + (unsigned)j * plane;
+              float t = rc_ld<COH>(rs1, o1);
+              if (dual) t += rc_ld<COH>(rs2, o1 - (unsigned)L.c1 * plane);
+              v[k][j] = t;
+            }
           }
-          *reinterpret_cast<f32x4*>(s_in + ch * RC_IN_FLOATS + ((r * 2 + hf) * RC_RS + col) * 4) = v;
+#pragma unroll
+          for (int k = 0; k < INFLIGHT; ++k) {
+            const int q = tid + (k0 + k) * 512;
+            const int ch = q / RC_ITEMS, rem = q - ch * RC_ITEMS;
+            const int r = rem / (2 * RC_PW), rem2 = rem - r * (2 * RC_PW);
+            const int hf = rem2 / RC_PW, col = rem2 - hf * RC_PW;
+            if (q < total)
+              *reinterpret_cast<f32x4*>(s_in + ch * RC_IN_FLOATS + ((r * 2 + hf) * RC_RS + col) * 4) = v[k];
+          }
         }
       };
       if (l > 0) stage(std::true_type{}); else stage(std::false_type{});
@@ -188,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rowchain_kernel(RowChainArgs a
         if (gx + e < a.w) mm[e] = mp[e];
     }
     __syncthreads();
+    RC_STAMP(2);
 
     // ---- MFMAs of this wave's K range
     f32x16 acc;
@@ -208,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rowchain_kernel(RowChainArgs a
         }
       }
     }
+    RC_STAMP(3);
     // ---- K groups meet in LDS: red[wk][oc local][px]
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -230,7 +261,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rowchain_kernel(RowChainArgs a
       }
       if (live) {
         const float slope = act_slope(L.act);
-        const float bb = L.bias ? L.bias[g_oc] : 0.f;
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
           float q = v[e] + bb;
@@ -260,8 +290,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rowchain_kernel(RowChainArgs a
       }
     }
     // ---- publish the tile: data acknowledged (this wave), then all waves, then the flag
+    RC_STAMP(4);
     __builtin_amdgcn_s_waitcnt(0);
+    RC_STAMP(5);
     __syncthreads();                     // also: every read of `red` / `s_in` of this layer is done
+    RC_STAMP(6);
     if (tid == 0)
       __hip_atomic_store(a.flags + ((size_t)l * a.ntile + tile) * PARTS + part, a.epoch, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
@@ -319,6 +352,11 @@ extern "C" int tg_conv3x3_chain(const tg_chain_layer* layers, int n_layers, int 
   const long long ntile = (long long)n * h * a.tiles_x;
   a.ntile = (int)ntile;
   a.flags = reinterpret_cast<unsigned*>(flags); a.err = err; a.epoch = epoch; a.poll_limit = poll_limit;
+#if TG_LAB
+  a.dbg = reinterpret_cast<long long*>(flags + tg_conv3x3_chain_flag_ints(RC_MAXL, n, h, w));   // lab: the tail of an over-sized flag buffer
+#else
+  a.dbg = nullptr;
+#endif
   int cmax = 1;
   for (int i = 0; i < n_layers; ++i) {
     const tg_chain_layer& l = layers[i];

@@ -15,3 +15,17 @@ for PMC in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY S
   timeout 600 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$i -o pmc -- $CMD > $OUT/pmc_${TAG}_$i.log 2>&1
   echo "pass $i rc=$? : $PMC"; ls $OUT/pmc_${TAG}_$i | head
 done
+# BASELINE configs[4] (2x BI, 268x640): its SRNet runs as the chained Winograd launch -- traffic passes only
+CMD5="python $REPO/bench.py --lr-size 3x268x640 --scale 2 --degradation BI --steps 6 --warmup 2 --clips 1 --no-roofline --no-pipeline --no-secondary --no-train-leg --cpu-frames 0 --aten-frames 0"
+for PMC in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$i -o pmc -- $CMD5 > $OUT/pmc_${TAG}_$i.log 2>&1
+  echo "pass $i rc=$? : $PMC (2xBI)"
+done
+# the training step (crop 128): traffic of the chained body launch and the layered weight-gradient launch
+CMDT="python $REPO/tools/bench_train.py --crop 128 --steps 3 --warmup 1 --force-d"
+for PMC in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$i -o pmc -- $CMDT > $OUT/pmc_${TAG}_$i.log 2>&1
+  echo "pass $i rc=$? : $PMC (train crop 128)"
+done

@@ -16,14 +16,14 @@ tag = sys.argv[1] if len(sys.argv) > 1 else 'r01b'
 rnd = sys.argv[2] if len(sys.argv) > 2 else 'r01'
 outdir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, 'profiles')     # the GPU box writes to gpurun_out/
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for i in (1, 2, 3, 4):
+for i in (1, 2, 3, 4, 5, 6, 7, 8):     # 5-6: the 2xBI config, 7-8: the training step (tools/gpu_pmc.sh)
     path = os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}_{i}', 'pmc_counter_collection.csv')
     if not os.path.isfile(path):
         continue
     for r in csv.DictReader(open(path)):
         if 'tg::' not in r['Kernel_Name']:
             continue
-        key = (r['Kernel_Name'].split('(')[0].replace('void ', ''), r['Grid_Size'])
+        key = (r['Kernel_Name'].split('(')[0].replace('void ', ''), r['Grid_Size'] + ('' if i <= 4 else (' [2xBI]' if i <= 6 else ' [train128]')))
         agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
 names = sorted({c for d in agg.values() for c in d})
 out = os.path.join(outdir, f'{rnd}_pmc_summary.csv')
