@@ -559,22 +559,37 @@ __global__ __launch_bounds__(512) void conv3x3_oneshot_kernel(Conv3x3Args a) {
   }
   // ---- the input patch of every chunk -> LDS
   const int total = nchunk * ITEMS_PER_CH;
-  for (int q = tid; q < total; q += 512) {
-    const int ch = q / ITEMS_PER_CH, rem = q - ch * ITEMS_PER_CH;
-    const int r = rem / (2 * PW), rem2 = rem - r * (2 * PW);
-    const int hf = rem2 / PW, col = rem2 - hf * PW;
-    const int gy = y0 - 1 + r, gx = x0 - 1 + col;
-    const bool ok = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-    const unsigned base = ok ? (unsigned)(((ch * CK + 4 * hf) * hw + gy * a.w + gx) * 4) : OOB;
-    f32x4 v;
+  // two items per thread in flight: all their loads are issued before the first LDS store (a loop of
+  // load -> store iterations pays the memory latency once per iteration)
+  constexpr int MAXQ = (MAXCH * ITEMS_PER_CH + 511) / 512;     // 4
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned o1 = base + (unsigned)j * plane;
-      float t = buf_load(rs1, o1);
-      if (DUAL) t += buf_load(rs2, o1 - (unsigned)a.c1 * plane);
-      v[j] = t;
+  for (int k0 = 0; k0 < MAXQ; k0 += 2) {
+    f32x4 v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + (k0 + k) * 512;
+      const int ch = q / ITEMS_PER_CH, rem = q - ch * ITEMS_PER_CH;
+      const int r = rem / (2 * PW), rem2 = rem - r * (2 * PW);
+      const int hf = rem2 / PW, col = rem2 - hf * PW;
+      const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+      const bool ok = q < total && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      const unsigned base = ok ? (unsigned)(((ch * CK + 4 * hf) * hw + gy * a.w + gx) * 4) : OOB;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned o1 = base + (unsigned)j * plane;
+        float t = buf_load(rs1, o1);
+        if (DUAL) t += buf_load(rs2, o1 - (unsigned)a.c1 * plane);
+        v[k][j] = t;
+      }
     }
-    *reinterpret_cast<f32x4*>(s_in + ch * IN_FLOATS + ((r * 2 + hf) * RS + col) * 4) = v;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + (k0 + k) * 512;
+      const int ch = q / ITEMS_PER_CH, rem = q - ch * ITEMS_PER_CH;
+      const int r = rem / (2 * PW), rem2 = rem - r * (2 * PW);
+      const int hf = rem2 / PW, col = rem2 - hf * PW;
+      if (q < total) *reinterpret_cast<f32x4*>(s_in + ch * IN_FLOATS + ((r * 2 + hf) * RS + col) * 4) = v[k];
+    }
   }
   __syncthreads();
 

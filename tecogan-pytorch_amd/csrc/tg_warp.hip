@@ -159,11 +159,24 @@ __global__ __launch_bounds__(128 * (R / RPT)) void flowup_warp_s2d_kernel(FusedA
 
   // ---- 1. LR-flow terms
   if (bicubic) {
-    for (int it = t; it < 2 * 4 * NV; it += NT) {
-      const int k = it % NV, p = (it / NV) & 3, ch = it / (4 * NV);
-      const unsigned cc = (unsigned)reflect_src(clampi(jbase + k, 0, a.w - 1), a.fw);
-      const unsigned o = ((unsigned)reflect_src(clampi(oy - 1 + p, 0, a.h - 1), a.fh) * a.fw + cc) * 4u;
-      s_raw[ch][p][k] = (TG_WARP_ABL & 4) ? 0.01f : bload(rf, o, ch * fhw * 4u);
+    {   // every load of the patch is issued before the first LDS store: a loop of load -> store
+        // iterations would pay the L2 latency once per iteration on the block's critical path
+      constexpr int FPT = (2 * 4 * NV + NT - 1) / NT;
+      float fv[FPT];
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) {
+        const int it = t + i * NT;
+        const int k = it % NV, p = (it / NV) & 3, ch = it / (4 * NV);
+        const unsigned cc = (unsigned)reflect_src(clampi(jbase + k, 0, a.w - 1), a.fw);
+        const unsigned o = ((unsigned)reflect_src(clampi(oy - 1 + p, 0, a.h - 1), a.fh) * a.fw + cc) * 4u;
+        fv[i] = (it < 2 * 4 * NV && !(TG_WARP_ABL & 4)) ? bload(rf, o, (ch & 1) * fhw * 4u) : 0.01f;
+      }
+#pragma unroll
+      for (int i = 0; i < FPT; ++i) {
+        const int it = t + i * NT;
+        const int k = it % NV, p = (it / NV) & 3, ch = it / (4 * NV);
+        if (it < 2 * 4 * NV) s_raw[ch][p][k] = fv[i];
+      }
     }
     if (t >= NT - S) {
       float k[4];
@@ -182,15 +195,27 @@ __global__ __launch_bounds__(128 * (R / RPT)) void flowup_warp_s2d_kernel(FusedA
       s_fl[r][0][k] = make_float2(sx_, sy_);
     }
   } else {
-    for (int it = t; it < R * NV; it += NT) {
+    constexpr int BPT = (R * NV + NT - 1) / NT;
+    float2 b0[BPT], b1[BPT];
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+      const int it = t + i * NT;
       const int r = it / NV, k = it - r * NV;
       const unsigned cc = (unsigned)reflect_src(clampi(jbase + k, 0, a.w - 1), a.fw);
       int y0, y1; float ly0, ly1;
-      bilinear_src(hy0 + r, S, a.h, y0, y1, ly0, ly1);
+      bilinear_src(hy0 + (r < R ? r : 0), S, a.h, y0, y1, ly0, ly1);
       unsigned o0 = ((unsigned)reflect_src(y0, a.fh) * a.fw + cc) * 4u;
       unsigned o1 = ((unsigned)reflect_src(y1, a.fh) * a.fw + cc) * 4u;
-      s_fl[r][0][k] = make_float2(bload(rf, o0, 0), bload(rf, o0, fhw * 4u));
-      s_fl[r][1][k] = make_float2(bload(rf, o1, 0), bload(rf, o1, fhw * 4u));
+      if (it < R * NV) {
+        b0[i] = make_float2(bload(rf, o0, 0), bload(rf, o0, fhw * 4u));
+        b1[i] = make_float2(bload(rf, o1, 0), bload(rf, o1, fhw * 4u));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BPT; ++i) {
+      const int it = t + i * NT;
+      const int r = it / NV, k = it - r * NV;
+      if (it < R * NV) { s_fl[r][0][k] = b0[i]; s_fl[r][1][k] = b1[i]; }
     }
   }
   __syncthreads();
