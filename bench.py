@@ -112,16 +112,20 @@ def kernel_table(net, plan, bufs, reps=20):
     return rows
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, tag=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
-    (profiles/pmc_traffic.json, written by tools/summarize_pmc.py); None if absent."""
+    (profiles/pmc_traffic.json, written by tools/summarize_pmc.py); None if absent.  The launches of
+    the other workloads of the counter run are kept under tagged keys ("... [2xBI]", "... [train128]")."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(path) as f:
             table = json.load(f)
         want = kernel.replace(' ', '').rstrip('>')
         for k, v in table.items():
-            if k.replace(' ', '').replace('tg::', '').startswith(want):
+            name, _, ktag = k.partition(' [')
+            if (ktag.rstrip(']') or None) != tag:
+                continue
+            if name.replace(' ', '').replace('tg::', '').startswith(want):
                 return v
     except Exception:
         pass
@@ -335,7 +339,8 @@ def config5_leg(dev, gen, frames):
                            'unit': 'TFLOP/s', 'launches_per_frame': dom['launches'],
                            'avg_launch_us': 1e3 * dom['ms_per_frame'] / dom['launches'],
                            'algorithmic_gflop_per_launch': dom['gflop'] / dom['launches'],
-                           'traffic': pmc_traffic(dom['kernel'])}
+                           'traffic': pmc_traffic(dom['kernel'], '2xBI'),
+                           'traffic_source': 'profiles/pmc_traffic.json (committed rocprofv3 --pmc passes, tools/gpu_pmc.sh); NOT measured in this run'}
         if wino:     # algorithmic FLOPs may exceed the pipe's peak in this form: the statement about the
             #          matrix pipe is the executed fraction, the one about the form its own ceiling
             out['roofline']['frac_vs_winograd_ceiling'] = ach / (MFMA_F32_PEAK_TFLOPS * 2.25)

@@ -36,8 +36,10 @@ with open(out, 'w', newline='') as f:
 traffic = {}
 for (k, g), d in agg.items():
     if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
-        # weight by dispatch count: per-symbol mean over all launches of a frame
-        t = traffic.setdefault(k, [0.0, 0])
+        # weight by dispatch count: per-symbol mean over all launches of a frame; the launches of
+        # the other workloads (2xBI clip, training step) are kept apart under a tagged key
+        tagk = k + (' ' + g[g.index('['):] if '[' in g else '')
+        t = traffic.setdefault(tagk, [0.0, 0])
         n = len(d['FETCH_SIZE'])
         t[0] += (sum(d['FETCH_SIZE']) / n + sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE'])) * 1024 * n
         t[1] += n
