@@ -20,6 +20,18 @@ static inline int grid_for(long long total, int cap = 4096) {
 // one block per channel: 16 waves when the channel plane is large (early discriminator
 // layers: 12 x 128 x 128 elements per channel), 4 otherwise
 static inline int bn_threads(int n, long long hw) { return (long long)n * hw >= 32768 ? 1024 : 256; }
+// slices of the batch a BatchNorm reduction is split into (1 = one block per channel): equal slices,
+// at least 32k elements each, aiming at ~512 blocks
+static inline int bn_slices(int n, int c, long long hw) {
+  for (int ns = 8; ns >= 2; --ns)
+    if (n % ns == 0 && (long long)(n / ns) * hw >= 32768 && c * ns <= 1024 && (long long)n * hw * c >= (long long)ns * 2 * c)
+      return ns;
+  return 1;
+}
+__global__ void bn_local_stats_kernel(const float* __restrict__ x, int n, int c, int hw, float* __restrict__ stats2c);
+__global__ void bn_merge_stats_kernel(const float* __restrict__ gathered, int world, float cnt_r, float eps,
+                                      float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                      float* __restrict__ run_mean, float* __restrict__ run_var, int c);
 #define TG_GRID_STRIDE(i, total)                                                   \
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total); \
        i += (long long)gridDim.x * blockDim.x)
@@ -503,8 +515,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(
   int ch = blockIdx.x;
   float a = 0.f, bq = 0.f;
   const float mu = mean[ch], is = invstd[ch];
+  // blockIdx.y = slice of n images (gridDim.y > 1: partial sums at + slice * 2c, bn_sum_slices_kernel adds them)
+  const long long base = (long long)blockIdx.y * n * c * hw;
+  sum_dz += (long long)blockIdx.y * 2 * c;
+  sum_dz_xhat += (long long)blockIdx.y * 2 * c;
   for (int b = 0; b < n; ++b) {
-    const long long off = ((long long)b * c + ch) * hw;
+    const long long off = base + ((long long)b * c + ch) * hw;
     for (int i = threadIdx.x; i < hw; i += blockDim.x) {
       float g = dy[off + i];
       float dz = y[off + i] > 0.f ? g : g * slope;
@@ -514,6 +530,14 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(
   }
   float r0 = block_sum(a, sm), r1 = block_sum(bq, sm);
   if (threadIdx.x == 0) { sum_dz[ch] = r0; sum_dz_xhat[ch] = r1; }
+}
+// out[j] = sum over slices (fixed order) of part[s * 2c + j], j < 2c
+__global__ void bn_sum_slices_kernel(const float* __restrict__ part, int ns, int c2, float* __restrict__ out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= c2) return;
+  float v = 0.f;
+  for (int s_ = 0; s_ < ns; ++s_) v += part[(long long)s_ * c2 + j];
+  out[j] = v;
 }
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                     const float* __restrict__ dy, const float* __restrict__ mean,
@@ -757,8 +781,19 @@ extern "C" int tg_bn_lrelu_train_fwd(const float* x, const float* gamma, const f
                                      float* save_invstd, int n, int c, int hw, tg_stream_t stream) {
   TG_REQUIRE(x && gamma && beta && y && save_mean && save_invstd, TG_E_ARG, "bn_fwd: null pointer");
   TG_REQUIRE(n > 0 && c > 0 && hw > 0 && (long long)n * hw > 1, TG_E_SHAPE, "bn_fwd: shape");
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(c), dim3(bn_threads(n, hw)), 0, ST, x, n, c, hw, eps, momentum, save_mean,
-                     save_invstd, running_mean, running_var);
+  // One block per channel leaves most of the device idle when c is small and the planes are large (the
+  // critic's 64-channel blocks on 24 HR clips: 64 blocks for 100 MB, 110 us).  Then: equal slices of the
+  // batch per block, (mean, M2) pairs merged with Chan's formula in slice order (deterministic).  The
+  // partials live in `y`, which the apply kernel overwrites afterwards.
+  const int ns = bn_slices(n, c, hw);
+  if (ns > 1) {
+    hipLaunchKernelGGL(bn_local_stats_kernel, dim3(c, ns), dim3(bn_threads(n / ns, hw)), 0, ST, x, n / ns, c, hw, y);
+    hipLaunchKernelGGL(bn_merge_stats_kernel, dim3(cdiv(c, 256)), dim3(256), 0, ST, (const float*)y, ns,
+                       (float)(n / ns) * (float)hw, eps, momentum, save_mean, save_invstd, running_mean, running_var, c);
+  } else {
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(c), dim3(bn_threads(n, hw)), 0, ST, x, n, c, hw, eps, momentum, save_mean,
+                       save_invstd, running_mean, running_var);
+  }
   long long total = (long long)n * c * hw;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, ST, x, save_mean,
                      save_invstd, gamma, beta, y, total, c, hw, slope);
@@ -774,8 +809,15 @@ extern "C" int tg_bn_lrelu_train_bwd(const float* x, const float* y, const float
              "bn_bwd: null pointer");
   float* s0 = scratch2c;
   float* s1 = scratch2c + c;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(c), dim3(bn_threads(n, hw)), 0, ST, x, y, dy, save_mean, save_invstd,
-                     n, c, hw, slope, s0, s1);
+  const int ns = dx ? bn_slices(n, c, hw) : 1;      // (the partial sums live in dx until the apply kernel overwrites it)
+  if (ns > 1) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(c, ns), dim3(bn_threads(n / ns, hw)), 0, ST, x, y, dy, save_mean,
+                       save_invstd, n / ns, c, hw, slope, dx, dx + c);
+    hipLaunchKernelGGL(bn_sum_slices_kernel, dim3(cdiv(2 * c, 256)), dim3(256), 0, ST, (const float*)dx, ns, 2 * c, s0);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(c), dim3(bn_threads(n, hw)), 0, ST, x, y, dy, save_mean, save_invstd,
+                       n, c, hw, slope, s0, s1);
+  }
   long long total = (long long)n * c * hw;
   if (dx)
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, ST, x, y, dy, save_mean,
@@ -786,8 +828,8 @@ extern "C" int tg_bn_lrelu_train_bwd(const float* x, const float* y, const float
       hipLaunchKernelGGL(axpy_kernel, dim3(1), dim3(256), 0, ST, dgamma, (const float*)s1, 1.0f, (long long)c);
       hipLaunchKernelGGL(axpy_kernel, dim3(1), dim3(256), 0, ST, dbeta, (const float*)s0, 1.0f, (long long)c);
     } else {
-      hipMemcpyAsync(dgamma, s1, c * sizeof(float), hipMemcpyDeviceToDevice, ST);
-      hipMemcpyAsync(dbeta, s0, c * sizeof(float), hipMemcpyDeviceToDevice, ST);
+      (void)hipMemcpyAsync(dgamma, s1, c * sizeof(float), hipMemcpyDeviceToDevice, ST);
+      (void)hipMemcpyAsync(dbeta, s0, c * sizeof(float), hipMemcpyDeviceToDevice, ST);
     }
   }
   return check_launch("bn_lrelu_train_bwd");
@@ -861,9 +903,13 @@ namespace tg {
 // (two passes over the plane, like bn_stats_kernel) -> stats2c = [mean | M2]
 __global__ __launch_bounds__(1024) void bn_local_stats_kernel(const float* __restrict__ x, int n, int c,
                                                              int hw, float* __restrict__ stats2c) {
+  // blockIdx.y = slice of the batch (gridDim.y equal slices of n images each; 1 in the per-rank form):
+  // slice s writes its (mean, M2) pair at stats2c + s * 2c -- the layout bn_merge_stats_kernel merges
   __shared__ float sm[16];
   __shared__ float s_mean;
   int ch = blockIdx.x;
+  x += (long long)blockIdx.y * n * c * hw;
+  stats2c += (long long)blockIdx.y * 2 * c;
   float s = 0.f;
   for (int b = 0; b < n; ++b) {
     const float* p = x + ((long long)b * c + ch) * hw;

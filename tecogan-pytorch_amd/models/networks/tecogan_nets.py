@@ -172,7 +172,8 @@ class SRNet(nn.Module):
     def up_mode(self):
         return ops.UP_BICUBIC if isinstance(self.upsample_func, nn.Module) else ops.UP_BILINEAR
 
-    def forward(self, lr_curr, hr_prev_tran, tape=None):
+    def forward(self, lr_curr, hr_prev_tran, tape=None, bi=None):
+        """bi (training only): `upsample_func(lr_curr)` computed by the caller for all frames at once."""
         lr_curr, hr_prev_tran = lr_curr.contiguous(), hr_prev_tran.contiguous()
         if tape is not None:
             n_, _, h_, w_ = lr_curr.shape
@@ -188,7 +189,7 @@ class SRNet(nn.Module):
             for k in self.conv_up:
                 out = TG.convt3x3s2(tape, self.conv_up[k], out, TG.RELU)
             return TG.conv3x3_small(tape, self.conv_out, out, TG.NONE, up_src=lr_curr,
-                                    up_mode=self.up_mode(), up_scale=self.scale)
+                                    up_mode=self.up_mode(), up_scale=self.scale, res=bi)
         out = self.conv_in['0'](lr_curr, ops.ACT_RELU, x2=hr_prev_tran)
         for rb in self.resblocks:
             t = rb.conv['0'](out, ops.ACT_RELU)
@@ -528,7 +529,9 @@ class FRNet(nn.Module):
 
         frames = []
         zeros = torch.zeros(n, s * s * c, h, w, dtype=torch.float32, device=lr_data.device)
-        hr_prev = self.srnet(lr_fm[0], zeros, tape=tape)
+        # upsample_func(lr_curr) of every frame in one launch (tecogan_nets.py:145 evaluates it per frame)
+        bi_fm = ops.upsample(lr_fm.view(t * n, c, h, w), s, self.srnet.up_mode()).view(t, n, c, s * h, s * w)
+        hr_prev = self.srnet(lr_fm[0], zeros, tape=tape, bi=bi_fm[0])
         frames.append(hr_prev)
         for i in range(1, t):
             if tape.side is not None and i == (t + 1) // 2:
@@ -538,7 +541,7 @@ class FRNet(nn.Module):
             warped = TG.backward_warp(tape, hr_prev, flow_fm[i - 1],
                                       dflow_out=functools.partial(flow_grad_slice, i - 1))
             tran = TG.space_to_depth(tape, warped, s)
-            hr_prev = self.srnet(lr_fm[i], tran, tape=tape)
+            hr_prev = self.srnet(lr_fm[i], tran, tape=tape, bi=bi_fm[i])
             frames.append(hr_prev)
         hr_data = ops.stack_time(frames)
 

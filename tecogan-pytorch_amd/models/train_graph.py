@@ -368,7 +368,7 @@ def srnet_body(tape, srnet, lr, tran):
         fw[i].w, fw[i].b = pk.data_ptr(), m.bias.data_ptr()
     acts = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=lr.device)
     flags, err, epoch = _ChainState.buffers(nl + 1, n, h, w, lr.device)
-    st = torch.cuda.current_stream().cuda_stream
+    st = ops._stream()
     L.check(L.lib().tg_srnet_body_fwd(fw, nb, lr.data_ptr(), c_lr, tran.data_ptr(), c_tran, acts.data_ptr(),
                                       n, nf, h, w, flags.data_ptr(), err.data_ptr(), epoch,
                                       _ChainState.poll_limit, st), 'tg_srnet_body_fwd')
@@ -401,7 +401,7 @@ def srnet_body(tape, srnet, lr, tran):
         fl, er, ep = _ChainState.buffers(nl + 1, n, h, w, g.device)
         L.check(L.lib().tg_srnet_body_bwd(dg, nb, acts.data_ptr(), dz.data_ptr(), d_tran.data_ptr(),
                                           c_tran, n, nf, h, w, fl.data_ptr(), er.data_ptr(), ep,
-                                          _ChainState.poll_limit, torch.cuda.current_stream().cuda_stream),
+                                          _ChainState.poll_limit, ops._stream()),
                 'tg_srnet_body_bwd')
         tape.keep.append(hold)
         if conv_in.weight.requires_grad:
@@ -417,11 +417,17 @@ def srnet_body(tape, srnet, lr, tran):
     return out
 
 
-def conv3x3_small(tape, layer, x, act=NONE, up_src=None, up_mode=ops.UP_NONE, up_scale=1):
-    """cout <= 4 head (flow[2] / conv_out).  `up_src` is data (no gradient)."""
+def conv3x3_small(tape, layer, x, act=NONE, up_src=None, up_mode=ops.UP_NONE, up_scale=1, res=None):
+    """cout <= 4 head (flow[2] / conv_out).  `up_src` is data (no gradient).  `res` (data as well): the
+    already up-sampled residual -- the forward then runs on the MFMA kernel (3 of 32 output columns
+    used, but 12 us instead of the 39 us of the 32-workgroup VALU launch on a 2 x 128 x 128 frame)."""
     w, b = layer.weight, layer.bias
     cout, cin = w.shape[0], w.shape[1]
-    y = ops.conv3x3_small(x, w, b, act, up_src=up_src, up_mode=up_mode, up_scale=up_scale)
+    if res is not None and act in (NONE, RELU, LRELU):
+        pk, ocb = layer.packed()
+        y = ops.conv3x3(x, pk, b, cin, cout, ocb, act, res=res, ksplit=1)
+    else:
+        y = ops.conv3x3_small(x, w, b, act, up_src=up_src, up_mode=up_mode, up_scale=up_scale)
     if tape is None:
         return y
 

@@ -10,7 +10,14 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_LRELU02, ACT_TANH24,  # noqa: F401
 UP_MODE = {'BD': UP_BICUBIC, 'BI': UP_BILINEAR}
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream (the raw-handle query is ~10x cheaper than building a
+    torch.cuda.Stream object; a training step asks ~650 times)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -294,7 +301,7 @@ _WGRAD_WS = {}
 def _wgrad_workspace(device, nfloats):
     # one scratch buffer per (device, stream): weight-gradient launches of the training step run on
     # the main stream and on a side stream at the same time (Tape.flush_deferred_async)
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    key = (str(device), _stream())
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < nfloats:
         ws = torch.empty(int(nfloats), dtype=torch.float32, device=device)
