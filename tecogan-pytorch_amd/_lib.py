@@ -56,6 +56,8 @@ SIGNATURES = {
     'tg_conv3x3_fwd': (I, [P, I64, I, P, I64, P, I, P, P, I64, P, I64, I, I, I, I, I, I, P]),
     'tg_conv3x3_fwd_phased': (I, [P, I64, P, I, P, P, I64, I, I, I, I, I, I, I, I, I, I, P]),
     'tg_conv3x3_fwd_phased_masked': (I, [P, I64, P, I, P, P, I64, P, I64, I, I, I, I, I, I, I, I, I, I, P]),
+    'tg_conv3x3s2_supported': (I, [I, I, I, I, I]),
+    'tg_conv3x3s2_fwd': (I, [P, I64, P, P, P, I64, P, I64, I, I, I, I, I, I, P]),
     'tg_conv3x3_fwd_masked': (I, [P, I64, I, P, I64, P, I, P, P, I64, P, I64, P, I64, I, I, I, I, I, I, P]),
     'tg_conv3x3_pick_ksplit': (I, [I, I, I, I, I]),
     'tg_conv3x3_splitk_fwd': (I, [P, I64, I, P, I64, P, I, P, P, I, I, I, I, I, I, I, P, I, P]),

@@ -665,6 +665,126 @@ __global__ __launch_bounds__(512) void conv3x3_oneshot_kernel(Conv3x3Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The one-shot scheme for a STRIDE-2 3x3 conv: y(oy, ox) = sum_k w[k] x(2 oy - 1 + ky, 2 ox - 1 + kx)
+// (zero outside) -- the data gradient of ConvTranspose2d(k3, s2, p1, op1) (tecogan_nets.py:119-126)
+// on the training frames.  Through its space-to-depth embedding that gradient is a 256-channel
+// phased conv walking 32 channel chunks (27 us per launch for 2 x 32 x 32 outputs); directly it is a
+// K = 576 contraction like any body layer: the patch is 3 input rows x 66 input columns per
+// 8-channel chunk, the B operand of output pixel ox and tap kx sits at column 2 ox + kx.
+constexpr int RS2 = 2 * TW + 2;                        // 66 patch columns
+__global__ __launch_bounds__(512) void conv3x3s2_oneshot_kernel(Conv3x3Args a) {
+  constexpr int OCB = 64, KG = 4, MAXCH = 8;
+  constexpr int IN_FLOATS = 3 * 2 * RS2 * 4;           // one chunk's patch
+  constexpr int ITEMS_PER_CH = 3 * 2 * RS2;            // 396 16-byte items
+  constexpr int W_VEC4 = 9 * CK * OCB / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_in = smem;                                  // [MAXCH][IN_FLOATS]; later the epilogue stage [64][36]
+  float* red = smem + MAXCH * IN_FLOATS;               // [2][KG-1][16][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+  const int lh = lane >> 5, ll = lane & 31;
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int x0 = tx * TW, y0 = ty;
+  const int hw = a.h * a.w;                            // OUTPUT plane
+  const int ih = 2 * a.h, iw = 2 * a.w, ihw = ih * iw; // input plane
+  const unsigned plane = (unsigned)ihw * 4u;
+  const int nchunk = a.nchunk;
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (long long)n * a.x_ns), 0, a.cin * ihw * 4, 0x00020000);
+  const int cpw = (nchunk + KG - 1) / KG;
+  const int c0 = wk * cpw;
+  const f32x4* wlane = reinterpret_cast<const f32x4*>(a.wpk) + (lh * OCB + wn * 32 + ll);
+  f32x4 aw[2][9];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int c = c0 + ci;
+    const bool on = ci < cpw && c < nchunk;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (on) v = wlane[(size_t)c * W_VEC4 + tap * (2 * OCB)];
+      aw[ci][tap] = v;
+    }
+  }
+  const int total = nchunk * ITEMS_PER_CH;
+  constexpr int MAXQ = (MAXCH * ITEMS_PER_CH + 511) / 512;     // 7
+#pragma unroll
+  for (int k0 = 0; k0 < MAXQ; k0 += 2) {
+    f32x4 v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + (k0 + k) * 512;
+      const int ch = q / ITEMS_PER_CH, rem = q - ch * ITEMS_PER_CH;
+      const int r = rem / (2 * RS2), rem2 = rem - r * (2 * RS2);
+      const int hf = rem2 / RS2, col = rem2 - hf * RS2;
+      const int gy = 2 * y0 - 1 + r, gx = 2 * x0 - 1 + col;
+      const bool ok = (k0 + k) < MAXQ && q < total && gy >= 0 && gy < ih && gx >= 0 && gx < iw;
+      const unsigned base = ok ? (unsigned)(((ch * CK + 4 * hf) * ihw + gy * iw + gx) * 4) : OOB;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[k][j] = buf_load(rs1, base + (unsigned)j * plane);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + (k0 + k) * 512;
+      const int ch = q / ITEMS_PER_CH, rem = q - ch * ITEMS_PER_CH;
+      const int r = rem / (2 * RS2), rem2 = rem - r * (2 * RS2);
+      const int hf = rem2 / RS2, col = rem2 - hf * RS2;
+      if ((k0 + k) < MAXQ && q < total) *reinterpret_cast<f32x4*>(s_in + ch * IN_FLOATS + ((r * 2 + hf) * RS2 + col) * 4) = v[k];
+    }
+  }
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int c = c0 + ci;
+    if (ci < cpw && c < nchunk) {
+      const float* si = s_in + c * IN_FLOATS + (lh * RS2 + 2 * ll) * 4;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(si + (ky * 2 * RS2 + kx) * 4);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ci][tap][kk], bq[kk], acc, 0, 0, 0);
+      }
+    }
+  }
+  if (wk > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wn * (KG - 1) + wk - 1) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  constexpr int ES = 36;
+  float* ep = smem;
+  if (wk == 0) {
+#pragma unroll
+    for (int g = 0; g < KG - 1; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[((wn * (KG - 1) + g) * 16 + r) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ep[(wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ES + ll] = acc[r];
+  }
+  __syncthreads();
+  const float slope = act_slope(a.act);
+  for (int i = tid; i < 64 * TW; i += 512) {
+    const int oc = i >> 5, p = i & 31;
+    const int gx = x0 + p;
+    if (oc < a.cout && gx < a.w) {
+      const long long off = (long long)oc * hw + (long long)y0 * a.w + gx;
+      float q = ep[oc * ES + p] + (a.bias ? a.bias[oc] : 0.f);
+      q = (q >= 0.f ? q : q * slope + 0.f) + (a.res ? a.res[(long long)n * a.res_ns + off] : 0.f);
+      if (a.mask && a.mask[(long long)n * a.mask_ns + off] <= 0.f) q = 0.f;
+      a.y[(long long)n * a.y_ns + off] = q;
+    }
+  }
+}
+
 // 3 = LDS-transposed 16-byte epilogue + LDS-DMA weight staging (measured +2 % on the frame,
 // parity suite green); bit 4 (start-up stagger of co-resident workgroups) measured null.
 #ifndef TG_CONV_OPT
@@ -909,6 +1029,37 @@ extern "C" int tg_conv3x3_fwd_phased_masked(const float* x, int64_t x_nstride, c
   return conv3x3_impl(x, x_nstride, cin, nullptr, 0, w_packed, ocb, bias, nullptr, 0, y, y_nstride, n, cin,
                       cout, h, w, act, 1, nullptr, stream, relu_mask, mask_nstride, tapsel, cphase, taps_phase0,
                       taps_phase1);
+}
+
+// shapes the stride-2 one-shot kernel takes: one 64-channel block, cin <= 64, at most 256 one-row tiles
+extern "C" int tg_conv3x3s2_supported(int n, int cin, int cout, int h_out, int w_out) {
+  if (n <= 0 || cin <= 0 || cin > 64 || cout <= 0 || cout > 64 || h_out <= 0 || w_out <= 0) return 0;
+  return (long long)n * h_out * cdiv(w_out, TW) <= 256 ? 1 : 0;
+}
+
+extern "C" int tg_conv3x3s2_fwd(const float* x, int64_t x_nstride, const float* w_packed, const float* bias,
+                                const float* relu_mask, int64_t mask_nstride, float* y, int64_t y_nstride, int n,
+                                int cin, int cout, int h_out, int w_out, int act, tg_stream_t stream) {
+  TG_REQUIRE(x && w_packed && y, TG_E_ARG, "conv3x3s2_fwd: null pointer");
+  TG_REQUIRE(tg_conv3x3s2_supported(n, cin, cout, h_out, w_out), TG_E_SHAPE,
+             "conv3x3s2_fwd: n=%d cin=%d cout=%d out %dx%d (cin, cout <= 64, <= 256 row tiles)", n, cin, cout, h_out, w_out);
+  TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_LRELU02, TG_E_ARG, "conv3x3s2_fwd: act=%d", act);
+  TG_REQUIRE((long long)(cin + CK) * 4 * h_out * w_out * 4 < (1ll << 31), TG_E_SHAPE, "conv3x3s2_fwd: item too large");
+  Conv3x3Args a{};
+  a.x = x; a.wpk = w_packed; a.bias = bias; a.y = y; a.x_ns = x_nstride; a.y_ns = y_nstride;
+  a.mask = relu_mask; a.mask_ns = mask_nstride;
+  a.c1 = cin; a.cin = cin; a.cout = cout; a.h = h_out; a.w = w_out; a.act = act;
+  a.tiles_x = cdiv(w_out, TW); a.tiles_y = h_out; a.nocg = 1; a.nchunk = cdiv(cin, CK);
+  const size_t lds = (size_t)(8 * 3 * 2 * RS2 * 4 + 2 * 3 * 16 * 64) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s2_oneshot_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv3x3s2_oneshot_kernel, dim3((unsigned)(a.tiles_x * a.tiles_y * n)), dim3(512), lds,
+                     (hipStream_t)stream, a);
+  return check_launch("conv3x3s2_oneshot");
 }
 
 extern "C" int tg_conv3x3_fwd_masked(const float* x, int64_t x_nstride, int c1, const float* x2,

@@ -513,7 +513,13 @@ def convt3x3s2(tape, layer, x, act=RELU):
         s = ops.space_to_depth(dz, 2)                              # (n, 4co, h, w)
         we = _CACHE.get(layer, ('cte',), _ver(w), lambda: ops.pack_conv3x3(_convt_embed(w.detach())))
         fuse = id(x) in tape.relu_outputs
-        if co % 8 == 0:      # phase py = 1 owns tap rows {0, 1}, py = 0 only {1}: 9 of 36 taps are non-zero
+        nx, _, hx, wx = x.shape
+        if ops.conv3x3s2_supported(nx, co, ci, hx, wx):
+            # small frames: the gradient taken directly as a stride-2 conv of dZ (K = 9 co) -- 11 us
+            # instead of 27 us for the 32-chunk phased form on s2d(dZ)
+            wk = _CACHE.get(layer, ('ctd',), _ver(w), lambda: ops.pack_conv3x3(w.detach().contiguous(), ocb=64)[0])
+            tape.add_grad(x, ops.conv3x3s2(dz, wk, co, ci, relu_mask=x if fuse else None), masked=fuse)
+        elif co % 8 == 0:      # phase py = 1 owns tap rows {0, 1}, py = 0 only {1}: 9 of 36 taps are non-zero
             tape.add_grad(x, ops.conv3x3_phased(s, we[0], 4 * co, ci, we[3], 1, co, ops.TAPS_1, ops.TAPS_01,
                                                 relu_mask=x if fuse else None), masked=fuse)
         else:

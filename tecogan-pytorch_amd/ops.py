@@ -150,6 +150,29 @@ def conv3x3_phased(x, wpk, cin, cout, ocb, tapsel, cphase, taps_phase0, taps_pha
     return out
 
 
+def conv3x3s2_supported(n, cin, cout, h_out, w_out):
+    return bool(L.lib().tg_conv3x3s2_supported(n, cin, cout, h_out, w_out))
+
+
+def conv3x3s2(x, wpk, cin, cout, relu_mask=None):
+    """Stride-2 3x3 conv (tg_conv3x3s2_fwd): x (n, cin, 2h, 2w) -> (n, cout, h, w); the data gradient of
+    ConvTranspose2d(k3, s2, p1, op1) with wpk = pack_conv3x3(W viewed as (cout = ci, cin = co), ocb 64)."""
+    _chk(x, 'x')
+    n, c, h2, w2 = x.shape
+    if c != cin or h2 % 2 or w2 % 2:
+        raise L.TecoganHipError(f'conv3x3s2: x {tuple(x.shape)} cin {cin}')
+    h, w = h2 // 2, w2 // 2
+    out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    if relu_mask is not None:
+        _chk(relu_mask, 'relu_mask')
+        if relu_mask.shape != out.shape:
+            raise L.TecoganHipError('conv3x3s2: relu_mask shape mismatch')
+    L.check(L.lib().tg_conv3x3s2_fwd(x.data_ptr(), cin * h2 * w2, wpk.data_ptr(), None, _ptr(relu_mask), cout * h * w,
+                                     out.data_ptr(), cout * h * w, n, cin, cout, h, w, ACT_NONE, _stream()),
+            'tg_conv3x3s2_fwd')
+    return out
+
+
 def convt3x3s2(x, wpk, bias, cout, act=ACT_NONE, out=None):
     _chk(x, 'x')
     n, cin, h, w = x.shape

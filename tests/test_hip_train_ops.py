@@ -586,3 +586,18 @@ def test_space_to_depth_vector_path_is_a_permutation(ops, n, c, h, w, s):
     y = ops.space_to_depth(dev(x), s)
     assert torch.equal(y.cpu(), ref)
     assert torch.equal(ops.depth_to_space(y, s).cpu(), x)
+
+
+@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 32), (2, 64, 64, 64, 64), (1, 24, 40, 9, 21), (3, 64, 16, 5, 40)])
+def test_convt_data_gradient_as_stride2_conv(ops, n, ci, co, h, w):
+    """tg_conv3x3s2_fwd: dX of ConvTranspose2d(ci, co, 3, 2, 1, 1) taken directly from dY (and the
+    ReLU-backward mask of the layer below in the same epilogue) against autograd."""
+    x = rs(1, (n, ci, h, w)).requires_grad_(True)
+    wt = (rs(2, (ci, co, 3, 3)) / (3.0 * ci ** 0.5))
+    dy = rs(3, (n, co, 2 * h, 2 * w))
+    F.conv_transpose2d(torch.relu(x), wt, None, stride=2, padding=1, output_padding=1).backward(dy)
+    assert ops.conv3x3s2_supported(n, co, ci, h, w)
+    wk = ops.pack_conv3x3(dev(wt), ocb=64)[0]
+    got = ops.conv3x3s2(dev(dy), wk, co, ci, relu_mask=dev(torch.relu(x.detach())))
+    assert relerr(got, x.grad) <= 1e-5, relerr(got, x.grad)
+    assert not ops.conv3x3s2_supported(2, 64, 64, 128, 128)
