@@ -250,11 +250,11 @@ def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=
         elif need_dx:
             pkd = _CACHE.get(layer, ('dg', 0), _ver(w), lambda: ops.pack_conv3x3_dgrad(
                 wd[:, :c1].contiguous()))
-            tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, c1, pkd[3], ksplit=1))
+            tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, c1, pkd[3], ksplit=None))
         if x2 is not None and need_dx2:
             pkd = _CACHE.get(layer, ('dg', 1), _ver(w), lambda: ops.pack_conv3x3_dgrad(
                 wd[:, c1:].contiguous()))
-            tape.add_grad(x2, ops.conv3x3(dz, pkd[0], None, cout, cin - c1, pkd[3], ksplit=1))
+            tape.add_grad(x2, ops.conv3x3(dz, pkd[0], None, cout, cin - c1, pkd[3], ksplit=None))
     tape.record(bwd)
     return y
 
