@@ -187,8 +187,12 @@ int tg_conv3x3_wino_chain(const tg_wino_layer* layers, int n_layers, int n, int 
 /* Dependent 3x3 layers of SMALL frames (the training unroll: 2 x 32 x 32 / 2 x 64 x 64 LR pixels per
  * frame, tecogan_nets.py:174-225) in ONE launch: one persistent workgroup per (image row, 32-pixel
  * segment[, 32-channel half]) walks all the layers and exchanges halo rows with its neighbours
- * through agent-scope memory + per-tile flags (tg_conv3x3_chain.hip).  Direct fp32-MFMA form, weights
- * packed by tg_conv3x3_pack with ocb = 64 (forward) or transposed = 2 (data gradient).
+ * through agent-scope memory + per-tile flags (tg_conv3x3_chain.hip).  Direct fp32-MFMA form.  The
+ * launcher picks the workgroups per tile from the shape (tg_conv3x3_chain_supported) and the weights must be
+ * packed for that choice -- pack_layout 64: tg_conv3x3_pack with ocb = 64 (transposed = 0 forward, 2 data
+ * gradient) for 1 or 2 workgroups per tile (32 x 32 x 2 MFMAs); pack_layout 16: tg_conv3x3_pack16
+ * (tg_conv3x3_pack16_floats() floats per layer) for 4 workgroups per tile (16 x 16 x 4 MFMAs, the
+ * smallest frames); a mismatch is TG_E_ARG.
  *   layers[i]: x (+ x2: channels [c1, cin)) -> y = relu_mask > 0 ? act(conv + bias) + res : 0;
  *              cin, cout <= 64; bias / res / relu_mask / x2 may be NULL; buffers may be reused along the
  *              chain in SRNet's patterns only (ping-pong, in-place residual sum).
@@ -201,7 +205,7 @@ int tg_conv3x3_wino_chain(const tg_wino_layer* layers, int n_layers, int n, int 
  *   epoch:     non-zero, different from the previous call on these flags.
  * Every workgroup must be resident at once: tg_conv3x3_chain_supported returns 0 when the grid would
  * exceed half of what the device holds (the call then fails with TG_E_SHAPE), else the number of
- * workgroups per tile it will use (1 or 2). */
+ * workgroups per tile it will use (1, 2 or 4). */
 typedef struct {
   const float* x; const float* x2; const float* w_packed; const float* bias; const float* res;
   const float* relu_mask;
@@ -211,8 +215,10 @@ typedef struct {
 } tg_chain_layer;
 int64_t tg_conv3x3_chain_flag_ints(int n_layers, int n, int h, int w);
 int tg_conv3x3_chain_supported(int n, int h, int w, int cmax);
-int tg_conv3x3_chain(const tg_chain_layer* layers, int n_layers, int n, int h, int w, int32_t* flags,
-                     int32_t* err, uint32_t epoch, int poll_limit, tg_stream_t stream);
+size_t tg_conv3x3_pack16_floats(void);
+int tg_conv3x3_pack16(const float* w, float* w_packed, int cin, int cout, int transposed, tg_stream_t stream);
+int tg_conv3x3_chain(const tg_chain_layer* layers, int n_layers, int n, int h, int w, int pack_layout,
+                     int32_t* flags, int32_t* err, uint32_t epoch, int poll_limit, tg_stream_t stream);
 /* SRNet's conv_in + nb residual blocks on one training frame (tecogan_nets.py:108-116, :141-143) and
  * the matching reverse sweep, each as one tg_conv3x3_chain launch.  acts / dz: 1 + 2*nb tensors
  * (n, nf, h, w) back to back, acts[0] = conv_in's output, acts[1+2b] / acts[2+2b] = block b's inner
@@ -222,10 +228,10 @@ int tg_conv3x3_chain(const tg_chain_layer* layers, int n_layers, int n, int h, i
  * layers[i] / dgrad[i]: forward / data-gradient packs of layer i (dgrad[0]: conv_in restricted to
  * input channels [c_lr, c_lr + c_tran), bias unused). */
 typedef struct { const float* w; const float* b; } tg_packed_layer;
-int tg_srnet_body_fwd(const tg_packed_layer* layers, int nb, const float* lr, int c_lr, const float* tran,
-                      int c_tran, float* acts, int n, int nf, int h, int w, int32_t* flags, int32_t* err,
-                      uint32_t epoch, int poll_limit, tg_stream_t stream);
-int tg_srnet_body_bwd(const tg_packed_layer* dgrad, int nb, const float* acts, float* dz,
+int tg_srnet_body_fwd(const tg_packed_layer* layers, int pack_layout, int nb, const float* lr, int c_lr,
+                      const float* tran, int c_tran, float* acts, int n, int nf, int h, int w, int32_t* flags,
+                      int32_t* err, uint32_t epoch, int poll_limit, tg_stream_t stream);
+int tg_srnet_body_bwd(const tg_packed_layer* dgrad, int pack_layout, int nb, const float* acts, float* dz,
                       float* d_tran, int c_tran, int n, int nf, int h, int w, int32_t* flags, int32_t* err,
                       uint32_t epoch, int poll_limit, tg_stream_t stream);
 

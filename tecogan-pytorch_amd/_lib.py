@@ -111,9 +111,11 @@ SIGNATURES = {
     'tg_conv3x3_wino_chain': (I, [C.POINTER(WinoLayer), I, I, I, I, I, P, I, P]),
     'tg_conv3x3_chain_flag_ints': (I64, [I, I, I, I]),
     'tg_conv3x3_chain_supported': (I, [I, I, I, I]),
-    'tg_conv3x3_chain': (I, [C.POINTER(ChainLayer), I, I, I, I, P, P, C.c_uint32, I, P]),
-    'tg_srnet_body_fwd': (I, [C.POINTER(PackedLayer), I, P, I, P, I, P, I, I, I, I, P, P, C.c_uint32, I, P]),
-    'tg_srnet_body_bwd': (I, [C.POINTER(PackedLayer), I, P, P, P, I, I, I, I, I, P, P, C.c_uint32, I, P]),
+    'tg_conv3x3_pack16_floats': (SZ, []),
+    'tg_conv3x3_pack16': (I, [P, P, I, I, I, P]),
+    'tg_conv3x3_chain': (I, [C.POINTER(ChainLayer), I, I, I, I, I, P, P, C.c_uint32, I, P]),
+    'tg_srnet_body_fwd': (I, [C.POINTER(PackedLayer), I, I, P, I, P, I, P, I, I, I, I, P, P, C.c_uint32, I, P]),
+    'tg_srnet_body_bwd': (I, [C.POINTER(PackedLayer), I, I, P, P, P, I, I, I, I, I, P, P, C.c_uint32, I, P]),
     'tg_wgrad3x3_body_workspace_floats': (SZ, [I, I, I, I, I, I]),
     'tg_wgrad3x3_body': (I, [P, P, I, I64, I, P, P, I, I, I, I, I, P]),
     'tg_bias_grad_body': (I, [P, I, I64, I, P, I, I, I, P]),

@@ -301,6 +301,183 @@ __global__ __launch_bounds__(512, 4) void conv3x3_rowchain_kernel(RowChainArgs a
   }
 }
 
+
+// ---- the 16 x 16 x 4 form: FOUR workgroups per tile (2 pixel halves x 2 channel halves) -----------
+// On the smallest frames (2 x 32 x 32: 64 row tiles) even the two-workgroup form keeps only half of
+// the SIMDs busy (128 workgroups x 8 waves on 256 CUs: 2.1 us of MFMA per layer of a 5.6 us layer).
+// v_mfma_f32_16x16x4_f32 tiles (16 channels x 16 pixels x 4 input channels) make a workgroup of
+// 16 pixels x 32 channels possible: 256 workgroups, one per CU, 36 MFMAs of 32 cycles per wave.
+//   A (weights): lane holds W[oc = 16 mb + (lane & 15)][ic = 8 chunk + 4 ks + (lane >> 4)][tap]; packed by
+//     pack3x3_m16_kernel as [oc half][chunk][tap][lane][mb * 2 + ks]: 9 16-byte loads per wave and layer;
+//   B (pixels): lane holds X[ic = 8 chunk + 4 ks + (lane >> 4)][row][px = (lane & 15) + kx]; the patch
+//     sits in LDS as [chunk][row 3][k 4][col 18][ks 2], so both k steps of a tap are ONE 8-byte read,
+//     conflict-free (16 consecutive columns per k);
+//   D: lane holds channels 16 mb + 4 (lane >> 4) + r, r = 0..3, of pixel (lane & 15).
+constexpr int R16_PW = 18;                                  // 16 pixels + halo
+constexpr int R16_CH_FLOATS = 3 * 4 * R16_PW * 2;           // 432 floats per 8-channel chunk
+
+// OIHW (transposed = 0) or the data gradient (2: channel roles swapped, taps rotated) -> the A layout
+__global__ void pack3x3_m16_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout,
+                                   int transposed) {
+  const int total = 2 * 8 * 9 * 64 * 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int e = i & 3, lane = (i >> 2) & 63;
+    int t = i >> 8;
+    const int tap = t % 9; t /= 9;
+    const int chunk = t & 7, och = t >> 3;
+    const int mb = e >> 1, ks = e & 1;
+    const int oc = och * 32 + mb * 16 + (lane & 15), ic = chunk * 8 + ks * 4 + (lane >> 4);
+    float v = 0.f;
+    if (oc < cout && ic < cin)
+      v = transposed == 2 ? w[((size_t)ic * cout + oc) * 9 + (8 - tap)] : w[((size_t)oc * cin + ic) * 9 + tap];
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(512, 4) void conv3x3_rowchain16_kernel(RowChainArgs a) {
+  constexpr int PARTS = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_in = smem;                                 // [8][R16_CH_FLOATS]
+  float* red = smem + 8 * R16_CH_FLOATS;              // [8 K groups][32 oc][16 px]
+  const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
+  const int lk = lane >> 4, lp = lane & 15;
+  int b = blockIdx.x;
+  const int part = b & 3; b >>= 2;
+  const int pxh = part & 1, och = part >> 1;
+  const int tile = b;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.h;
+  const int n = b / a.h;
+  const int x0 = tx * RC_TW + pxh * 16, y0 = ty;
+  const int hw = a.h * a.w;
+  const unsigned plane = (unsigned)hw * 4u;
+  const int g_half = tx * 2 + pxh, n_half = a.tiles_x * 2;      // this workgroup's 16-pixel column block
+  // epilogue assignment: one output per thread
+  const int e_oc = tid >> 4, e_px = tid & 15;
+  const int g_oc = och * 32 + e_oc, gx = x0 + e_px;
+
+  for (int l = 0; l < a.nlayer; ++l) {
+    const RCLayer& L = a.L[l];
+    const int nchunk = (L.cin + CK - 1) / CK;
+    RC_STAMP(0);
+    // ---- this wave's weights (its 8-channel chunk, 9 taps) and the thread's bias
+    f32x4 aw[9];
+    {
+      const f32x4* wl = reinterpret_cast<const f32x4*>(L.wpk) + ((size_t)(och * 8 + wk) * 9) * 64 + lane;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) aw[tap] = wk < nchunk ? wl[tap * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool live = g_oc < L.cout && gx < a.w;
+    const float bb = (L.bias && g_oc < L.cout) ? L.bias[g_oc] : 0.f;
+    // ---- wait: rows y-1..y+1 x column blocks g-1..g+1 x both channel halves of the previous layer
+    if (l > 0) {
+      if (tid < 18) {
+        const int p = tid & 1, nb_ = tid >> 1;
+        const int ny = ty - 1 + nb_ / 3, ng = g_half - 1 + nb_ % 3;
+        if (ny >= 0 && ny < a.h && ng >= 0 && ng < n_half) {
+          const int ntile_ = (n * a.h + ny) * a.tiles_x + (ng >> 1);
+          const unsigned* f = a.flags + ((size_t)(l - 1) * a.ntile + ntile_) * PARTS + (p * 2 + (ng & 1));
+          int polls = 0;
+          bool fault = a.poll_limit < 0;
+          while (!fault && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            fault = ++polls > a.poll_limit;
+          }
+          if (fault) __hip_atomic_fetch_add(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      __syncthreads();
+    }
+    RC_STAMP(1);
+    // ---- the patch: (channel c, row r, column) -> LDS [c >> 3][r][c & 3][col][(c >> 2) & 1]
+    {
+      const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(L.x + (long long)n * L.x_ns), 0, L.c1 * hw * 4, 0x00020000);
+      const bool dual = L.x2 != nullptr;
+      const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(dual ? L.x2 + (long long)n * L.x2_ns : L.x), 0,
+          dual ? (L.cin - L.c1) * hw * 4 : 0, 0x00020000);
+      const int total = nchunk * 8 * 3 * R16_PW;
+      auto stage = [&](auto coh) {
+        constexpr bool COH = decltype(coh)::value;
+        constexpr int MAXQ = (64 * 3 * R16_PW + 511) / 512;     // 7 per thread at 64 input channels
+        float v[MAXQ];
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) {
+          const int q = tid + k * 512;
+          const int col = q % R16_PW, t2 = q / R16_PW;
+          const int r = t2 % 3, c = t2 / 3;
+          const int gy = y0 - 1 + r, px = x0 - 1 + col;
+          const bool ok = q < total && gy >= 0 && gy < a.h && px >= 0 && px < a.w;
+          const unsigned o1 = ok ? (unsigned)((c * hw + gy * a.w + px) * 4) : RC_OOB;
+          float t = rc_ld<COH>(rs1, o1);
+          if (dual) t += rc_ld<COH>(rs2, o1 - (unsigned)L.c1 * plane);
+          v[k] = t;
+        }
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) {
+          const int q = tid + k * 512;
+          const int col = q % R16_PW, t2 = q / R16_PW;
+          const int r = t2 % 3, c = t2 / 3;
+          if (q < total) s_in[(c >> 3) * R16_CH_FLOATS + (((r * 4 + (c & 3)) * R16_PW + col) << 1) + ((c >> 2) & 1)] = v[k];
+        }
+      };
+      if (l > 0) stage(std::true_type{}); else stage(std::false_type{});
+    }
+    const long long eoff = (long long)g_oc * hw + (long long)y0 * a.w + gx;
+    float rr = 0.f, mm = 1.f;
+    if (live && L.res) {
+      const float* rp = L.res + (long long)n * L.res_ns + eoff;
+      rr = l > 0 ? __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *rp;
+    }
+    if (live && L.mask) mm = L.mask[(long long)n * L.mask_ns + eoff];
+    __syncthreads();
+    RC_STAMP(2);
+    // ---- MFMAs: this wave = input channels [8 wk, 8 wk + 8)
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (wk < nchunk) {
+      const float* si = s_in + wk * R16_CH_FLOATS + ((lk * R16_PW + lp) << 1);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const float2 bq = *reinterpret_cast<const float2*>(si + ((ky * 4 * R16_PW + kx) << 1));
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[tap][0], bq.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[tap][2], bq.x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[tap][1], bq.y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[tap][3], bq.y, acc[1], 0, 0, 0);
+      }
+    }
+    RC_STAMP(3);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wk * 32 + mb * 16 + 4 * lk + r) << 4) + lp] = acc[mb][r];
+    __syncthreads();
+    {
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) v += red[((g * 32 + e_oc) << 4) + e_px];      // fixed order
+      if (live) {
+        const float slope = act_slope(L.act);
+        float q = v + bb;
+        q = (q >= 0.f ? q : q * slope + 0.f) + rr;
+        q = mm > 0.f ? q : 0.f;
+        float* yp = L.y + (long long)n * L.y_ns;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yp, 0, L.cout * hw * 4, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q), ry, (int)((unsigned)eoff * 4u), 0, RC_SC1);
+      }
+    }
+    RC_STAMP(4);
+    __builtin_amdgcn_s_waitcnt(0);
+    RC_STAMP(5);
+    __syncthreads();
+    RC_STAMP(6);
+    if (tid == 0)
+      __hip_atomic_store(a.flags + ((size_t)l * a.ntile + tile) * PARTS + part, a.epoch, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int KG> static size_t rc_lds_bytes() {
   return (size_t)(8 * RC_IN_FLOATS + KG * (8 / KG) * 32 * RC_TW) * sizeof(float);
 }
@@ -322,27 +499,62 @@ template <int KG> static int rc_capacity() {
   return cap = per_cu * ncu;
 }
 
+static size_t rc16_lds_bytes() { return (size_t)(8 * R16_CH_FLOATS + 8 * 32 * 16) * sizeof(float); }
+static int rc16_capacity() {
+  static int cap = -1;
+  if (cap >= 0) return cap;
+  const void* fn = reinterpret_cast<const void*>(conv3x3_rowchain16_kernel);
+  int per_cu = 0, dev = 0, ncu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, rc16_lds_bytes()) != hipSuccess ||
+      hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return cap = 0;
+  }
+  return cap = per_cu * ncu;
+}
+
 }  // namespace tg
 
 using namespace tg;
 
 extern "C" int64_t tg_conv3x3_chain_flag_ints(int n_layers, int n, int h, int w) {
   if (n_layers <= 0 || n_layers > RC_MAXL || n <= 0 || h <= 0 || w <= 0) return -1;
-  return (int64_t)n_layers * n * h * cdiv(w, RC_TW) * 2;
+  return (int64_t)n_layers * n * h * cdiv(w, RC_TW) * 4;
+}
+
+extern "C" size_t tg_conv3x3_pack16_floats(void) { return (size_t)2 * 8 * 9 * 64 * 4; }
+
+extern "C" int tg_conv3x3_pack16(const float* w, float* w_packed, int cin, int cout, int transposed,
+                                 tg_stream_t stream) {
+  TG_REQUIRE(w && w_packed, TG_E_ARG, "conv3x3_pack16: null pointer");
+  TG_REQUIRE(cin > 0 && cin <= 64 && cout > 0 && cout <= 64 && (transposed == 0 || transposed == 2), TG_E_SHAPE,
+             "conv3x3_pack16: cin=%d cout=%d (<= 64) transposed=%d (0 | 2)", cin, cout, transposed);
+  hipLaunchKernelGGL(pack3x3_m16_kernel, dim3(144), dim3(256), 0, (hipStream_t)stream, w, w_packed, cin, cout, transposed);
+  return check_launch("pack3x3_m16");
 }
 
 // 0: the shape cannot run as a chained launch on this device (too many tiles to be resident at
-// once, channels > 64); else the number of workgroups per tile (1 or 2) the launcher will use.
+// once, channels > 64); else the number of workgroups per tile the launcher will use: 4 = the
+// 16 x 16 x 4 form (weights packed by tg_conv3x3_pack16), 2 / 1 = the 32 x 32 x 2 forms
+// (tg_conv3x3_pack, ocb 64).
 extern "C" int tg_conv3x3_chain_supported(int n, int h, int w, int cmax) {
   if (n <= 0 || h <= 0 || w <= 0 || cmax <= 0 || cmax > 64) return 0;
   const long long ntile = (long long)n * h * cdiv(w, RC_TW);
+  int ncu = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  // four workgroups per tile while that is at most one workgroup per CU (and resident twice over)
+  if (4 * ntile <= ncu && 2 * 4 * ntile <= rc16_capacity()) return 4;
   if (2 * ntile * 2 <= rc_capacity<8>()) return 2;
   if (2 * ntile <= rc_capacity<4>()) return 1;
   return 0;
 }
 
-extern "C" int tg_conv3x3_chain(const tg_chain_layer* layers, int n_layers, int n, int h, int w, int32_t* flags,
-                                int32_t* err, uint32_t epoch, int poll_limit, tg_stream_t stream) {
+extern "C" int tg_conv3x3_chain(const tg_chain_layer* layers, int n_layers, int n, int h, int w, int pack_layout,
+                                int32_t* flags, int32_t* err, uint32_t epoch, int poll_limit, tg_stream_t stream) {
   TG_REQUIRE(layers && flags && err, TG_E_ARG, "conv3x3_chain: null pointer");
   TG_REQUIRE(n_layers >= 1 && n_layers <= RC_MAXL, TG_E_ARG, "conv3x3_chain: %d layers (1..%d)", n_layers, RC_MAXL);
   TG_REQUIRE(n > 0 && h > 0 && w > 0, TG_E_SHAPE, "conv3x3_chain: n=%d h=%d w=%d", n, h, w);
@@ -375,7 +587,15 @@ extern "C" int tg_conv3x3_chain(const tg_chain_layer* layers, int n_layers, int 
   const int parts = tg_conv3x3_chain_supported(n, h, w, cmax);
   TG_REQUIRE(parts > 0, TG_E_SHAPE,
              "conv3x3_chain: %lld tiles cannot all be resident on this device (see tg_conv3x3_chain_supported)", ntile);
+  TG_REQUIRE(pack_layout == (parts == 4 ? 16 : 64), TG_E_ARG,
+             "conv3x3_chain: weights packed in layout %d, this shape runs with %d workgroups per tile and needs layout %d "
+             "(tg_conv3x3_chain_supported: 4 -> tg_conv3x3_pack16, 1 | 2 -> tg_conv3x3_pack with ocb 64)",
+             pack_layout, parts, parts == 4 ? 16 : 64);
   hipStream_t s = (hipStream_t)stream;
+  if (parts == 4) {
+    hipLaunchKernelGGL(conv3x3_rowchain16_kernel, dim3((unsigned)(ntile * 4)), dim3(512), rc16_lds_bytes(), s, a);
+    return check_launch("conv3x3_chain16");
+  }
   if (parts == 2)
     hipLaunchKernelGGL(conv3x3_rowchain_kernel<8>, dim3((unsigned)(ntile * 2)), dim3(512), rc_lds_bytes<8>(), s, a);
   else
@@ -402,9 +622,9 @@ static int body_common(int nb, int n, int nf, int h, int w, const void* a, const
   return TG_OK;
 }
 
-extern "C" int tg_srnet_body_fwd(const tg_packed_layer* layers, int nb, const float* lr, int c_lr, const float* tran,
-                                 int c_tran, float* acts, int n, int nf, int h, int w, int32_t* flags, int32_t* err,
-                                 uint32_t epoch, int poll_limit, tg_stream_t stream) {
+extern "C" int tg_srnet_body_fwd(const tg_packed_layer* layers, int pack_layout, int nb, const float* lr, int c_lr,
+                                 const float* tran, int c_tran, float* acts, int n, int nf, int h, int w,
+                                 int32_t* flags, int32_t* err, uint32_t epoch, int poll_limit, tg_stream_t stream) {
   if (int rc = body_common(nb, n, nf, h, w, layers, lr, acts)) return rc;
   TG_REQUIRE(tran && c_lr > 0 && c_tran > 0 && c_lr + c_tran <= 64, TG_E_ARG, "srnet_body_fwd: c_lr=%d c_tran=%d", c_lr, c_tran);
   const int64_t hw = (int64_t)h * w, ns = (int64_t)nf * hw, ts = (int64_t)n * ns;
@@ -424,10 +644,10 @@ extern "C" int tg_srnet_body_fwd(const tg_packed_layer* layers, int nb, const fl
     d.c1 = first ? c_lr : nf; d.cin = first ? c_lr + c_tran : nf; d.cout = nf;
     d.act = conv2 ? TG_ACT_NONE : TG_ACT_RELU;
   }
-  return tg_conv3x3_chain(cl, 1 + 2 * nb, n, h, w, flags, err, epoch, poll_limit, stream);
+  return tg_conv3x3_chain(cl, 1 + 2 * nb, n, h, w, pack_layout, flags, err, epoch, poll_limit, stream);
 }
 
-extern "C" int tg_srnet_body_bwd(const tg_packed_layer* dgrad, int nb, const float* acts, float* dz,
+extern "C" int tg_srnet_body_bwd(const tg_packed_layer* dgrad, int pack_layout, int nb, const float* acts, float* dz,
                                  float* d_tran, int c_tran, int n, int nf, int h, int w, int32_t* flags, int32_t* err,
                                  uint32_t epoch, int poll_limit, tg_stream_t stream) {
   if (int rc = body_common(nb, n, nf, h, w, dgrad, dz, acts)) return rc;
@@ -460,5 +680,5 @@ extern "C" int tg_srnet_body_bwd(const tg_packed_layer* dgrad, int nb, const flo
     d.x = dz; d.w_packed = dgrad[0].w; d.y = d_tran;
     d.x_nstride = ns; d.y_nstride = (int64_t)c_tran * hw; d.c1 = nf; d.cin = nf; d.cout = c_tran; d.act = TG_ACT_NONE;
   }
-  return tg_conv3x3_chain(cl, k, n, h, w, flags, err, epoch, poll_limit, stream);
+  return tg_conv3x3_chain(cl, k, n, h, w, pack_layout, flags, err, epoch, poll_limit, stream);
 }

@@ -319,15 +319,21 @@ class _ChainState:
         return fl, cls.err, cls.epoch
 
     @classmethod
-    def usable(cls, n, nf, cin0, h, w):
-        if cls.disabled or nf > 64 or cin0 > 64:
-            return False
+    def parts(cls, n, h, w):
+        """workgroups per tile the launcher uses for this shape (0: not supported): 4 needs the
+        16 x 16 x 4 weight layout (ops.pack_conv3x3_m16), 1 / 2 the 64-channel-block layout."""
         key = (n, h, w)
         r = cls.supported.get(key)
         if r is None:
             from .. import _lib as L
-            r = cls.supported[key] = L.lib().tg_conv3x3_chain_supported(n, h, w, 64) > 0
+            r = cls.supported[key] = int(L.lib().tg_conv3x3_chain_supported(n, h, w, 64))
         return r
+
+    @classmethod
+    def usable(cls, n, nf, cin0, h, w):
+        if cls.disabled or nf > 64 or cin0 > 64:
+            return False
+        return cls.parts(n, h, w) > 0
 
 
 def chain_check():
@@ -359,17 +365,21 @@ def srnet_body(tape, srnet, lr, tran):
     c_tran, nf = tran.shape[1], conv_in.cout
     fw = (L.PackedLayer * nl)()
     keep = []
+    layout = 16 if _ChainState.parts(n, h, w) == 4 else 64
     for i, m in enumerate(layers):
-        pk, ocb = m.packed()
-        if ocb != 64:         # the chained kernel reads the 64-channel-block layout whatever cout is
-            pk = _CACHE.get(m, ('fw64',), _ver(m.weight),
-                            lambda m=m: ops.pack_conv3x3(m.weight.detach().contiguous(), ocb=64)[0])
+        if layout == 16:
+            pk = _CACHE.get(m, ('fw16',), _ver(m.weight), lambda m=m: ops.pack_conv3x3_m16(m.weight))
+        else:
+            pk, ocb = m.packed()
+            if ocb != 64:         # the chained kernel reads the 64-channel-block layout whatever cout is
+                pk = _CACHE.get(m, ('fw64',), _ver(m.weight),
+                                lambda m=m: ops.pack_conv3x3(m.weight.detach().contiguous(), ocb=64)[0])
         keep.append(pk)
         fw[i].w, fw[i].b = pk.data_ptr(), m.bias.data_ptr()
     acts = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=lr.device)
     flags, err, epoch = _ChainState.buffers(nl + 1, n, h, w, lr.device)
     st = ops._stream()
-    L.check(L.lib().tg_srnet_body_fwd(fw, nb, lr.data_ptr(), c_lr, tran.data_ptr(), c_tran, acts.data_ptr(),
+    L.check(L.lib().tg_srnet_body_fwd(fw, layout, nb, lr.data_ptr(), c_lr, tran.data_ptr(), c_tran, acts.data_ptr(),
                                       n, nf, h, w, flags.data_ptr(), err.data_ptr(), epoch,
                                       _ChainState.poll_limit, st), 'tg_srnet_body_fwd')
     out = acts[nl - 1]
@@ -385,21 +395,32 @@ def srnet_body(tape, srnet, lr, tran):
         w_in = conv_in.weight
         # (ocb = 64 explicitly: pack_conv3x3_dgrad would pick the 32-channel layout for c_tran <= 32,
         #  e.g. the 12 warped-frame channels of a 2x model)
-        pk0 = _CACHE.get(conv_in, ('dg64', 1), _ver(w_in), lambda: ops.pack_conv3x3_dgrad(
-            w_in.detach()[:, c_lr:].contiguous(), ocb=64))
-        hold.append(pk0)
-        dg[0].w = pk0[0].data_ptr()
+        if layout == 16:
+            pk0 = _CACHE.get(conv_in, ('dg16', 1), _ver(w_in),
+                             lambda: ops.pack_conv3x3_m16(w_in.detach()[:, c_lr:].contiguous(), transposed=2))
+            hold.append(pk0)
+            dg[0].w = pk0.data_ptr()
+        else:
+            pk0 = _CACHE.get(conv_in, ('dg64', 1), _ver(w_in), lambda: ops.pack_conv3x3_dgrad(
+                w_in.detach()[:, c_lr:].contiguous(), ocb=64))
+            hold.append(pk0)
+            dg[0].w = pk0[0].data_ptr()
         for i, m in enumerate(layers[1:], 1):
             wm = m.weight
-            pk = _CACHE.get(m, ('dg64', 0), _ver(wm),
-                            lambda wm=wm: ops.pack_conv3x3_dgrad(wm.detach().contiguous(), ocb=64))
-            hold.append(pk)
-            dg[i].w = pk[0].data_ptr()
+            if layout == 16:
+                pk = _CACHE.get(m, ('dg16', 0), _ver(wm), lambda wm=wm: ops.pack_conv3x3_m16(wm, transposed=2))
+                hold.append(pk)
+                dg[i].w = pk.data_ptr()
+            else:
+                pk = _CACHE.get(m, ('dg64', 0), _ver(wm),
+                                lambda wm=wm: ops.pack_conv3x3_dgrad(wm.detach().contiguous(), ocb=64))
+                hold.append(pk)
+                dg[i].w = pk[0].data_ptr()
         dz = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=g.device)
         dz[nl - 1].copy_(g)       # the gradient of the body's output lives in the block's last slot
         d_tran = torch.empty(n, c_tran, h, w, dtype=torch.float32, device=g.device)
         fl, er, ep = _ChainState.buffers(nl + 1, n, h, w, g.device)
-        L.check(L.lib().tg_srnet_body_bwd(dg, nb, acts.data_ptr(), dz.data_ptr(), d_tran.data_ptr(),
+        L.check(L.lib().tg_srnet_body_bwd(dg, layout, nb, acts.data_ptr(), dz.data_ptr(), d_tran.data_ptr(),
                                           c_tran, n, nf, h, w, fl.data_ptr(), er.data_ptr(), ep,
                                           _ChainState.poll_limit, ops._stream()),
                 'tg_srnet_body_bwd')

@@ -150,6 +150,19 @@ def conv3x3_phased(x, wpk, cin, cout, ocb, tapsel, cphase, taps_phase0, taps_pha
     return out
 
 
+def pack_conv3x3_m16(weight, transposed=0):
+    """tg_conv3x3_pack16: the A-operand layout of the 16 x 16 x 4 chained kernel (cin, cout <= 64);
+    transposed = 2: the data gradient (channel roles swapped, taps rotated)."""
+    w = _chk(weight.detach().contiguous(), 'weight')
+    cout, cin = w.shape[0], w.shape[1]
+    out = torch.empty(L.lib().tg_conv3x3_pack16_floats(), dtype=torch.float32, device=w.device)
+    if transposed == 2:
+        L.check(L.lib().tg_conv3x3_pack16(w.data_ptr(), out.data_ptr(), cout, cin, 2, _stream()), 'tg_conv3x3_pack16')
+    else:
+        L.check(L.lib().tg_conv3x3_pack16(w.data_ptr(), out.data_ptr(), cin, cout, 0, _stream()), 'tg_conv3x3_pack16')
+    return out
+
+
 def conv3x3s2_supported(n, cin, cout, h_out, w_out):
     return bool(L.lib().tg_conv3x3s2_supported(n, cin, cout, h_out, w_out))
 

@@ -9,7 +9,9 @@ hw = int(os.environ.get('HW', '32')); n, nb, nf = 2, 10, 64
 nl = 1 + 2 * nb
 lib = L.lib()
 ws = [torch.randn(64, 51 if i == 0 else 64, 3, 3, device='cuda') * 0.03 for i in range(nl)]
-pk = [ops.pack_conv3x3(w)[0] for w in ws]
+parts = lib.tg_conv3x3_chain_supported(n, hw, hw, 64)
+layout = 16 if parts == 4 else 64
+pk = [ops.pack_conv3x3_m16(w) if layout == 16 else ops.pack_conv3x3(w, ocb=64)[0] for w in ws]
 bs = [torch.zeros(64, device='cuda') for _ in range(nl)]
 fw = (L.PackedLayer * nl)()
 for i in range(nl):
@@ -21,16 +23,16 @@ flags = torch.zeros(nfl + 2 * 24 * 8 + 64, dtype=torch.int32, device='cuda')
 err = torch.zeros(16, dtype=torch.int32).pin_memory()
 st = torch.cuda.current_stream().cuda_stream
 for ep in range(1, 6):
-    L.check(lib.tg_srnet_body_fwd(fw, nb, lr.data_ptr(), 3, tran.data_ptr(), 48, acts.data_ptr(), n, nf, hw, hw,
+    L.check(lib.tg_srnet_body_fwd(fw, layout, nb, lr.data_ptr(), 3, tran.data_ptr(), 48, acts.data_ptr(), n, nf, hw, hw,
                                   flags.data_ptr(), err.data_ptr(), ep, 1 << 21, st), 'fwd')
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for ep in range(6, 26):
-    L.check(lib.tg_srnet_body_fwd(fw, nb, lr.data_ptr(), 3, tran.data_ptr(), 48, acts.data_ptr(), n, nf, hw, hw,
+    L.check(lib.tg_srnet_body_fwd(fw, layout, nb, lr.data_ptr(), 3, tran.data_ptr(), 48, acts.data_ptr(), n, nf, hw, hw,
                                   flags.data_ptr(), err.data_ptr(), ep, 1 << 21, st), 'fwd')
 e1.record(); torch.cuda.synchronize()
-print(f'hw={hw}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per 21-layer launch, faults {int(err[0])}')
+print(f'hw={hw} parts={parts}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per 21-layer launch, faults {int(err[0])}')
 dbg = flags[nfl:nfl + 2 * 24 * 8].view(torch.int64).cpu().view(24, 8)[:nl].double() / 2.3     # ns (the counter runs at the ~2.3 GHz shader clock here)
 d = dbg[1:-1]                      # steady-state layers
 names = ['wait flags', 'stage patch', 'MFMA', 'reduce+epilogue', 'store ack', 'barrier', 'flag->next top']
