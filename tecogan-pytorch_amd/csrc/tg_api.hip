@@ -146,7 +146,6 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   p->WZ = workspace + off[11]; p->wz_ready = false;
   p->CHAINF = reinterpret_cast<int32_t*>(workspace + off[12]); p->chain_ready = false; p->epoch = 0; p->chain_layers = 0;
   p->chain_err = nullptr; p->chain_disabled = false; p->chain_faults = 0; p->chain_poll_limit = tg::TG_CHAIN_POLL_LIMIT_DEFAULT;
-#ifndef TG_EXP_NO_HOSTALLOC
   if (!cfg->fnet_only) {
     void* hp = nullptr;
     if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hp) {
@@ -156,7 +155,6 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
       (void)hipGetLastError();      // no fault channel -> no chained launch (per-layer launches are always safe)
     }
   }
-#endif
   p->FA = workspace + off[7]; p->FB = workspace + off[8]; p->FPART = workspace + off[9];
   p->FLOW2 = workspace + off[10];
   p->PART = workspace + off[6];

@@ -843,6 +843,48 @@ def conv3x3_wino(x, u_packed, bias, cin, cout, act=ACT_NONE, x2=None, res=None, 
     return y
 
 
+class RowChain:
+    """tg_conv3x3_chain: dependent 3x3 layers of small frames in one persistent launch.  `layers` is a
+    list of dicts (x, w (OIHW weight tensor), bias=None, act=ACT_NONE, x2=None, res=None, mask=None, y);
+    the weights are packed here in the layout the launcher's choice for this shape needs."""
+
+    def __init__(self, layers, n, h, w):
+        lib = L.lib()
+        self.n, self.h, self.w = n, h, w
+        self.parts = lib.tg_conv3x3_chain_supported(n, h, w, 64)
+        if self.parts == 0:
+            raise L.TecoganHipError(f'RowChain: {n}x{h}x{w} cannot run as a chained launch on this device')
+        self.layout = 16 if self.parts == 4 else 64
+        self.keep = [layers]
+        self.arr = (L.ChainLayer * len(layers))()
+        for i, d in enumerate(layers):
+            a = self.arr[i]
+            wt = d['w']
+            pk = pack_conv3x3_m16(wt) if self.layout == 16 else pack_conv3x3(wt, ocb=64)[0]
+            self.keep.append(pk)
+            x, x2, res, mask, y = d['x'], d.get('x2'), d.get('res'), d.get('mask'), d['y']
+            a.x, a.x2, a.w_packed, a.bias = x.data_ptr(), _ptr(x2), pk.data_ptr(), _ptr(d.get('bias'))
+            a.res, a.relu_mask, a.y = _ptr(res), _ptr(mask), y.data_ptr()
+            a.x_nstride, a.y_nstride = x.stride(0), y.stride(0)
+            a.x2_nstride = x2.stride(0) if x2 is not None else 0
+            a.res_nstride = res.stride(0) if res is not None else 0
+            a.mask_nstride = mask.stride(0) if mask is not None else 0
+            a.c1, a.cin, a.cout, a.act = x.shape[1], wt.shape[1], wt.shape[0], d.get('act', ACT_NONE)
+        self.nl = len(layers)
+        self.flags = torch.zeros(lib.tg_conv3x3_chain_flag_ints(self.nl, n, h, w) + 16, dtype=torch.int32,
+                                 device=layers[0]['x'].device)
+        self.err = self.flags[-16:]
+        self.epoch = 0
+
+    def run(self, poll_limit=1 << 21):
+        self.epoch += 1
+        L.check(L.lib().tg_conv3x3_chain(self.arr, self.nl, self.n, self.h, self.w, self.layout, self.flags.data_ptr(),
+                                         self.err.data_ptr(), self.epoch, poll_limit, _stream()), 'tg_conv3x3_chain')
+
+    def faults(self):
+        return int(self.err[0].item())
+
+
 class WinoChain:
     """tg_conv3x3_wino_chain: dependent 3x3 layers in one launch.  `layers` is a list of dicts
     (x, u, bias, cin, act, x2=None, res=None, y) of device tensors; the flag buffer and the epoch

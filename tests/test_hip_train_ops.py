@@ -601,3 +601,77 @@ def test_convt_data_gradient_as_stride2_conv(ops, n, ci, co, h, w):
     got = ops.conv3x3s2(dev(dy), wk, co, ci, relu_mask=dev(torch.relu(x.detach())))
     assert relerr(got, x.grad) <= 1e-5, relerr(got, x.grad)
     assert not ops.conv3x3s2_supported(2, 64, 64, 128, 128)
+
+
+@pytest.mark.parametrize('n,h,w', [(2, 32, 32), (2, 64, 64), (3, 9, 70), (1, 20, 37)])
+def test_row_chain_with_reused_buffers_equals_layer_launches(ops, n, h, w):
+    """tg_conv3x3_chain in SRNet's INFERENCE buffer pattern -- two ping-pong tensors and in-place
+    residual sums (include/tecogan_hip.h: 'buffers may be reused along the chain in SRNet's patterns') --
+    in all three workgroup forms, launch after launch, against one launch per layer: a write-after-read
+    race or a lost flag would show as a mismatch."""
+    g = torch.Generator().manual_seed(23)
+    nb = 4
+    lr, s2d = dev(torch.rand(n, 3, h, w, generator=g)), dev(torch.rand(n, 48, h, w, generator=g))
+    ws = [dev(torch.randn(64, 51, 3, 3, generator=g) * 0.04)] + \
+         [dev(torch.randn(64, 64, 3, 3, generator=g) * 0.03) for _ in range(2 * nb)]
+    bs = [dev(torch.randn(64, generator=g) * 0.1) for _ in range(2 * nb + 1)]
+    pks = [ops.pack_conv3x3(x, ocb=64) for x in ws]
+
+    def make(A, B):
+        layers = [dict(x=lr, x2=s2d, w=ws[0], bias=bs[0], act=1, y=A)]
+        for b in range(nb):
+            layers.append(dict(x=A, w=ws[1 + 2 * b], bias=bs[1 + 2 * b], act=1, y=B))
+            layers.append(dict(x=B, w=ws[2 + 2 * b], bias=bs[2 + 2 * b], act=0, res=A, y=A))
+        return layers
+    A1, B1, A2, B2 = (torch.empty(n, 64, h, w, device='cuda') for _ in range(4))
+    seq, chain = make(A1, B1), ops.RowChain(make(A2, B2), n, h, w)
+    for it in range(6):
+        lr.uniform_(); s2d.uniform_()
+        for i, d in enumerate(seq):
+            ops.conv3x3(d['x'], pks[i][0], d['bias'], d['w'].shape[1], 64, 64, d['act'], x2=d.get('x2'),
+                        res=d.get('res'), out=d['y'], ksplit=1)
+        chain.run()
+        torch.cuda.synchronize()
+        assert relerr(A2, A1) <= 2e-5 and relerr(B2, B1) <= 2e-5, (it, chain.parts, relerr(A2, A1), relerr(B2, B1))
+        if it:
+            assert torch.equal(A2, prev_a) is False        # (new inputs every iteration)
+        prev_a = A2.clone()
+    assert chain.faults() == 0
+    with pytest.raises(Exception):                          # weights in the wrong layout are refused
+        from tecogan_pytorch_amd import _lib as L
+        L.check(L.lib().tg_conv3x3_chain(chain.arr, chain.nl, n, h, w, 16 if chain.layout == 64 else 64,
+                                         chain.flags.data_ptr(), chain.err.data_ptr(), 999, 1 << 21, None), 'layout')
+
+
+def test_body_weight_and_bias_gradients_in_one_launch(ops):
+    """tg_wgrad3x3_body / tg_bias_grad_body over per-frame blocks against one wgrad3x3_multi /
+    bias_grad_multi per layer."""
+    nf, nl, n, h, w, frames = 64, 7, 2, 16, 24, 5
+    acts = [dev(rs(10 + f, (nl, n, nf, h, w))) for f in range(frames)]
+    dz = [dev(rs(50 + f, (nl, n, nf, h, w))) for f in range(frames)]
+    grads = [torch.zeros(nf, nf, 3, 3, device='cuda') for _ in range(nl - 1)]
+    dbs = [torch.zeros(nf, device='cuda') for _ in range(nl)]
+    ops.wgrad3x3_body(dz, acts, grads)
+    ops.bias_grad_body(dz, dbs)
+    for L_ in range(1, nl):
+        ref = torch.zeros(nf, nf, 3, 3, device='cuda')
+        ops.wgrad3x3_multi([d[L_] for d in dz], [a[L_ - 1] for a in acts], ref)
+        assert relerr(grads[L_ - 1], ref) <= 2e-5, (L_, relerr(grads[L_ - 1], ref))
+    for L_ in range(nl):
+        ref = torch.zeros(nf, device='cuda')
+        ops.bias_grad_multi([d[L_] for d in dz], ref)
+        assert relerr(dbs[L_], ref) <= 1e-5, L_
+    ops.wgrad3x3_body(dz, acts, grads)                      # accumulate doubles
+    ref = torch.zeros(nf, nf, 3, 3, device='cuda')
+    ops.wgrad3x3_multi([d[1] for d in dz], [a[0] for a in acts], ref)
+    assert relerr(grads[0], 2 * ref) <= 2e-5
+
+
+def test_div_scalar_is_ieee_division(ops):
+    x = dev(rs(3, (1000,), -5, 5))
+    y = x.clone()
+    ops.div_scalar_(y, 3.0)
+    assert torch.equal(y.cpu(), x.cpu() / 3.0)        # (the host's division: torch's device kernel multiplies by 1/3)
+    z = torch.empty_like(x)
+    ops.div_scalar_(z, 7.0, x)
+    assert torch.equal(z.cpu(), x.cpu() / 7.0)
