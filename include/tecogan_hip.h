@@ -113,7 +113,7 @@ int tg_conv3x3_fwd_phased(const float* x, int64_t x_nstride, const float* w_pack
  * zero outside x (n, cin, 2 h_out, 2 w_out) -- the data gradient of ConvTranspose2d(k3, s2, p1, op1)
  * (tecogan_nets.py:119-126) taken directly (K = 9 cin) instead of through the 4 cin-channel phased
  * embedding; w_packed = tg_conv3x3_pack(W as (cout = ci, cin = co), ocb 64).  relu_mask as in
- * tg_conv3x3_fwd_masked.  tg_conv3x3s2_supported: cin, cout <= 64 and <= 256 one-row tiles. */
+ * tg_conv3x3_fwd_masked.  tg_conv3x3s2_supported: cin, cout <= 64 and <= 1024 one-row tiles. */
 int tg_conv3x3s2_supported(int n, int cin, int cout, int h_out, int w_out);
 int tg_conv3x3s2_fwd(const float* x, int64_t x_nstride, const float* w_packed, const float* bias,
                      const float* relu_mask, int64_t mask_nstride, float* y, int64_t y_nstride, int n,

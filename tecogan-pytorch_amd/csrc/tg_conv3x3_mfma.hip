@@ -1031,10 +1031,12 @@ extern "C" int tg_conv3x3_fwd_phased_masked(const float* x, int64_t x_nstride, c
                       taps_phase1);
 }
 
-// shapes the stride-2 one-shot kernel takes: one 64-channel block, cin <= 64, at most 256 one-row tiles
+// shapes the stride-2 one-shot kernel takes: one 64-channel block, cin <= 64, at most 1024 one-row tiles
+// (two workgroups per CU: two rounds; measured against the phased form on s2d(x) in tools/time_ops.py)
+static const int S2_MAX_TILES = 1024;
 extern "C" int tg_conv3x3s2_supported(int n, int cin, int cout, int h_out, int w_out) {
   if (n <= 0 || cin <= 0 || cin > 64 || cout <= 0 || cout > 64 || h_out <= 0 || w_out <= 0) return 0;
-  return (long long)n * h_out * cdiv(w_out, TW) <= 256 ? 1 : 0;
+  return (long long)n * h_out * cdiv(w_out, TW) <= S2_MAX_TILES ? 1 : 0;
 }
 
 extern "C" int tg_conv3x3s2_fwd(const float* x, int64_t x_nstride, const float* w_packed, const float* bias,
@@ -1042,7 +1044,7 @@ extern "C" int tg_conv3x3s2_fwd(const float* x, int64_t x_nstride, const float* 
                                 int cin, int cout, int h_out, int w_out, int act, tg_stream_t stream) {
   TG_REQUIRE(x && w_packed && y, TG_E_ARG, "conv3x3s2_fwd: null pointer");
   TG_REQUIRE(tg_conv3x3s2_supported(n, cin, cout, h_out, w_out), TG_E_SHAPE,
-             "conv3x3s2_fwd: n=%d cin=%d cout=%d out %dx%d (cin, cout <= 64, <= 256 row tiles)", n, cin, cout, h_out, w_out);
+             "conv3x3s2_fwd: n=%d cin=%d cout=%d out %dx%d (cin, cout <= 64, <= 1024 row tiles)", n, cin, cout, h_out, w_out);
   TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_LRELU02, TG_E_ARG, "conv3x3s2_fwd: act=%d", act);
   TG_REQUIRE((long long)(cin + CK) * 4 * h_out * w_out * 4 < (1ll << 31), TG_E_SHAPE, "conv3x3s2_fwd: item too large");
   Conv3x3Args a{};

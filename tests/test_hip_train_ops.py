@@ -588,7 +588,8 @@ def test_space_to_depth_vector_path_is_a_permutation(ops, n, c, h, w, s):
     assert torch.equal(ops.depth_to_space(y, s).cpu(), x)
 
 
-@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 32), (2, 64, 64, 64, 64), (1, 24, 40, 9, 21), (3, 64, 16, 5, 40)])
+@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 32), (2, 64, 64, 64, 64), (1, 24, 40, 9, 21), (3, 64, 16, 5, 40),
+                                          (2, 64, 64, 128, 128)])
 def test_convt_data_gradient_as_stride2_conv(ops, n, ci, co, h, w):
     """tg_conv3x3s2_fwd: dX of ConvTranspose2d(ci, co, 3, 2, 1, 1) taken directly from dY (and the
     ReLU-backward mask of the layer below in the same epilogue) against autograd."""
@@ -600,7 +601,7 @@ def test_convt_data_gradient_as_stride2_conv(ops, n, ci, co, h, w):
     wk = ops.pack_conv3x3(dev(wt), ocb=64)[0]
     got = ops.conv3x3s2(dev(dy), wk, co, ci, relu_mask=dev(torch.relu(x.detach())))
     assert relerr(got, x.grad) <= 1e-5, relerr(got, x.grad)
-    assert not ops.conv3x3s2_supported(2, 64, 64, 128, 128)
+    assert not ops.conv3x3s2_supported(8, 64, 64, 256, 256)
 
 
 @pytest.mark.parametrize('n,h,w', [(2, 32, 32), (2, 64, 64), (3, 9, 70), (1, 20, 37)])
