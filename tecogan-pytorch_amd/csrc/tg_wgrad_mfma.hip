@@ -22,6 +22,7 @@
 
 namespace tg {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int WG_R = 2;                 // rows per pixel tile
 constexpr int WG_TW = 32;               // cols per pixel tile
 constexpr int WG_CSA = WG_R * WG_TW + 4;         // 68: A channel stride (floats), 17 slots (odd)
@@ -68,11 +69,32 @@ __host__ __device__ constexpr bool wtap_on(int code, int k) {
          (code == WTAPS_1 && k == 1);
 }
 
-template <int RY, int RX>
+// Tile geometry of one workgroup step: R rows x TW columns of P pixels (K of the GEMM) and the Q patch
+// they meet.  <2, 32>: the general form.  <4, 16> / <8, 8>: the same 64 pixels folded for narrow maps
+// (FNet's 16 x 16 and 8 x 8 levels waste 50-75 % of a 32-column tile).  S2: Q is sampled with stride 2,
+//   G[a][b][ky][kx] = sum P[n][a][y][x] * Q[n][b][2y - 1 + ky][2x - 1 + kx]
+// -- the weight gradient of ConvTranspose2d(k3, s2, p1, op1) (tecogan_nets.py:119-126; P = its input,
+// Q = dZ at twice the resolution) taken straight from dZ: one row of 32 pixels meets a 3 x 65 patch.
+template <int R_, int TW_, int S2_>
+struct WgGeo {
+  static constexpr int R = R_, TW = TW_, S2 = S2_;
+  static constexpr int PIX = R * TW;
+  static constexpr int CSA = PIX + 4;                       // A channel stride (floats)
+  static constexpr int BR = S2 ? 2 * R + 1 : R + 2;         // Q patch rows / columns
+  static constexpr int BC = S2 ? 2 * TW + 1 : TW + 2;
+  static constexpr int RSB = S2 ? BC + 2 : TW + 3;          // B row stride
+  static constexpr int CSB = (BR * RSB) | 1;                // odd channel stride -> conflict free
+  static constexpr int A_FLOATS = 64 * CSA, B_FLOATS = 64 * CSB;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)(A_FLOATS + B_FLOATS) * sizeof(float);
+};
+using WgGeoStd = WgGeo<WG_R, WG_TW, 0>;
+static_assert(WgGeoStd::CSA == WG_CSA && WgGeoStd::RSB == WG_RSB && WgGeoStd::CSB == WG_CSB, "geometry");
+
+template <int RY, int RX, class G = WgGeoStd, bool VEC = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem;                          // [2][WG_A_FLOATS]
-  float* sB = smem + 2 * WG_A_FLOATS;        // [2][WG_B_FLOATS]
+  float* sA = smem;                          // [2][A_FLOATS]
+  float* sB = smem + 2 * G::A_FLOATS;        // [2][B_FLOATS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cot = wave & 1, cit = wave >> 1;
@@ -84,6 +106,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   const int a0 = ab * 64, b0 = bb * 64;
   const int hw = a.h * a.w;
   const unsigned plane = (unsigned)hw * 4u;
+  const int hq = G::S2 ? 2 * a.h : a.h, wq = G::S2 ? 2 * a.w : a.w;
+  const unsigned planeq = (unsigned)(hq * wq) * 4u;
 
   f32x16 acc[9];
 #pragma unroll
@@ -92,19 +116,49 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int lh = lane >> 5, ll = lane & 31;
-  const int a_rd = (cot * 32 + ll) * WG_CSA + 4 * lh;
-  const int b_rd = (cit * 32 + ll) * WG_CSB + 4 * lh;
+  const int a_rd = (cot * 32 + ll) * G::CSA + 4 * lh;
+  const int b_rd = (cit * 32 + ll) * G::CSB + (G::S2 ? 8 : 4) * lh;
 
-  constexpr int A_PER_T = (64 * WG_R * WG_TW) / 256;                 // 16
-  constexpr int B_ELEMS = 64 * (WG_R + 2) * (WG_TW + 2);            // 8704
-  constexpr int B_PER_T = B_ELEMS / 256;                             // 34
-  float ra[A_PER_T], rb[B_PER_T];
+  // ---- staging, element-wise form (any width / alignment) ------------------------------------
+  constexpr int A_PER_T = (64 * G::PIX) / 256;                       // 16 (8 for the stride-2 form)
+  constexpr int B_ELEMS = 64 * G::BR * G::BC;                        // 8704 for <2, 32>
+  constexpr int B_PER_T = (B_ELEMS + 255) / 256;                     // 34
+  constexpr bool B_EXACT = B_ELEMS % 256 == 0;
+  // ---- staging, vector form (w % 4 == 0, 16-byte aligned planes): the rows of a tile are read as
+  // aligned 16-byte groups (8-byte pairs in the stride-2 form, whose patch starts at an even
+  // column), position (row, group) is a per-THREAD constant and the loop walks channels -- one add
+  // per load and immediate LDS offsets instead of ~20 index instructions per element (the staging
+  // skeleton was ~19 % of the launch), and 3.4x fewer memory instructions.
+  //   A: PIX / 4 groups per channel, thread -> group tid % (PIX/4), channels tid / (PIX/4) + CSTEP * i
+  //   B: KG = (TW + 8) / 4 groups per row from column x0 - 4, padded to a power of two KGP; thread ->
+  //      (k = tid % KGP, r = tid / KGP % (64 / KGP)), its wave owns 16 channels
+  //   B, stride 2: 33 pairs per row from column 2 x0 - 2; thread -> position tid % 128 of the 3 x 33,
+  //      its half of the workgroup owns 32 channels
+  constexpr int VW = G::S2 ? 2 : 4;                                  // floats per B load
+  constexpr int AV_PER_T = G::PIX / 16, A_CSTEP = 1024 / G::PIX;     // 4 loads, channels 16 apart (2 / 32)
+  constexpr int KG = G::S2 ? 33 : (G::TW + 8) / 4;
+  constexpr int KGP = KG <= 4 ? 4 : (KG <= 8 ? 8 : 16);
+  constexpr int BV_PER_T = G::S2 ? 32 : 16;
+  static_assert(G::S2 || 64 / KGP >= G::BR, "patch rows must fit the 64 positions of a wave");
+  constexpr int RA_N = VEC ? AV_PER_T * 4 : A_PER_T, RB_N = VEC ? BV_PER_T * VW : B_PER_T;
+  float ra[RA_N], rb[RB_N];
+  // per-thread constants of the vector form
+  const int va_k = tid % (G::TW / 4), va_r = (tid / (G::TW / 4)) % G::R, va_c = tid / (G::PIX / 4);
+  int vb_k, vb_r, vb_c;
+  bool vb_on;
+  if (G::S2) {
+    const int pos = tid & 127;
+    vb_r = pos / 33; vb_k = pos - vb_r * 33; vb_c = (tid >> 7) * 32; vb_on = pos < 99;
+  } else {
+    vb_k = tid & (KGP - 1); vb_r = (tid / KGP) & (64 / KGP - 1); vb_c = (tid >> 6) * 16;
+    vb_on = vb_k < KG && vb_r < G::BR;
+  }
 
   auto load_tile = [&](int tile) {
     int n = tile / (a.tiles_x * a.tiles_y);
     int rem = tile - n * (a.tiles_x * a.tiles_y);
     int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
-    int x0 = tx * WG_TW, y0 = ty * WG_R;
+    int x0 = tx * G::TW, y0 = ty * G::R;
     const int seg = __builtin_amdgcn_readfirstlane(n / a.n_per_seg);
     const int ln = __builtin_amdgcn_readfirstlane(n - seg * a.n_per_seg);
     const float* pbase = a.pseg[seg];
@@ -116,11 +170,43 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(pbase + (long long)ln * a.p_ns), 0, a.ca * hw * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(qbase + (long long)ln * a.q_ns), 0, a.cb * hw * 4, 0x00020000);
+        const_cast<float*>(qbase + (long long)ln * a.q_ns), 0, a.cb * hq * wq * 4, 0x00020000);
+    if constexpr (VEC) {
+      {
+        const int gy = y0 + va_r, gx = x0 + 4 * va_k;
+        const bool ok = gy < a.h && gx < a.w;                  // w % 4 == 0: a group is inside or outside
+        const unsigned off0 = ok ? ((unsigned)(a0 + va_c) * plane + (unsigned)(gy * a.w + gx) * 4u) : WG_OOB;
+#pragma unroll
+        for (int i = 0; i < AV_PER_T; ++i) {                   // (channel tail: past num_records -> 0)
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+              rp, (int)(off0 + (unsigned)(i * A_CSTEP) * plane), 0, 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ra[4 * i + e] = v[e];
+        }
+      }
+      {
+        const int gy = (G::S2 ? 2 * y0 : y0) - 1 + vb_r;
+        const int gx = G::S2 ? 2 * x0 - 2 + 2 * vb_k : x0 - 4 + 4 * vb_k;
+        const bool ok = vb_on && gy >= 0 && gy < hq && gx >= 0 && gx < wq;
+        const unsigned off0 = ok ? ((unsigned)(b0 + vb_c) * planeq + (unsigned)(gy * wq + gx) * 4u) : WG_OOB;
+#pragma unroll
+        for (int i = 0; i < BV_PER_T; ++i) {
+          const unsigned off = off0 + (unsigned)i * planeq;
+          if constexpr (G::S2) {
+            const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rq, (int)off, 0, 0));
+            rb[2 * i] = v[0]; rb[2 * i + 1] = v[1];
+          } else {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, (int)off, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rb[4 * i + e] = v[e];
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
       int idx = tid + i * 256;
-      int c = idx >> 6, r = (idx >> 5) & 1, col = idx & 31;
+      int c = idx / G::PIX, rc = idx % G::PIX, r = rc / G::TW, col = rc % G::TW;
       int gy = y0 + r, gx = x0 + col;
       bool ok = gy < a.h && gx < a.w;      // channel tail handled by num_records
       unsigned off = ok ? ((unsigned)(a0 + c) * plane + (unsigned)(gy * a.w + gx) * 4u) : WG_OOB;
@@ -129,31 +215,52 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i) {
       int idx = tid + i * 256;
-      int c = idx / ((WG_R + 2) * (WG_TW + 2));
-      int rem2 = idx - c * ((WG_R + 2) * (WG_TW + 2));
-      int r = rem2 / (WG_TW + 2), col = rem2 - r * (WG_TW + 2);
-      int gy = y0 - 1 + r, gx = x0 - 1 + col;
-      bool ok = gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
-      unsigned off = ok ? ((unsigned)(b0 + c) * plane + (unsigned)(gy * a.w + gx) * 4u) : WG_OOB;
+      int c = idx / (G::BR * G::BC);
+      int rem2 = idx - c * (G::BR * G::BC);
+      int r = rem2 / G::BC, col = rem2 - r * G::BC;
+      int gy = (G::S2 ? 2 * y0 : y0) - 1 + r, gx = (G::S2 ? 2 * x0 : x0) - 1 + col;
+      bool ok = (B_EXACT || idx < B_ELEMS) && gy >= 0 && gy < hq && gx >= 0 && gx < wq;
+      unsigned off = ok ? ((unsigned)(b0 + c) * planeq + (unsigned)(gy * wq + gx) * 4u) : WG_OOB;
       rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, (int)off, 0, 0));
+    }
     }
   };
   auto store_tile = [&](int buf) {
-    float* pa = sA + buf * WG_A_FLOATS;
-    float* pb = sB + buf * WG_B_FLOATS;
+    float* pa = sA + buf * G::A_FLOATS;
+    float* pb = sB + buf * G::B_FLOATS;
+    if constexpr (VEC) {
+      float* qa = pa + va_c * G::CSA + va_r * G::TW + 4 * va_k;               // 16-byte aligned (CSA % 4 == 0)
+#pragma unroll
+      for (int i = 0; i < AV_PER_T; ++i)
+        *reinterpret_cast<f32x4*>(qa + i * A_CSTEP * G::CSA) = f32x4{ra[4 * i], ra[4 * i + 1], ra[4 * i + 2], ra[4 * i + 3]};
+      // patch column of element e of the group: stride 1: 4k - 3 + e (columns x0 - 4 .. x0 - 2 are not part
+      // of the patch); stride 2: 2k - 1 + e (column 2 x0 - 2 is not)
+      const int col0 = G::S2 ? 2 * vb_k - 1 : 4 * vb_k - 3;
+      float* qb = pb + vb_c * G::CSB + vb_r * G::RSB + col0;
+      if (vb_on) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          if (col0 + e >= 0 && col0 + e < G::BC) {
+#pragma unroll
+            for (int i = 0; i < BV_PER_T; ++i) qb[i * G::CSB + e] = rb[VW * i + e];
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < A_PER_T; ++i) {
       int idx = tid + i * 256;
-      int c = idx >> 6, rc = idx & 63;
-      pa[c * WG_CSA + rc] = ra[i];
+      int c = idx / G::PIX, rc = idx % G::PIX;
+      pa[c * G::CSA + rc] = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_PER_T; ++i) {
       int idx = tid + i * 256;
-      int c = idx / ((WG_R + 2) * (WG_TW + 2));
-      int rem2 = idx - c * ((WG_R + 2) * (WG_TW + 2));
-      int r = rem2 / (WG_TW + 2), col = rem2 - r * (WG_TW + 2);
-      pb[c * WG_CSB + r * WG_RSB + col] = rb[i];
+      int c = idx / (G::BR * G::BC);
+      int rem2 = idx - c * (G::BR * G::BC);
+      int r = rem2 / G::BC, col = rem2 - r * G::BC;
+      if (B_EXACT || idx < B_ELEMS) pb[c * G::CSB + r * G::RSB + col] = rb[i];
+    }
     }
   };
 
@@ -168,29 +275,31 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
 #define WG_ABL 0      // compile-time ablation bits (tools/build_lab_libs.sh builds one library per value)
 #endif
 #define WGABL(bit) ((WG_ABL & (bit)) != 0)
+  constexpr int NBV = G::S2 ? 9 : 6;         // shifted Q values one (row, group of 4 pixels) needs per tap row
+  constexpr int QS = G::S2 ? 2 : 1;          // Q step per P pixel
   for (; tile < a.ntiles; tile += a.nsplit, ++it) {
     const int buf = it & 1;
     const bool more = tile + a.nsplit < a.ntiles;
     if (more && !WGABL(1)) load_tile(tile + a.nsplit);
-    const float* pa = sA + buf * WG_A_FLOATS + a_rd;
-    const float* pb = sB + buf * WG_B_FLOATS + b_rd;
+    const float* pa = sA + buf * G::A_FLOATS + a_rd;
+    const float* pb = sB + buf * G::B_FLOATS + b_rd;
 #pragma unroll
-    for (int r = 0; r < WG_R; ++r) {
+    for (int r = 0; r < G::R; ++r) {
 #pragma unroll
-      for (int g = 0; g < WG_TW / 8; ++g) {
+      for (int g = 0; g < G::TW / 8; ++g) {
         f32x4 av = {1.f, 2.f, 3.f, 4.f};
-        float bv[3][6];
+        float bv[3][NBV];
         if (!WGABL(8)) {
-          av = *reinterpret_cast<const f32x4*>(pa + r * WG_TW + 8 * g);
+          av = *reinterpret_cast<const f32x4*>(pa + r * G::TW + 8 * g);
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int c6 = 0; c6 < 6; ++c6) bv[ky][c6] = pb[(r + ky) * WG_RSB + 8 * g + c6];
+            for (int c6 = 0; c6 < NBV; ++c6) bv[ky][c6] = pb[(QS * r + ky) * G::RSB + QS * 8 * g + c6];
         } else {
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int c6 = 0; c6 < 6; ++c6) bv[ky][c6] = (float)(ky + c6 + r + g);
+            for (int c6 = 0; c6 < NBV; ++c6) bv[ky][c6] = (float)(ky + c6 + r + g);
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -199,9 +308,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
             if (wtap_on(RY, ky) && wtap_on(RX, kx)) {
 #pragma unroll
               for (int kk = 0; kk < 4; ++kk) {
-                if (WGABL(4)) acc[ky * 3 + kx][kk] += av[kk] * bv[ky][kk + kx];
+                if (WGABL(4)) acc[ky * 3 + kx][kk] += av[kk] * bv[ky][QS * kk + kx];
                 else
-                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[ky][kk + kx],
+                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[ky][QS * kk + kx],
                                                                         acc[ky * 3 + kx], 0, 0, 0);
               }
             }
@@ -227,23 +336,33 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   }
 }
 
-__global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) {
-  if (a.cphase == 0) { wgrad_body<WTAPS_ALL, WTAPS_ALL>(a); return; }
+// the un-phased, un-layered launches in the other geometries
+template <class G, bool VEC>
+__global__ __launch_bounds__(256) void wgrad3x3_mfma_geo_kernel(WgradArgs a) {
+  wgrad_body<WTAPS_ALL, WTAPS_ALL, G, VEC>(a);
+}
+
+template <bool VEC>
+__device__ __forceinline__ void wgrad_std_dispatch(const WgradArgs& a) {
+  if (a.cphase == 0) { wgrad_body<WTAPS_ALL, WTAPS_ALL, WgGeoStd, VEC>(a); return; }
   // block-uniform: the 64 b channels of this block belong to one sub-pixel phase
   const int bb = ((int)blockIdx.x / a.nsplit) % a.nbb;      // (phased launches are never layered)
   const int ph = (bb * 64) / a.cphase;
   const int ry = a.rowsets[(ph >> 1) & 1], rx = a.rowsets[ph & 1];
   switch (ry * 4 + rx) {
-    case WTAPS_01 * 4 + WTAPS_01: wgrad_body<WTAPS_01, WTAPS_01>(a); break;
-    case WTAPS_01 * 4 + WTAPS_12: wgrad_body<WTAPS_01, WTAPS_12>(a); break;
-    case WTAPS_12 * 4 + WTAPS_01: wgrad_body<WTAPS_12, WTAPS_01>(a); break;
-    case WTAPS_12 * 4 + WTAPS_12: wgrad_body<WTAPS_12, WTAPS_12>(a); break;
-    case WTAPS_01 * 4 + WTAPS_1: wgrad_body<WTAPS_01, WTAPS_1>(a); break;
-    case WTAPS_1 * 4 + WTAPS_01: wgrad_body<WTAPS_1, WTAPS_01>(a); break;
-    case WTAPS_1 * 4 + WTAPS_1: wgrad_body<WTAPS_1, WTAPS_1>(a); break;
-    default: wgrad_body<WTAPS_ALL, WTAPS_ALL>(a); break;
+    case WTAPS_01 * 4 + WTAPS_01: wgrad_body<WTAPS_01, WTAPS_01, WgGeoStd, VEC>(a); break;
+    case WTAPS_01 * 4 + WTAPS_12: wgrad_body<WTAPS_01, WTAPS_12, WgGeoStd, VEC>(a); break;
+    case WTAPS_12 * 4 + WTAPS_01: wgrad_body<WTAPS_12, WTAPS_01, WgGeoStd, VEC>(a); break;
+    case WTAPS_12 * 4 + WTAPS_12: wgrad_body<WTAPS_12, WTAPS_12, WgGeoStd, VEC>(a); break;
+    case WTAPS_01 * 4 + WTAPS_1: wgrad_body<WTAPS_01, WTAPS_1, WgGeoStd, VEC>(a); break;
+    case WTAPS_1 * 4 + WTAPS_01: wgrad_body<WTAPS_1, WTAPS_01, WgGeoStd, VEC>(a); break;
+    case WTAPS_1 * 4 + WTAPS_1: wgrad_body<WTAPS_1, WTAPS_1, WgGeoStd, VEC>(a); break;
+    default: wgrad_body<WTAPS_ALL, WTAPS_ALL, WgGeoStd, VEC>(a); break;
   }
 }
+__global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) { wgrad_std_dispatch<false>(a); }
+// the same with the vector staging (w % 4 == 0, 16-byte aligned operands)
+__global__ __launch_bounds__(256) void wgrad3x3_mfma_vec_kernel(WgradArgs a) { wgrad_std_dispatch<true>(a); }
 
 // g[e] = (accumulate ? g[e] : 0) + sum_s part[s][e]  over the written column range.
 // A block reduces 64 consecutive outputs; its 4 waves take interleaved quarters of the splits
@@ -447,12 +566,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_layers_kernel(const float* _
 using namespace tg;
 
 constexpr int SC_MAXBLK = 768;      // persistent blocks of the small-ca kernel (3 per CU)
-static int wgrad_nsplit(int n, int h, int w, int ca, int cb) {
-  if (ca <= 4) {
+// tile geometry of an un-phased launch: 0 = 2 x 32, 1 = 4 x 16 (maps up to 16 wide), 2 = 8 x 8 (up to 8 wide)
+static int wgrad_geo(int h, int w) { return w <= 8 && h > 2 ? 2 : (w <= 16 && h > 2 ? 1 : 0); }
+static void wgrad_tile(int geo, int* r, int* tw) {
+  *r = geo == 2 ? 8 : (geo == 1 ? 4 : (geo == 3 ? 1 : WG_R));
+  *tw = geo == 2 ? 8 : (geo == 1 ? 16 : WG_TW);
+}
+static int wgrad_nsplit(int n, int h, int w, int ca, int cb, int geo = 0) {
+  if (ca <= 4 && geo != 3) {
     const int nt = n * cdiv(h, SC_TR) * cdiv(w, SC_TW), per_b = SC_MAXBLK / cdiv(cb, 64);
     return nt < per_b ? nt : (per_b > 0 ? per_b : 1);
   }
-  int ntiles = n * cdiv(h, WG_R) * cdiv(w, WG_TW);
+  int r, tw;
+  wgrad_tile(geo, &r, &tw);
+  int ntiles = n * cdiv(h, r) * cdiv(w, tw);
   int blocks_ch = cdiv(ca, 64) * cdiv(cb, 64);
   int s = 512 / blocks_ch;
   if (s < 1) s = 1;
@@ -463,23 +590,65 @@ static int wgrad_nsplit(int n, int h, int w, int ca, int cb) {
 
 extern "C" size_t tg_wgrad3x3_workspace_floats(int n, int ca, int cb_total, int h, int w) {
   if (n <= 0 || ca <= 0 || cb_total <= 0 || h <= 0 || w <= 0) return 0;
-  return (size_t)wgrad_nsplit(n, h, w, ca, cb_total) * ca * cb_total * 9;
+  // (the un-phased launch may fold the tile for a narrow map; phased launches use 2 x 32: the larger count)
+  const int s0 = wgrad_nsplit(n, h, w, ca, cb_total), s1 = wgrad_nsplit(n, h, w, ca, cb_total, wgrad_geo(h, w));
+  return (size_t)(s0 > s1 ? s0 : s1) * ca * cb_total * 9;
+}
+
+extern "C" size_t tg_wgrad3x3_convt_workspace_floats(int n, int ci, int co, int h, int w) {
+  if (n <= 0 || ci <= 0 || co <= 0 || h <= 0 || w <= 0) return 0;
+  return (size_t)wgrad_nsplit(n, h, w, ci, co, 3) * ci * co * 9;
+}
+
+template <class G, bool VEC>
+static void launch_geo2(const WgradArgs& a, unsigned blocks, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_mfma_geo_kernel<G, VEC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad3x3_mfma_geo_kernel<G, VEC>), dim3(blocks), dim3(256), G::LDS_BYTES, s, a);
+}
+template <class G>
+static void launch_geo(const WgradArgs& a, unsigned blocks, hipStream_t s, bool vec) {
+  if (vec) launch_geo2<G, true>(a, blocks, s); else launch_geo2<G, false>(a, blocks, s);
+}
+static void launch_std(const WgradArgs& a, unsigned blocks, hipStream_t s, bool vec) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_mfma_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgGeoStd::LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_mfma_vec_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgGeoStd::LDS_BYTES);
+    attr_set = true;
+  }
+  if (vec) hipLaunchKernelGGL(wgrad3x3_mfma_vec_kernel, dim3(blocks), dim3(256), WgGeoStd::LDS_BYTES, s, a);
+  else hipLaunchKernelGGL(wgrad3x3_mfma_kernel, dim3(blocks), dim3(256), WgGeoStd::LDS_BYTES, s, a);
+}
+// the vector staging needs whole 16-byte groups: widths that are multiples of 4 and aligned planes
+static bool wgrad_vec_ok(const WgradArgs& a, int nseg) {
+  if (a.w % 4 != 0 || a.p_ns % 4 != 0 || a.q_ns % 4 != 0 || a.lstride % 4 != 0) return false;
+  for (int i = 0; i < nseg; ++i)
+    if (((uintptr_t)a.pseg[i] | (uintptr_t)a.qseg[i]) & 15) return false;
+  return true;
 }
 
 static int wgrad_launch(const float* const* p_list, const float* const* q_list, int nseg,
                         int64_t p_nstride, int64_t q_nstride, float* grad, float* workspace,
                         int n_per_seg, int ca, int cb, int cb_total, int cb_off, int h, int w,
                         int accumulate, tg_stream_t stream, int cphase = 0, int set_p0 = 0,
-                        int set_p1 = 0) {
+                        int set_p1 = 0, int stride2 = 0) {
   TG_REQUIRE(p_list && q_list && grad && workspace, TG_E_ARG, "wgrad3x3: null pointer");
   TG_REQUIRE(nseg >= 1 && nseg <= WG_MAXSEG, TG_E_ARG, "wgrad3x3: %d segments (1..%d)", nseg, WG_MAXSEG);
   TG_REQUIRE(n_per_seg > 0 && ca > 0 && cb > 0 && h > 0 && w > 0 && cb_off >= 0 &&
                  cb_off + cb <= cb_total, TG_E_SHAPE,
              "wgrad3x3: n=%dx%d ca=%d cb=%d (+%d of %d) h=%d w=%d", nseg, n_per_seg, ca, cb, cb_off,
              cb_total, h, w);
-  TG_REQUIRE((long long)(ca > cb ? ca : cb) * h * w * 4 < (1ll << 31), TG_E_SHAPE,
+  TG_REQUIRE((long long)(ca > (stride2 ? 4 * cb : cb) ? ca : (stride2 ? 4 * cb : cb)) * h * w * 4 < (1ll << 31), TG_E_SHAPE,
              "wgrad3x3: one batch item must be < 2 GiB");
-  if (ca <= 4 && !cphase) {
+  const int geo = stride2 ? 3 : (cphase ? 0 : wgrad_geo(h, w));
+  if (ca <= 4 && !cphase && !stride2) {
     WgradSmallArgs sa{};
     for (int i = 0; i < nseg; ++i) {
       TG_REQUIRE(p_list[i] && q_list[i], TG_E_ARG, "wgrad3x3: null segment %d", i);
@@ -509,10 +678,12 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
   a.n_per_seg = n_per_seg;
   a.part = workspace; a.p_ns = p_nstride; a.q_ns = q_nstride;
   a.ca = ca; a.cb = cb; a.cb_total = cb_total; a.cb_off = cb_off; a.n = n; a.h = h; a.w = w;
-  a.tiles_x = cdiv(w, WG_TW); a.tiles_y = cdiv(h, WG_R);
+  int tile_r, tile_w;
+  wgrad_tile(geo, &tile_r, &tile_w);
+  a.tiles_x = cdiv(w, tile_w); a.tiles_y = cdiv(h, tile_r);
   a.ntiles = n * a.tiles_x * a.tiles_y;
   a.nab = cdiv(ca, 64); a.nbb = cdiv(cb, 64);
-  a.nsplit = wgrad_nsplit(n, h, w, ca, cb_total);   // same value the workspace was sized with
+  a.nsplit = wgrad_nsplit(n, h, w, ca, cb_total, geo);   // at most what the workspace was sized with
   static const int maxwg = TG_LAB_ENV("TG_WGRAD_MAXWG", 0);     // lab: cap the K split (workgroups per channel block)
   if (maxwg > 0 && a.nsplit > maxwg) a.nsplit = maxwg;
   a.cphase = cphase; a.rowsets[0] = (unsigned char)set_p0; a.rowsets[1] = (unsigned char)set_p1;
@@ -522,16 +693,19 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
                "wgrad3x3: phased taps need cb = 4 phases of a multiple of 64 channels (cb=%d cphase=%d)", cb,
                cphase);
   }
-  size_t lds = 2 * (size_t)(WG_A_FLOATS + WG_B_FLOATS) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_mfma_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
   unsigned blocks = (unsigned)(a.nab * a.nbb * a.nsplit);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad3x3_mfma_kernel, dim3(blocks), dim3(256), lds, s, a);
+  static const int novec = TG_LAB_ENV("TG_WGRAD_NOVEC", 0);      // lab: A/B of the two staging forms
+  const bool vec = !novec && wgrad_vec_ok(a, nseg);
+  if (geo == 0) {
+    launch_std(a, blocks, s, vec);
+  } else if (geo == 1) {
+    launch_geo<WgGeo<4, 16, 0>>(a, blocks, s, vec);
+  } else if (geo == 2) {
+    launch_geo<WgGeo<8, 8, 0>>(a, blocks, s, vec);
+  } else {
+    launch_geo<WgGeo<1, 32, 1>>(a, blocks, s, vec);
+  }
   int rc = check_launch("wgrad3x3_mfma");
   if (rc != TG_OK) return rc;
   long long total = (long long)ca * cb * 9;
@@ -585,15 +759,9 @@ extern "C" int tg_wgrad3x3_body(const float* const* dz_bases, const float* const
   a.nab = a.nbb = cdiv(c, 64);
   a.nsplit = body_nsplit(nframes, n_per_frame, nlayers, c, h, w);
   a.nlayer = nlayers; a.lstride = layer_stride;
-  size_t lds = 2 * (size_t)(WG_A_FLOATS + WG_B_FLOATS) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_mfma_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(wgrad3x3_mfma_kernel, dim3((unsigned)(nlayers * a.nab * a.nbb * a.nsplit)), dim3(256), lds, s, a);
+  static const int novec = TG_LAB_ENV("TG_WGRAD_NOVEC", 0);
+  launch_std(a, (unsigned)(nlayers * a.nab * a.nbb * a.nsplit), s, !novec && wgrad_vec_ok(a, nframes));
   int rc = check_launch("wgrad3x3_body");
   if (rc != TG_OK) return rc;
   const long long total = (long long)c * c * 9;
@@ -618,6 +786,16 @@ extern "C" int tg_wgrad3x3_multi_phased(const float* const* p_list, const float*
   TG_REQUIRE(cphase > 0, TG_E_ARG, "wgrad3x3_multi_phased: cphase=%d", cphase);
   return wgrad_launch(p_list, q_list, nseg, p_nstride, q_nstride, grad, workspace, n_per_seg, ca, cb,
                       cb, 0, h, w, accumulate, stream, cphase, taps_phase0, taps_phase1);
+}
+
+// dW of ConvTranspose2d(ci, co, 3, 2, 1, output_padding 1): x_list[i] (n_per_seg, ci, h, w) = the layer's
+// inputs, dz_list[i] (n_per_seg, co, 2h, 2w) = the gradients of its pre-activation; grad (ci, co, 3, 3)
+// in the layer's own weight layout.  No space-to-depth copy of dZ, the nine taps in one balanced pass.
+extern "C" int tg_wgrad3x3_convt_multi(const float* const* x_list, const float* const* dz_list, int nseg,
+                                       float* grad, float* workspace, int n_per_seg, int ci, int co, int h, int w,
+                                       int accumulate, tg_stream_t stream) {
+  return wgrad_launch(x_list, dz_list, nseg, (int64_t)ci * h * w, (int64_t)co * 4 * h * w, grad, workspace, n_per_seg,
+                      ci, co, co, 0, h, w, accumulate, stream, 0, 0, 0, 1);
 }
 
 extern "C" int tg_wgrad3x3_multi(const float* const* p_list, const float* const* q_list, int nseg,

@@ -102,9 +102,9 @@ class Tape:
     # are collected during the reverse sweep and reduced by ONE wgrad launch per layer
     # over the concatenated batch: 19x fewer launches / split-K reductions, and enough
     # pixel tiles per launch to fill the GPU.
-    def defer_wgrad(self, key, p, q, target, cb_off=0, post=None, phased=None):
+    def defer_wgrad(self, key, p, q, target, cb_off=0, post=None, phased=None, convt=False):
         ent = self.deferred.setdefault(key, {'p': [], 'q': [], 'target': target, 'cb_off': cb_off,
-                                             'post': post, 'phased': phased})
+                                             'post': post, 'phased': phased, 'convt': convt})
         ent['p'].append(p)
         ent['q'].append(q)
 
@@ -121,7 +121,13 @@ class Tape:
             return all(t.shape == ts[0].shape and t.is_contiguous() for t in ts)
         for ent in self.deferred.values():
             multi = len(ent['p']) > 1 and same(ent['p']) and same(ent['q'])
-            if ent['post'] is None:
+            if ent.get('convt'):       # (x, dZ at twice the resolution) pairs of a transposed conv
+                if same(ent['p']) and same(ent['q']):
+                    ops.wgrad3x3_convt_multi(ent['p'], ent['q'], ent['target'], accumulate=True)
+                else:
+                    for x_, d_ in zip(ent['p'], ent['q']):
+                        ops.wgrad3x3_convt_multi([x_.contiguous()], [d_.contiguous()], ent['target'], accumulate=True)
+            elif ent['post'] is None:
                 if multi:      # one launch over the per-frame tensors where they lie
                     ops.wgrad3x3_multi(ent['p'], ent['q'], ent['target'], cb_off=ent['cb_off'],
                                        accumulate=True)
@@ -531,26 +537,36 @@ def convt3x3s2(tape, layer, x, act=RELU):
             return
         premasked = act == RELU and id(y) not in tape.unmasked       # every contribution came masked
         dz = ops.act_bwd(g, y, act, out=g) if (act != NONE and not premasked) else g
-        s = ops.space_to_depth(dz, 2)                              # (n, 4co, h, w)
-        we = _CACHE.get(layer, ('cte',), _ver(w), lambda: ops.pack_conv3x3(_convt_embed(w.detach())))
         fuse = id(x) in tape.relu_outputs
         nx, _, hx, wx = x.shape
+        direct = co <= 64 and ci <= 64 and dz.is_contiguous() and x.is_contiguous()
+        s = None
         if ops.conv3x3s2_supported(nx, co, ci, hx, wx):
             # small frames: the gradient taken directly as a stride-2 conv of dZ (K = 9 co) -- 11 us
             # instead of 27 us for the 32-chunk phased form on s2d(dZ)
             wk = _CACHE.get(layer, ('ctd',), _ver(w), lambda: ops.pack_conv3x3(w.detach().contiguous(), ocb=64)[0])
             tape.add_grad(x, ops.conv3x3s2(dz, wk, co, ci, relu_mask=x if fuse else None), masked=fuse)
-        elif co % 8 == 0:      # phase py = 1 owns tap rows {0, 1}, py = 0 only {1}: 9 of 36 taps are non-zero
-            tape.add_grad(x, ops.conv3x3_phased(s, we[0], 4 * co, ci, we[3], 1, co, ops.TAPS_1, ops.TAPS_01,
-                                                relu_mask=x if fuse else None), masked=fuse)
         else:
-            tape.add_grad(x, ops.conv3x3(s, we[0], None, 4 * co, ci, we[3], ksplit=1,
-                                         relu_mask=x if fuse else None), masked=fuse)
+            s = ops.space_to_depth(dz, 2)                          # (n, 4co, h, w)
+            we = _CACHE.get(layer, ('cte',), _ver(w), lambda: ops.pack_conv3x3(_convt_embed(w.detach())))
+            if co % 8 == 0:    # phase py = 1 owns tap rows {0, 1}, py = 0 only {1}: 9 of 36 taps are non-zero
+                tape.add_grad(x, ops.conv3x3_phased(s, we[0], 4 * co, ci, we[3], 1, co, ops.TAPS_1, ops.TAPS_01,
+                                                    relu_mask=x if fuse else None), masked=fuse)
+            else:
+                tape.add_grad(x, ops.conv3x3(s, we[0], None, 4 * co, ci, we[3], ksplit=1,
+                                             relu_mask=x if fuse else None), masked=fuse)
         if w.requires_grad:
-            def post(ge):                                          # G[ci][(ph,co)][ty][tx]
-                _, inv = _embed_index('convt', ci, co, ge.device)
-                ops.index_gather(ge, inv, out=_grad_buf(w), accumulate=True)
-            tape.defer_wgrad(('ct', id(layer)), x, s, None, 0, post, phased=(co, ops.TAPS_1, ops.TAPS_01))
+            if direct:
+                # dW straight from dZ (tg_wgrad3x3_convt_multi): no s2d copy, no embedded gradient to gather back
+                tape.defer_wgrad(('ctw', id(layer)), x, dz, _grad_buf(w), convt=True)
+            else:
+                if s is None:
+                    s = ops.space_to_depth(dz, 2)
+
+                def post(ge):                                      # G[ci][(ph,co)][ty][tx]
+                    _, inv = _embed_index('convt', ci, co, ge.device)
+                    ops.index_gather(ge, inv, out=_grad_buf(w), accumulate=True)
+                tape.defer_wgrad(('ct', id(layer)), x, s, None, 0, post, phased=(co, ops.TAPS_1, ops.TAPS_01))
             tape.defer_bias(_grad_buf(b), dz)
     tape.record(bwd)
     return y

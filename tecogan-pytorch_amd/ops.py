@@ -408,6 +408,30 @@ def wgrad3x3_multi(p_list, q_list, grad, cb_off=0, accumulate=True, phased=None)
     return grad
 
 
+def wgrad3x3_convt_multi(x_list, dz_list, grad, accumulate=True):
+    """tg_wgrad3x3_convt_multi: grad (ci, co, 3, 3) (+)= dW of ConvTranspose2d(ci, co, 3, 2, 1, 1) over the
+    (input x_i (n, ci, h, w), output gradient dz_i (n, co, 2h, 2w)) pairs, straight from dZ."""
+    if len(x_list) != len(dz_list) or not x_list:
+        raise L.TecoganHipError('wgrad3x3_convt_multi: empty or mismatched lists')
+    for t in list(x_list) + list(dz_list):
+        _chk(t, 'segment')
+    _chk(grad, 'grad')
+    n, ci, h, w = x_list[0].shape
+    co = dz_list[0].shape[1]
+    if any(t.shape != x_list[0].shape for t in x_list) or any(t.shape != (n, co, 2 * h, 2 * w) for t in dz_list) \
+            or tuple(grad.shape) != (ci, co, 3, 3):
+        raise L.TecoganHipError(f'wgrad3x3_convt_multi: x {tuple(x_list[0].shape)} dz {tuple(dz_list[0].shape)} '
+                                f'grad {tuple(grad.shape)}')
+    lib = L.lib()
+    for i in range(0, len(x_list), MAX_SEGS):
+        xs, ds = x_list[i:i + MAX_SEGS], dz_list[i:i + MAX_SEGS]
+        ws = _wgrad_workspace(grad.device, lib.tg_wgrad3x3_convt_workspace_floats(n * len(xs), ci, co, h, w))
+        L.check(lib.tg_wgrad3x3_convt_multi(_ptr_array(xs), _ptr_array(ds), len(xs), grad.data_ptr(), ws.data_ptr(),
+                                            n, ci, co, h, w, 1 if (accumulate or i > 0) else 0, _stream()),
+                'tg_wgrad3x3_convt_multi')
+    return grad
+
+
 def wgrad3x3_body(dz_list, acts_list, grads, accumulate=True):
     """tg_wgrad3x3_body: weight gradients of the chained SRNet body's 2*nb residual-block convs over ALL
     unrolled frames in one launch.  dz_list[f] / acts_list[f]: (1 + 2nb, n, c, h, w) blocks of frame f

@@ -35,7 +35,10 @@ def ops():
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w', [(2, 64, 64, 16, 40), (1, 51, 64, 9, 33), (1, 6, 32, 12, 20),
-                                            (2, 3, 64, 10, 34), (1, 128, 256, 5, 9), (1, 64, 3, 20, 36)])
+                                            (2, 3, 64, 10, 34), (1, 128, 256, 5, 9), (1, 64, 3, 20, 36),
+                                            # narrow maps: the weight gradient folds its pixel tile to 4 x 16 / 8 x 8
+                                            (5, 128, 128, 16, 16), (7, 256, 128, 8, 8), (3, 64, 96, 11, 13),
+                                            (9, 256, 256, 4, 4), (2, 32, 64, 19, 7), (300, 64, 64, 8, 8)])
 def test_conv3x3_dgrad_and_wgrad(ops, n, cin, cout, h, w):
     x = rs(1, (n, cin, h, w)).requires_grad_(True)
     wt = (rs(2, (cout, cin, 3, 3)) / (3.0 * cin ** 0.5)).requires_grad_(True)
@@ -51,6 +54,23 @@ def test_conv3x3_dgrad_and_wgrad(ops, n, cin, cout, h, w):
     ops.wgrad3x3(dev(dz), dev(x.detach()), g, accumulate=False)
     assert relerr(g, wt.grad) <= 2e-5, relerr(g, wt.grad)
     ops.wgrad3x3(dev(dz), dev(x.detach()), g, accumulate=True)          # accumulate doubles
+    assert relerr(g, 2 * wt.grad) <= 2e-5
+
+
+@pytest.mark.parametrize('nseg,n,ci,co,h,w', [(1, 2, 64, 64, 16, 32), (3, 2, 64, 64, 9, 21), (1, 1, 24, 40, 5, 70),
+                                              (19, 2, 64, 64, 32, 32), (2, 3, 64, 16, 7, 33),
+                                              (2, 2, 64, 64, 12, 20), (1, 2, 40, 24, 3, 36)])
+def test_convt_weight_gradient_straight_from_dz(ops, nseg, n, ci, co, h, w):
+    """tg_wgrad3x3_convt_multi: dW of ConvTranspose2d(ci, co, 3, 2, 1, 1) over per-frame (x, dZ) pairs against
+    autograd on the concatenated batch."""
+    xs = [rs(10 + i, (n, ci, h, w)) for i in range(nseg)]
+    dzs = [rs(40 + i, (n, co, 2 * h, 2 * w)) for i in range(nseg)]
+    wt = (rs(2, (ci, co, 3, 3)) / (3.0 * ci ** 0.5)).requires_grad_(True)
+    F.conv_transpose2d(torch.cat(xs), wt, None, stride=2, padding=1, output_padding=1).backward(torch.cat(dzs))
+    g = torch.zeros(ci, co, 3, 3, device='cuda')
+    ops.wgrad3x3_convt_multi([dev(t) for t in xs], [dev(t) for t in dzs], g, accumulate=False)
+    assert relerr(g, wt.grad) <= 2e-5, relerr(g, wt.grad)
+    ops.wgrad3x3_convt_multi([dev(t) for t in xs], [dev(t) for t in dzs], g, accumulate=True)
     assert relerr(g, 2 * wt.grad) <= 2e-5
 
 
