@@ -61,6 +61,10 @@ struct WgradArgs {
   //  the compiler and every access turns into a scratch load -- measured 4x slower.)
   int nlayer;
   long long lstride;
+  // K split inside the workgroup (un-phased 2 x 32 launches): with ca <= 32 (bit 0) / cb <= 32 (bit 1) the
+  // wave pairs that would multiply zero padding take alternate groups of 8 pixels instead and write
+  // their sums as extra splits: partial index = split * KS + kid, KS = 2 or 4.
+  int kmode;
 };
 
 enum { WTAPS_ALL = 0, WTAPS_01 = 1, WTAPS_12 = 2, WTAPS_1 = 3 };
@@ -90,14 +94,19 @@ struct WgGeo {
 using WgGeoStd = WgGeo<WG_R, WG_TW, 0>;
 static_assert(WgGeoStd::CSA == WG_CSA && WgGeoStd::RSB == WG_RSB && WgGeoStd::CSB == WG_CSB, "geometry");
 
-template <int RY, int RX, class G = WgGeoStd, bool VEC = false>
+template <int RY, int RX, class G = WgGeoStd, bool VEC = false, int KS = 1>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                          // [2][A_FLOATS]
   float* sB = smem + 2 * G::A_FLOATS;        // [2][B_FLOATS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cot = wave & 1, cit = wave >> 1;
+  int cot = wave & 1, cit = wave >> 1;
+  int kid = 0;
+  if (KS > 1) {                              // (wave-uniform)
+    if (a.kmode & 1) { kid = cot; cot = 0; }
+    if (a.kmode & 2) { kid += cit * ((a.kmode & 1) ? 2 : 1); cit = 0; }
+  }
   int b = blockIdx.x;
   const int split = b % a.nsplit; b /= a.nsplit;
   const int bb = b % a.nbb; b /= a.nbb;
@@ -116,8 +125,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int lh = lane >> 5, ll = lane & 31;
-  const int a_rd = (cot * 32 + ll) * G::CSA + 4 * lh;
-  const int b_rd = (cit * 32 + ll) * G::CSB + (G::S2 ? 8 : 4) * lh;
+  const int a_rd = (cot * 32 + ll) * G::CSA + 4 * lh + 8 * kid;
+  const int b_rd = (cit * 32 + ll) * G::CSB + (G::S2 ? 8 : 4) * lh + (G::S2 ? 16 : 8) * kid;
 
   // ---- staging, element-wise form (any width / alignment) ------------------------------------
   constexpr int A_PER_T = (64 * G::PIX) / 256;                       // 16 (8 for the stride-2 form)
@@ -286,7 +295,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
 #pragma unroll
     for (int r = 0; r < G::R; ++r) {
 #pragma unroll
-      for (int g = 0; g < G::TW / 8; ++g) {
+      for (int g = 0; g < G::TW / 8; g += KS) {     // (K split: this wave's groups are kid, kid + KS, ...)
         f32x4 av = {1.f, 2.f, 3.f, 4.f};
         float bv[3][NBV];
         if (!WGABL(8)) {
@@ -321,7 +330,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   }
 
   // D[i = a-channel][j = b-channel]: lane holds j = ll, registers walk i
-  float* out = a.part + ((long long)li * a.nsplit + split) * a.ca * a.cb_total * 9;
+  float* out = a.part + (((long long)li * a.nsplit + split) * KS + kid) * a.ca * a.cb_total * 9;
   const int bj = b0 + cit * 32 + ll;
   if (bj < a.cb) {
 #pragma unroll
@@ -360,6 +369,11 @@ __device__ __forceinline__ void wgrad_std_dispatch(const WgradArgs& a) {
     default: wgrad_body<WTAPS_ALL, WTAPS_ALL, WgGeoStd, VEC>(a); break;
   }
 }
+// un-phased 2 x 32 launches with 2 or 4 waves sharing the pixels of a tile (WgradArgs::kmode)
+template <bool VEC, int KS>
+__global__ __launch_bounds__(256) void wgrad3x3_mfma_ks_kernel(WgradArgs a) {
+  wgrad_body<WTAPS_ALL, WTAPS_ALL, WgGeoStd, VEC, KS>(a);
+}
 __global__ __launch_bounds__(256) void wgrad3x3_mfma_kernel(WgradArgs a) { wgrad_std_dispatch<false>(a); }
 // the same with the vector staging (w % 4 == 0, 16-byte aligned operands)
 __global__ __launch_bounds__(256) void wgrad3x3_mfma_vec_kernel(WgradArgs a) { wgrad_std_dispatch<true>(a); }
@@ -368,12 +382,15 @@ __global__ __launch_bounds__(256) void wgrad3x3_mfma_vec_kernel(WgradArgs a) { w
 // A block reduces 64 consecutive outputs; its 4 waves take interleaved quarters of the splits
 // (coalesced 256-byte rows, 4 independent chains per thread) and are combined through LDS in a
 // fixed order, so the result does not depend on scheduling.
+// swapped (a launch with <= 4 SHIFTED channels, run by the small-ca kernel with the operands exchanged):
+//   G[a][b][ky][kx] = sum P[a](y, x) Q[b](y + ky - 1, x + kx - 1) seen from Q's side is G'[b][a][2 - ky][2 - kx];
+//   the partials are [split][cb][ca][9] and entry (b, a, 8 - t) goes to grad[a][cb_off + b][t].
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part,
                                                            float* __restrict__ g, int nsplit, int ca,
                                                            int cb, int cb_total, int cb_off,
-                                                           int accumulate) {
+                                                           int accumulate, int swapped) {
   __shared__ float sm[4][64];
-  const long long stride = (long long)ca * cb_total * 9;
+  const long long stride = swapped ? (long long)cb * ca * 9 : (long long)ca * cb_total * 9;
   const long long total = (long long)ca * cb * 9;
   const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const long long i = (long long)blockIdx.x * 64 + o;
@@ -383,7 +400,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     int t = (int)(i % 9); long long r = i / 9;
     int bj = (int)(r % cb); int ai = (int)(r / cb);
     e = ((long long)ai * cb_total + cb_off + bj) * 9 + t;
-    const float* p = part + e;
+    const float* p = part + (swapped ? ((long long)bj * ca + ai) * 9 + (8 - t) : e);
     int k = sg;
     for (; k + 12 < nsplit; k += 16) {
       s0 += p[(long long)k * stride];
@@ -422,9 +439,10 @@ struct WgradSmallArgs {
   long long p_ns, q_ns;
   int ca, cb, cb_total, cb_off, n, h, w, tiles_x, tiles_y, ntiles, nblk, nbb;
 };
+template <bool VEC>
 __global__ __launch_bounds__(256) void wgrad3x3_smallca_kernel(WgradSmallArgs a) {
   __shared__ float sQ[64 * SC_QCS];                 // 52.5 KB
-  __shared__ float sP[4 * SC_TR * SC_TW];
+  __shared__ __attribute__((aligned(16))) float sP[4 * SC_TR * SC_TW];
   const int tid = threadIdx.x, bl = tid & 63, g = tid >> 6;
   const int bb = blockIdx.x % a.nbb, blk = blockIdx.x / a.nbb;
   const int b0 = bb * 64;
@@ -438,7 +456,14 @@ __global__ __launch_bounds__(256) void wgrad3x3_smallca_kernel(WgradSmallArgs a)
   // loads of the block's NEXT tile are in flight while this one is being accumulated
   constexpr int QN = 64 * (SC_TR + 2) * SC_QRS, QPT = (QN + 255) / 256;      // 51 per thread
   constexpr int PN = 4 * SC_TR * SC_TW, PPT = PN / 256;                      // 2 per thread
-  float rqv[QPT], rpv[PPT];
+  // vector form (w % 4 == 0, aligned planes; see wgrad_body): the Q rows as 16-byte groups from column
+  // x0 - 4 -- position (row, group) = tid % 64 of the 6 x 10, the thread's wave walks channels w, w + 4, ...;
+  // the P tile as 128 groups, one per thread of the first two waves
+  constexpr int QV = 16;
+  float rqv[VEC ? QV * 4 : QPT], rpv[VEC ? 4 : PPT];
+  const int vq_pos = tid & 63, vq_r = vq_pos / 10, vq_k = vq_pos - vq_r * 10, vq_c = tid >> 6;
+  const bool vq_on = vq_pos < 60;
+  const int vp_c = tid >> 5, vp_r = (tid >> 3) & 3, vp_k = tid & 7;
   auto issue = [&](int tile) {
     const int n = tile / (a.tiles_x * a.tiles_y);
     const int rem = tile - n * (a.tiles_x * a.tiles_y);
@@ -449,8 +474,27 @@ __global__ __launch_bounds__(256) void wgrad3x3_smallca_kernel(WgradSmallArgs a)
         const_cast<float*>(a.qseg[seg] + (long long)ln * a.q_ns), 0, a.cb * hw * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.pseg[seg] + (long long)ln * a.p_ns), 0, a.ca * hw * 4, 0x00020000);
+    if constexpr (VEC) {
+      const int gy = y0 - 1 + vq_r, gx = x0 - 4 + 4 * vq_k;
+      const bool ok = vq_on && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+      const unsigned off0 = ok ? (unsigned)(((b0 + vq_c) * hw + gy * a.w + gx) * 4) : WG_OOB;
 #pragma unroll
-    for (int k = 0; k < QPT; ++k) {
+      for (int i = 0; i < QV; ++i) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rq, (int)(off0 + (unsigned)(4 * i) * (unsigned)hw * 4u), 0, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rqv[4 * i + e] = v[e];
+      }
+      const int py = y0 + vp_r, px = x0 + 4 * vp_k;
+      const bool pok = tid < 128 && py < a.h && px < a.w;
+      const unsigned poff = pok ? (unsigned)((vp_c * hw + py * a.w + px) * 4) : WG_OOB;
+      const f32x4 pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, (int)poff, 0, 0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rpv[e] = pv[e];
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < (VEC ? 0 : QPT); ++k) {
       const int i = tid + k * 256;
       const int c = i % SC_QRS, r = (i / SC_QRS) % (SC_TR + 2), ch = i / (SC_QRS * (SC_TR + 2));
       const int gy = y0 - 1 + r, gx = x0 - 1 + c;
@@ -459,7 +503,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_smallca_kernel(WgradSmallArgs a)
       rqv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rq, (int)off, 0, 0));
     }
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
+    for (int k = 0; k < (VEC ? 0 : PPT); ++k) {
       const int i = tid + k * 256;
       const int c = i % SC_TW, r = (i / SC_TW) % SC_TR, ch = i / (SC_TW * SC_TR);
       const int gy = y0 + r, gx = x0 + c;
@@ -469,14 +513,29 @@ __global__ __launch_bounds__(256) void wgrad3x3_smallca_kernel(WgradSmallArgs a)
     }
   };
   auto commit = [&]() {
+    if constexpr (VEC) {
+      const int col0 = 4 * vq_k - 3;                     // patch column of element 0 of the group
+      float* q = sQ + vq_c * SC_QCS + vq_r * SC_QRS + col0;
+      if (vq_on) {
 #pragma unroll
-    for (int k = 0; k < QPT; ++k) {
+        for (int e = 0; e < 4; ++e) {
+          if (col0 + e >= 0 && col0 + e < SC_QRS) {
+#pragma unroll
+            for (int i = 0; i < QV; ++i) q[4 * i * SC_QCS + e] = rqv[4 * i + e];
+          }
+        }
+      }
+      if (tid < 128) *reinterpret_cast<f32x4*>(sP + tid * 4) = f32x4{rpv[0], rpv[1], rpv[2], rpv[3]};
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < (VEC ? 0 : QPT); ++k) {
       const int i = tid + k * 256;
       const int c = i % SC_QRS, r = (i / SC_QRS) % (SC_TR + 2), ch = i / (SC_QRS * (SC_TR + 2));
       if (i < QN) sQ[ch * SC_QCS + r * SC_QRS + c] = rqv[k];
     }
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) sP[tid + k * 256] = rpv[k];
+    for (int k = 0; k < (VEC ? 0 : PPT); ++k) sP[tid + k * 256] = rpv[k];
   };
   if (blk < a.ntiles) issue(blk);
   for (int tile = blk; tile < a.ntiles; tile += a.nblk) {
@@ -566,6 +625,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_layers_kernel(const float* _
 using namespace tg;
 
 constexpr int SC_MAXBLK = 768;      // persistent blocks of the small-ca kernel (3 per CU)
+// in-workgroup K split (WgradArgs::kmode): the workspace holds kmode's extra partials when cb_total <= 64
+static int wgrad_kmode(int ca, int cb, int cb_total) {
+  return (ca <= 32 ? 1 : 0) | (cb <= 32 && cb_total <= 64 ? 2 : 0);
+}
 // tile geometry of an un-phased launch: 0 = 2 x 32, 1 = 4 x 16 (maps up to 16 wide), 2 = 8 x 8 (up to 8 wide)
 static int wgrad_geo(int h, int w) { return w <= 8 && h > 2 ? 2 : (w <= 16 && h > 2 ? 1 : 0); }
 static void wgrad_tile(int geo, int* r, int* tw) {
@@ -574,8 +637,12 @@ static void wgrad_tile(int geo, int* r, int* tw) {
 }
 static int wgrad_nsplit(int n, int h, int w, int ca, int cb, int geo = 0) {
   if (ca <= 4 && geo != 3) {
+    // persistent blocks: at most 3 per CU, and at least ~3 tiles each (a block's final reduction and
+    // its partial cost about one tile)
     const int nt = n * cdiv(h, SC_TR) * cdiv(w, SC_TW), per_b = SC_MAXBLK / cdiv(cb, 64);
-    return nt < per_b ? nt : (per_b > 0 ? per_b : 1);
+    int nb = nt < per_b ? nt : (per_b > 0 ? per_b : 1);
+    if (nb > 256 / cdiv(cb, 64) && nb * 3 > nt) nb = nt / 3 > 256 / cdiv(cb, 64) ? nt / 3 : 256 / cdiv(cb, 64);
+    return nb > 0 ? nb : 1;
   }
   int r, tw;
   wgrad_tile(geo, &r, &tw);
@@ -592,7 +659,13 @@ extern "C" size_t tg_wgrad3x3_workspace_floats(int n, int ca, int cb_total, int 
   if (n <= 0 || ca <= 0 || cb_total <= 0 || h <= 0 || w <= 0) return 0;
   // (the un-phased launch may fold the tile for a narrow map; phased launches use 2 x 32: the larger count)
   const int s0 = wgrad_nsplit(n, h, w, ca, cb_total), s1 = wgrad_nsplit(n, h, w, ca, cb_total, wgrad_geo(h, w));
-  return (size_t)(s0 > s1 ? s0 : s1) * ca * cb_total * 9;
+  const int ks = (ca <= 32 ? 2 : 1) * (cb_total <= 64 ? 2 : 1);        // room for wgrad_kmode's extra partials
+  size_t need = (size_t)(s0 > s1 ? s0 : s1) * ks * ca * cb_total * 9;
+  if (ca > 4) {        // a launch over <= 4 of the cb_total columns goes to the small-ca kernel, operands exchanged
+    const size_t sw = (size_t)wgrad_nsplit(n, h, w, 4, ca) * 4 * ca * 9;
+    if (sw > need) need = sw;
+  }
+  return need;
 }
 
 extern "C" size_t tg_wgrad3x3_convt_workspace_floats(int n, int ci, int co, int h, int w) {
@@ -614,7 +687,19 @@ template <class G>
 static void launch_geo(const WgradArgs& a, unsigned blocks, hipStream_t s, bool vec) {
   if (vec) launch_geo2<G, true>(a, blocks, s); else launch_geo2<G, false>(a, blocks, s);
 }
+template <bool VEC, int KS>
+static void launch_ks(const WgradArgs& a, unsigned blocks, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_mfma_ks_kernel<VEC, KS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)WgGeoStd::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad3x3_mfma_ks_kernel<VEC, KS>), dim3(blocks), dim3(256), WgGeoStd::LDS_BYTES, s, a);
+}
 static void launch_std(const WgradArgs& a, unsigned blocks, hipStream_t s, bool vec) {
+  if (a.kmode == 3) { if (vec) launch_ks<true, 4>(a, blocks, s); else launch_ks<false, 4>(a, blocks, s); return; }
+  if (a.kmode) { if (vec) launch_ks<true, 2>(a, blocks, s); else launch_ks<false, 2>(a, blocks, s); return; }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_mfma_kernel),
@@ -625,6 +710,14 @@ static void launch_std(const WgradArgs& a, unsigned blocks, hipStream_t s, bool 
   }
   if (vec) hipLaunchKernelGGL(wgrad3x3_mfma_vec_kernel, dim3(blocks), dim3(256), WgGeoStd::LDS_BYTES, s, a);
   else hipLaunchKernelGGL(wgrad3x3_mfma_kernel, dim3(blocks), dim3(256), WgGeoStd::LDS_BYTES, s, a);
+}
+static void launch_smallca(const WgradSmallArgs& sa, int nseg, hipStream_t s) {
+  bool vec = sa.w % 4 == 0 && sa.p_ns % 4 == 0 && sa.q_ns % 4 == 0;
+  for (int i = 0; i < nseg && vec; ++i)
+    if (((uintptr_t)sa.pseg[i] | (uintptr_t)sa.qseg[i]) & 15) vec = false;
+  static const int novec = TG_LAB_ENV("TG_WGRAD_NOVEC", 0);
+  if (vec && !novec) hipLaunchKernelGGL(wgrad3x3_smallca_kernel<true>, dim3((unsigned)(sa.nblk * sa.nbb)), dim3(256), 0, s, sa);
+  else hipLaunchKernelGGL(wgrad3x3_smallca_kernel<false>, dim3((unsigned)(sa.nblk * sa.nbb)), dim3(256), 0, s, sa);
 }
 // the vector staging needs whole 16-byte groups: widths that are multiples of 4 and aligned planes
 static bool wgrad_vec_ok(const WgradArgs& a, int nseg) {
@@ -661,13 +754,35 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
     sa.nbb = cdiv(cb, 64);
     sa.nblk = wgrad_nsplit(n, h, w, ca, cb_total);        // = what the workspace was sized with (cb <= cb_total)
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad3x3_smallca_kernel, dim3((unsigned)(sa.nblk * sa.nbb)), dim3(256), 0, s, sa);
+    launch_smallca(sa, nseg, s);
     int rc = check_launch("wgrad3x3_smallca");
     if (rc != TG_OK) return rc;
     const long long total = (long long)ca * cb * 9;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, grad,
-                       sa.nblk, ca, cb, cb_total, cb_off, accumulate);
+                       sa.nblk, ca, cb, cb_total, cb_off, accumulate, 0);
     return check_launch("wgrad_reduce");
+  }
+  if (cb <= 4 && !cphase && !stride2) {
+    // few SHIFTED channels: the small-ca kernel with the operands exchanged (wgrad_reduce_swapped_kernel)
+    WgradSmallArgs sa{};
+    for (int i = 0; i < nseg; ++i) {
+      TG_REQUIRE(p_list[i] && q_list[i], TG_E_ARG, "wgrad3x3: null segment %d", i);
+      sa.pseg[i] = q_list[i]; sa.qseg[i] = p_list[i];
+    }
+    const int n = nseg * n_per_seg;
+    sa.n_per_seg = n_per_seg; sa.part = workspace; sa.p_ns = q_nstride; sa.q_ns = p_nstride;
+    sa.ca = cb; sa.cb = ca; sa.cb_total = ca; sa.cb_off = 0; sa.n = n; sa.h = h; sa.w = w;
+    sa.tiles_x = cdiv(w, SC_TW); sa.tiles_y = cdiv(h, SC_TR); sa.ntiles = n * sa.tiles_x * sa.tiles_y;
+    sa.nbb = cdiv(ca, 64);
+    sa.nblk = wgrad_nsplit(n, h, w, cb, ca);               // the small-ca rule with the roles exchanged
+    hipStream_t s = (hipStream_t)stream;
+    launch_smallca(sa, nseg, s);
+    int rc = check_launch("wgrad3x3_smallca(swapped)");
+    if (rc != TG_OK) return rc;
+    const long long total = (long long)ca * cb * 9;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace,
+                       grad, sa.nblk, ca, cb, cb_total, cb_off, accumulate, 1);
+    return check_launch("wgrad_reduce(swapped)");
   }
   WgradArgs a{};
   for (int i = 0; i < nseg; ++i) {
@@ -697,6 +812,8 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
   hipStream_t s = (hipStream_t)stream;
   static const int novec = TG_LAB_ENV("TG_WGRAD_NOVEC", 0);      // lab: A/B of the two staging forms
   const bool vec = !novec && wgrad_vec_ok(a, nseg);
+  if (geo == 0 && !cphase) a.kmode = wgrad_kmode(ca, cb, cb_total);
+  const int ks = a.kmode == 3 ? 4 : (a.kmode ? 2 : 1);
   if (geo == 0) {
     launch_std(a, blocks, s, vec);
   } else if (geo == 1) {
@@ -710,7 +827,7 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
   if (rc != TG_OK) return rc;
   long long total = (long long)ca * cb * 9;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace,
-                     grad, a.nsplit, ca, cb, cb_total, cb_off, accumulate);
+                     grad, a.nsplit * ks, ca, cb, cb_total, cb_off, accumulate, 0);
   return check_launch("wgrad_reduce");
 }
 

@@ -38,7 +38,10 @@ def ops():
                                             (2, 3, 64, 10, 34), (1, 128, 256, 5, 9), (1, 64, 3, 20, 36),
                                             # narrow maps: the weight gradient folds its pixel tile to 4 x 16 / 8 x 8
                                             (5, 128, 128, 16, 16), (7, 256, 128, 8, 8), (3, 64, 96, 11, 13),
-                                            (9, 256, 256, 4, 4), (2, 32, 64, 19, 7), (300, 64, 64, 8, 8)])
+                                            (9, 256, 256, 4, 4), (2, 32, 64, 19, 7), (300, 64, 64, 8, 8),
+                                            # waves sharing a tile's pixels (<= 32 channels on a side), <= 4 shifted channels
+                                            (2, 27, 64, 20, 36), (3, 32, 64, 9, 33), (2, 64, 32, 12, 40), (2, 3, 32, 16, 24),
+                                            (1, 4, 40, 7, 19), (2, 2, 3, 8, 64)])
 def test_conv3x3_dgrad_and_wgrad(ops, n, cin, cout, h, w):
     x = rs(1, (n, cin, h, w)).requires_grad_(True)
     wt = (rs(2, (cout, cin, 3, 3)) / (3.0 * cin ** 0.5)).requires_grad_(True)
