@@ -125,6 +125,15 @@ int tg_conv3x3_fwd_phased_masked(const float* x, int64_t x_nstride, const float*
                                  float* y, int64_t y_nstride, int n, int cin, int cout, int h, int w,
                                  int act, int tapsel, int cphase, int taps_phase0, int taps_phase1,
                                  tg_stream_t stream);
+/* The same launch with the channel chunks split over `ksplit` workgroup sets (deterministic: partial sums
+ * [ksplit][n][cout][h][w] in `partials`, added in a fixed order by the finalize launch, which also applies
+ * bias / act) -- for the critic's deeper blocks, whose 48-192 tiles cannot fill 256 CUs.
+ * tg_conv3x3_phased_pick_ksplit returns the recommended factor (1 = use tg_conv3x3_fwd_phased). */
+int tg_conv3x3_phased_pick_ksplit(int n, int cin, int cout, int h, int w, int ocb);
+int tg_conv3x3_fwd_phased_splitk(const float* x, int64_t x_nstride, const float* w_packed, int ocb,
+                                 const float* bias, float* y, int n, int cin, int cout, int h, int w,
+                                 int act, int tapsel, int cphase, int taps_phase0, int taps_phase1,
+                                 int ksplit, float* partials, tg_stream_t stream);
 /* tg_conv3x3_fwd followed by a ReLU-backward mask in the same epilogue:
  *   y = relu_mask > 0 ? y : 0      (relu_mask: (n,cout,h,w) fp32, e.g. a ReLU layer's output)
  * Used by the training tape: the data-gradient conv of a layer (weights packed with

@@ -81,6 +81,8 @@ SIGNATURES = {
     'tg_wgrad3x3': (I, [P, I64, P, I64, P, P, I, I, I, I, I, I, I, I, P]),
     'tg_wgrad3x3_multi': (I, [P, P, I, I64, I64, P, P, I, I, I, I, I, I, I, I, P]),
     'tg_wgrad3x3_multi_phased': (I, [P, P, I, I64, I64, P, P, I, I, I, I, I, I, I, I, I, P]),
+    'tg_conv3x3_phased_pick_ksplit': (I, [I, I, I, I, I, I]),
+    'tg_conv3x3_fwd_phased_splitk': (I, [P, I64, P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P]),
     'tg_wgrad3x3_convt_workspace_floats': (SZ, [I, I, I, I, I]),
     'tg_wgrad3x3_convt_multi': (I, [P, P, I, P, P, I, I, I, I, I, I, P]),
     'tg_bias_grad_multi': (I, [P, I, P, I, I, I, I, P]),

@@ -1031,6 +1031,36 @@ extern "C" int tg_conv3x3_fwd_phased_masked(const float* x, int64_t x_nstride, c
                       taps_phase1);
 }
 
+// Split factor for a phased launch that cannot fill the device (the critic's deeper 4x4 / s2 blocks:
+// 48-192 workgroups walking 32-64 channel chunks, each chunk a full load -> LDS -> MFMA round trip
+// with nothing else resident on the CU -- 67 us for 0.8 GFLOP at crop 128).  1 = no split.
+extern "C" int tg_conv3x3_phased_pick_ksplit(int n, int cin, int cout, int h, int w, int ocb) {
+  if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (ocb != 32 && ocb != 64)) return 1;
+  const int rows = conv3x3_rows_per_wg(ocb, (long long)n * h * w);
+  const long long wgs = (long long)cdiv(w, TW) * cdiv(h, rows) * cdiv(cout, ocb) * n;
+  const int nchunk = cdiv(cin, CK);
+  if (wgs >= 384 || nchunk < 16) return 1;
+  int ks = 2;
+  while (ks < 8 && wgs * ks * 2 <= 1024 && nchunk / (ks * 2) >= 4) ks *= 2;
+  return ks;
+}
+
+extern "C" int tg_conv3x3_fwd_phased_splitk(const float* x, int64_t x_nstride, const float* w_packed, int ocb,
+                                            const float* bias, float* y, int n, int cin, int cout, int h, int w,
+                                            int act, int tapsel, int cphase, int taps_phase0, int taps_phase1,
+                                            int ksplit, float* partials, tg_stream_t stream) {
+  TG_REQUIRE(y && partials, TG_E_ARG, "conv3x3_fwd_phased_splitk: null pointer");
+  TG_REQUIRE(tapsel == 1 || tapsel == 2, TG_E_ARG, "conv3x3_fwd_phased_splitk: tapsel=%d", tapsel);
+  TG_REQUIRE(ksplit >= 2 && ksplit <= 16 && ksplit <= cdiv(cin, CK), TG_E_ARG,
+             "conv3x3_fwd_phased_splitk: ksplit=%d for cin=%d", ksplit, cin);
+  TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_LRELU02, TG_E_ARG, "conv3x3_fwd_phased_splitk: act=%d", act);
+  int rc = conv3x3_impl(x, x_nstride, cin, nullptr, 0, w_packed, ocb, nullptr, nullptr, 0, partials,
+                        (int64_t)cout * h * w, n, cin, cout, h, w, TG_ACT_NONE, ksplit, partials, stream, nullptr, 0,
+                        tapsel, cphase, taps_phase0, taps_phase1);
+  if (rc != TG_OK) return rc;
+  return conv3x3_splitk_finalize(partials, ksplit, bias, act, 0, y, n, cout, h, w, stream);
+}
+
 // shapes the stride-2 one-shot kernel takes: one 64-channel block, cin <= 64, at most 1024 one-row tiles
 // (two workgroups per CU: two rounds; measured against the phased form on s2d(x) in tools/time_ops.py)
 static const int S2_MAX_TILES = 1024;

@@ -142,6 +142,15 @@ def conv3x3_phased(x, wpk, cin, cout, ocb, tapsel, cphase, taps_phase0, taps_pha
         _chk(relu_mask, 'relu_mask')
         if relu_mask.shape != out.shape:
             raise L.TecoganHipError('conv3x3_phased: relu_mask shape mismatch')
+    ks = 1 if relu_mask is not None or not out.is_contiguous() else \
+        L.lib().tg_conv3x3_phased_pick_ksplit(n, cin, cout, h, w, ocb)
+    if ks > 1:          # too few tiles for the device: channel chunks split over ks workgroup sets + finalize
+        part = torch.empty(ks * n * cout * h * w, dtype=torch.float32, device=x.device)
+        L.check(L.lib().tg_conv3x3_fwd_phased_splitk(x.data_ptr(), cin * h * w, wpk.data_ptr(), ocb, None,
+                                                     out.data_ptr(), n, cin, cout, h, w, ACT_NONE, int(tapsel),
+                                                     int(cphase), int(taps_phase0), int(taps_phase1), ks,
+                                                     part.data_ptr(), _stream()), 'tg_conv3x3_fwd_phased_splitk')
+        return out
     L.check(L.lib().tg_conv3x3_fwd_phased_masked(x.data_ptr(), cin * h * w, wpk.data_ptr(), ocb, None,
                                                  _ptr(relu_mask), cout * h * w, out.data_ptr(), cout * h * w,
                                                  n, cin, cout, h, w, ACT_NONE, int(tapsel), int(cphase),
