@@ -226,6 +226,17 @@ int64_t tg_conv3x3_chain_flag_ints(int n_layers, int n, int h, int w);
 int tg_conv3x3_chain_supported(int n, int h, int w, int cmax);
 size_t tg_conv3x3_pack16_floats(void);
 int tg_conv3x3_pack16(const float* w, float* w_packed, int cin, int cout, int transposed, tg_stream_t stream);
+/* All the layers of a chain packed by one launch.  Item: source weights (O, i_total, 3, 3), of which the
+ * input-channel slice [i_off, i_off + I) is used; transposed 0: the layer (cin = I, cout = O), 2: its data
+ * gradient (cin = O, cout = I); out: tg_conv3x3_chain_packed_floats(pack_layout, cin) floats, in the layout
+ * of tg_conv3x3_pack16 (16) / tg_conv3x3_pack with ocb 64 (64). */
+typedef struct tg_pack_item {
+  const float* w;
+  float* out;
+  int cin, cout, transposed, i_total, i_off;
+} tg_pack_item;
+size_t tg_conv3x3_chain_packed_floats(int pack_layout, int cin);
+int tg_conv3x3_chain_pack(const tg_pack_item* items, int n_items, int pack_layout, tg_stream_t stream);
 int tg_conv3x3_chain(const tg_chain_layer* layers, int n_layers, int n, int h, int w, int pack_layout,
                      int32_t* flags, int32_t* err, uint32_t epoch, int poll_limit, tg_stream_t stream);
 /* SRNet's conv_in + nb residual blocks on one training frame (tecogan_nets.py:108-116, :141-143) and

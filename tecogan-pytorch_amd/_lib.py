@@ -42,6 +42,11 @@ class PackedLayer(C.Structure):
     _fields_ = [('w', C.c_void_p), ('b', C.c_void_p)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('out', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('transposed', C.c_int),
+                ('i_total', C.c_int), ('i_off', C.c_int)]
+
+
 class LayerWeights(C.Structure):
     _fields_ = [('w', C.c_void_p), ('b', C.c_void_p), ('u', C.c_void_p)]
 
@@ -117,6 +122,8 @@ SIGNATURES = {
     'tg_conv3x3_chain_supported': (I, [I, I, I, I]),
     'tg_conv3x3_pack16_floats': (SZ, []),
     'tg_conv3x3_pack16': (I, [P, P, I, I, I, P]),
+    'tg_conv3x3_chain_packed_floats': (SZ, [I, I]),
+    'tg_conv3x3_chain_pack': (I, [P, I, I, P]),
     'tg_conv3x3_chain': (I, [C.POINTER(ChainLayer), I, I, I, I, I, P, P, C.c_uint32, I, P]),
     'tg_srnet_body_fwd': (I, [C.POINTER(PackedLayer), I, I, P, I, P, I, P, I, I, I, I, P, P, C.c_uint32, I, P]),
     'tg_srnet_body_bwd': (I, [C.POINTER(PackedLayer), I, I, P, P, P, I, I, I, I, I, P, P, C.c_uint32, I, P]),

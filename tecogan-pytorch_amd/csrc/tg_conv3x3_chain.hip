@@ -534,6 +534,60 @@ extern "C" int tg_conv3x3_pack16(const float* w, float* w_packed, int cin, int c
   return check_launch("pack3x3_m16");
 }
 
+// Every layer of a chain packed by ONE launch (the training step re-packs 2 x 21 weight tensors after each
+// optimiser step: 42 launches of ~3 us otherwise).  Item i: source tensor (O, i_total, 3, 3), of which the
+// input-channel slice [i_off, i_off + I) is used; transposed = 0: the layer itself (cin = I, cout = O),
+// 2: its data gradient (cin = O, cout = I, taps rotated).  blockIdx.y = item.
+struct PackItems { tg_pack_item it[RC_MAXL]; };
+__global__ void chain_pack_kernel(PackItems p, int layout) {
+  const tg_pack_item& q = p.it[blockIdx.y];
+  const int cin = q.cin, cout = q.cout;
+  const int total = layout == 16 ? 2 * 8 * 9 * 64 * 4 : cdiv(cin, 8) * 9 * 8 * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int oc, ic, tap;
+    if (layout == 16) {                      // (pack3x3_m16_kernel)
+      const int e = i & 3, lane = (i >> 2) & 63;
+      int t = i >> 8;
+      tap = t % 9; t /= 9;
+      const int chunk = t & 7, och = t >> 3;
+      oc = och * 32 + (e >> 1) * 16 + (lane & 15); ic = chunk * 8 + (e & 1) * 4 + (lane >> 4);
+    } else {                                 // (pack3x3_kernel, one 64-channel block)
+      const int j = i & 3;
+      int t = i >> 2;
+      const int o = t & 63; t >>= 6;
+      const int half = t & 1; t >>= 1;
+      tap = t % 9;
+      oc = o; ic = (t / 9) * 8 + 4 * half + j;
+    }
+    float v = 0.f;
+    if (oc < cout && ic < cin)
+      v = q.transposed == 2 ? q.w[((size_t)ic * q.i_total + q.i_off + oc) * 9 + (8 - tap)]
+                            : q.w[((size_t)oc * q.i_total + q.i_off + ic) * 9 + tap];
+    q.out[i] = v;
+  }
+}
+
+extern "C" size_t tg_conv3x3_chain_packed_floats(int pack_layout, int cin) {
+  return pack_layout == 16 ? (size_t)2 * 8 * 9 * 64 * 4 : (size_t)cdiv(cin, 8) * 9 * 8 * 64;
+}
+
+extern "C" int tg_conv3x3_chain_pack(const tg_pack_item* items, int n_items, int pack_layout, tg_stream_t stream) {
+  TG_REQUIRE(items && n_items >= 1 && n_items <= RC_MAXL, TG_E_ARG, "conv3x3_chain_pack: %d items (1..%d)", n_items, RC_MAXL);
+  TG_REQUIRE(pack_layout == 16 || pack_layout == 64, TG_E_ARG, "conv3x3_chain_pack: layout %d (16 | 64)", pack_layout);
+  PackItems p{};
+  for (int i = 0; i < n_items; ++i) {
+    const tg_pack_item& q = items[i];
+    TG_REQUIRE(q.w && q.out && q.cin > 0 && q.cin <= 64 && q.cout > 0 && q.cout <= 64 &&
+                   (q.transposed == 0 || q.transposed == 2) && q.i_off >= 0 &&
+                   q.i_off + (q.transposed == 2 ? q.cout : q.cin) <= q.i_total, TG_E_ARG,
+               "conv3x3_chain_pack: item %d cin=%d cout=%d transposed=%d slice %d of %d", i, q.cin, q.cout, q.transposed,
+               q.i_off, q.i_total);
+    p.it[i] = q;
+  }
+  hipLaunchKernelGGL(chain_pack_kernel, dim3(144, (unsigned)n_items), dim3(256), 0, (hipStream_t)stream, p, pack_layout);
+  return check_launch("chain_pack");
+}
+
 // 0: the shape cannot run as a chained launch on this device (too many tiles to be resident at
 // once, channels > 64); else the number of workgroups per tile the launcher will use: 4 = the
 // 16 x 16 x 4 form (weights packed by tg_conv3x3_pack16), 2 / 1 = the 32 x 32 x 2 forms

@@ -370,18 +370,20 @@ def srnet_body(tape, srnet, lr, tran):
     n, c_lr, h, w = lr.shape
     c_tran, nf = tran.shape[1], conv_in.cout
     fw = (L.PackedLayer * nl)()
-    keep = []
     layout = 16 if _ChainState.parts(n, h, w) == 4 else 64
+    # all 2 x (1 + 2nb) packs (forward, data gradient) of the body by two launches, cached on the network
+    # until a parameter changes (every layer is updated by the same optimiser step: first and last are checked)
+    ver = (_ver(layers[0].weight), _ver(layers[-1].weight), layout, c_lr)
+
+    def build():
+        ws = [m.weight.detach() for m in layers]
+        f = ops.chain_pack([(wt, 0, wt.shape[1], 0) for wt in ws], layout)
+        # (the data gradient of conv_in only reaches `tran`: input channels [c_lr, c_lr + c_tran))
+        d = ops.chain_pack([(ws[0], c_lr, c_tran, 2)] + [(wt, 0, wt.shape[1], 2) for wt in ws[1:]], layout)
+        return f, d
+    keep, dgp = _CACHE.get(srnet, ('body',), ver, build)
     for i, m in enumerate(layers):
-        if layout == 16:
-            pk = _CACHE.get(m, ('fw16',), _ver(m.weight), lambda m=m: ops.pack_conv3x3_m16(m.weight))
-        else:
-            pk, ocb = m.packed()
-            if ocb != 64:         # the chained kernel reads the 64-channel-block layout whatever cout is
-                pk = _CACHE.get(m, ('fw64',), _ver(m.weight),
-                                lambda m=m: ops.pack_conv3x3(m.weight.detach().contiguous(), ocb=64)[0])
-        keep.append(pk)
-        fw[i].w, fw[i].b = pk.data_ptr(), m.bias.data_ptr()
+        fw[i].w, fw[i].b = keep[i].data_ptr(), m.bias.data_ptr()
     acts = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=lr.device)
     flags, err, epoch = _ChainState.buffers(nl + 1, n, h, w, lr.device)
     st = ops._stream()
@@ -397,31 +399,9 @@ def srnet_body(tape, srnet, lr, tran):
         if g is None:
             return
         dg = (L.PackedLayer * nl)()
-        hold = []
-        w_in = conv_in.weight
-        # (ocb = 64 explicitly: pack_conv3x3_dgrad would pick the 32-channel layout for c_tran <= 32,
-        #  e.g. the 12 warped-frame channels of a 2x model)
-        if layout == 16:
-            pk0 = _CACHE.get(conv_in, ('dg16', 1), _ver(w_in),
-                             lambda: ops.pack_conv3x3_m16(w_in.detach()[:, c_lr:].contiguous(), transposed=2))
-            hold.append(pk0)
-            dg[0].w = pk0.data_ptr()
-        else:
-            pk0 = _CACHE.get(conv_in, ('dg64', 1), _ver(w_in), lambda: ops.pack_conv3x3_dgrad(
-                w_in.detach()[:, c_lr:].contiguous(), ocb=64))
-            hold.append(pk0)
-            dg[0].w = pk0[0].data_ptr()
-        for i, m in enumerate(layers[1:], 1):
-            wm = m.weight
-            if layout == 16:
-                pk = _CACHE.get(m, ('dg16', 0), _ver(wm), lambda wm=wm: ops.pack_conv3x3_m16(wm, transposed=2))
-                hold.append(pk)
-                dg[i].w = pk.data_ptr()
-            else:
-                pk = _CACHE.get(m, ('dg64', 0), _ver(wm),
-                                lambda wm=wm: ops.pack_conv3x3_dgrad(wm.detach().contiguous(), ocb=64))
-                hold.append(pk)
-                dg[i].w = pk[0].data_ptr()
+        hold = dgp
+        for i in range(nl):
+            dg[i].w = dgp[i].data_ptr()
         dz = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=g.device)
         dz[nl - 1].copy_(g)       # the gradient of the body's output lives in the block's last slot
         d_tran = torch.empty(n, c_tran, h, w, dtype=torch.float32, device=g.device)

@@ -172,6 +172,27 @@ def pack_conv3x3_m16(weight, transposed=0):
     return out
 
 
+def chain_pack(items, layout):
+    """tg_conv3x3_chain_pack: items = [(weight (O, I_total, 3, 3), i_off, i_cnt, transposed)] -> list of packed
+    tensors (views of one buffer) in the chained kernels' layout `layout` (16 | 64), ONE launch."""
+    lib = L.lib()
+    arr = (L.PackItem * len(items))()
+    sizes = []
+    for wt, i_off, i_cnt, tr in items:
+        _chk(wt, 'weight')
+        cin, cout = (wt.shape[0], i_cnt) if tr == 2 else (i_cnt, wt.shape[0])
+        sizes.append(int(lib.tg_conv3x3_chain_packed_floats(layout, cin)))
+    buf = torch.empty(sum(sizes), dtype=torch.float32, device=items[0][0].device)
+    outs, off = [], 0
+    for a, (wt, i_off, i_cnt, tr), sz in zip(arr, items, sizes):
+        o = buf[off:off + sz]; off += sz
+        outs.append(o)
+        a.w, a.out, a.transposed, a.i_total, a.i_off = wt.data_ptr(), o.data_ptr(), tr, wt.shape[1], i_off
+        a.cin, a.cout = (wt.shape[0], i_cnt) if tr == 2 else (i_cnt, wt.shape[0])
+    L.check(lib.tg_conv3x3_chain_pack(arr, len(items), layout, _stream()), 'tg_conv3x3_chain_pack')
+    return outs
+
+
 def conv3x3s2_supported(n, cin, cout, h_out, w_out):
     return bool(L.lib().tg_conv3x3s2_supported(n, cin, cout, h_out, w_out))
 
