@@ -77,17 +77,19 @@ def test_convt_weight_gradient_straight_from_dz(ops, nseg, n, ci, co, h, w):
     assert relerr(g, 2 * wt.grad) <= 2e-5
 
 
-def test_wgrad_two_sources(ops):
-    """cat[x1(3ch), x2(48ch)] input: two calls into column ranges of one gradient."""
-    x = rs(1, (2, 51, 16, 24)).requires_grad_(True)
-    wt = (rs(2, (64, 51, 3, 3)) / 20).requires_grad_(True)
-    dz = rs(3, (2, 64, 16, 24))
+@pytest.mark.parametrize('cout,c1,c2,h,w', [(64, 3, 48, 16, 24), (64, 16, 16, 12, 40), (32, 12, 20, 9, 36), (48, 2, 30, 7, 21)])
+def test_wgrad_two_sources(ops, cout, c1, c2, h, w):
+    """cat[x1, x2] input: two calls into column ranges of one gradient (3 + 48: conv_in; the others put
+    the column offset on the paths where waves share a tile's pixels / the operands are exchanged)."""
+    x = rs(1, (2, c1 + c2, h, w)).requires_grad_(True)
+    wt = (rs(2, (cout, c1 + c2, 3, 3)) / 20).requires_grad_(True)
+    dz = rs(3, (2, cout, h, w))
     F.conv2d(x, wt, None, padding=1).backward(dz)
-    g = torch.zeros(64, 51, 3, 3, device='cuda')
+    g = torch.zeros(cout, c1 + c2, 3, 3, device='cuda')
     xd = x.detach()
-    ops.wgrad3x3(dev(dz), dev(xd[:, :3]), g, cb_off=0, accumulate=False)
-    ops.wgrad3x3(dev(dz), dev(xd[:, 3:]), g, cb_off=3, accumulate=False)
-    assert relerr(g, wt.grad) <= 2e-5
+    ops.wgrad3x3(dev(dz), dev(xd[:, :c1]), g, cb_off=0, accumulate=False)
+    ops.wgrad3x3(dev(dz), dev(xd[:, c1:]), g, cb_off=c1, accumulate=False)
+    assert relerr(g, wt.grad) <= 2e-5, relerr(g, wt.grad)
 
 
 @pytest.mark.parametrize('act', [1, 2, 3])
