@@ -496,6 +496,13 @@ def main():
             local_rank = 0
             torch.cuda.set_device(0)
             dist.init_process_group(backend='gloo')
+            # N processes on ONE GPU: the chained launches assume the process owns the device (every
+            # workgroup a launch waits for must get a slot while the waiters spin); with several processes
+            # time-sharing the CUs their fail-safe can trip (measured at 2 ranks: ~400 workgroups timed
+            # out, the plan fell back -- INTEGRATION.md).  The rehearsal walks the per-layer paths instead.
+            os.environ['TG_WINO_CHAIN'] = '0'
+            from tecogan_pytorch_amd.models.networks.tecogan_nets import SRNet
+            SRNet.chain_body = False
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))

@@ -148,6 +148,10 @@ class _ResBlock(nn.Module):
 class SRNet(nn.Module):
     """Reconstruction network, tecogan_nets.py:103-147."""
 
+    # training: conv_in + residual blocks of a frame as one chained launch when the shape allows
+    # (class-wide switch; an instance may override it)
+    chain_body = True
+
     def __init__(self, in_nc, out_nc, nf, nb, upsample_func, scale):
         super().__init__()
         self.scale = scale
@@ -159,7 +163,6 @@ class SRNet(nn.Module):
         self.conv_up = _block(ups)
         self.conv_out = _Conv(nf, out_nc)
         self.upsample_func = upsample_func
-        self.chain_body = True     # training: conv_in + residual blocks of a frame as one chained launch when the shape allows
 
     def layers(self):
         out = [self.conv_in['0']]

@@ -48,6 +48,12 @@ def main():
     from tecogan_pytorch_amd.models import define_model
     from tecogan_pytorch_amd.utils import dist_utils
     opt = make_opt()
+    if world > 1 and backend != 'nccl':
+        # the ranks share cuda:0: chained launches assume the process owns the device;
+        # this test is about the exchange, so the shared-GPU ranks run one launch per layer
+        os.environ['TG_WINO_CHAIN'] = '0'
+        from tecogan_pytorch_amd.models.networks.tecogan_nets import SRNet
+        SRNet.chain_body = False
     if world > 1:
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank),
                           WORLD_SIZE=str(world), LOCAL_RANK=str(rank if backend == 'nccl' else 0))
