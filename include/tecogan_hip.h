@@ -336,6 +336,14 @@ int tg_conv3x3_small_fwd_u8(const float* x, int64_t x_nstride, const float* w_oi
                             tg_stream_t stream);
 int tg_conv3x3_small_can_fuse_u8(const float* x, int64_t x_nstride, const float* y,
                                  int64_t y_nstride, int n, int cin, int h, int w);
+/* y = act(conv3x3(x) + bias) + res with an explicit residual tensor (n, cout, h, w) -- the training step
+ * computes the bicubic frame of `out += upsample_func(lr_curr)` (tecogan_nets.py:145) once per step instead
+ * of 16 taps per pixel in every epilogue.  w % 4 == 0, 16-byte aligned planes.  (Launches of a few
+ * workgroups -- the training frames -- run as 4-row tiles with the waves of a workgroup splitting the input
+ * channels, with or without a residual: tg_conv3x3_small_fwd picks that form by itself.) */
+int tg_conv3x3_small_fwd_res(const float* x, int64_t x_nstride, const float* w_oihw, const float* bias,
+                             const float* res, int64_t res_nstride, float* y, int64_t y_nstride, int n,
+                             int cin, int cout, int h, int w, int act, tg_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Fused: reflect-pad(bottom/right) -> scale * upsample -> backward_warp ->

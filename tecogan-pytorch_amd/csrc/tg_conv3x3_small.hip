@@ -37,6 +37,8 @@ struct SmallArgs {
   int tiles_x, tiles_y;
   uint8_t* u8;         // optional (n == 1): the same result as HWC uint8, float32_to_uint8
                        // (codes/utils/data_utils.py:80-87) fused into the epilogue
+  const float* res;    // optional (n, cout, h, w) residual added after the activation (training: the
+  long long res_ns;    // bicubic frame computed once per step); conv3x3_small_ks_kernel only
 };
 
 template <int COUT>
@@ -359,6 +361,144 @@ __global__ __launch_bounds__(256) void conv3x3_small_v2_kernel(SmallArgs a) {
   }
 }
 
+// ---- small frames (the training unroll: 2 x 128 x 128 / 2 x 256 x 256 HR pixels per launch) -------
+// The 16 x 64 tiles above give 32 / 128 workgroups there, each walking 16 channel chunks with a
+// global-load round trip per chunk: 39 us for 0.1 GFLOP (the step used the MFMA kernel instead, 3 of 32
+// output columns alive: 16 / 43 us).  Here a tile is 4 rows x 64 columns and the FOUR WAVES of a
+// workgroup split the input channels (wave k: chunks k, k + 4, ...), each staging its chunks into its
+// own slice of LDS -- no workgroup barrier inside the loop -- and the partial sums meet in LDS once at
+// the end (fixed order: deterministic).  4x the workgroups, 4x fewer dependent round trips each.
+constexpr int K_TH = 4, K_PH = K_TH + 2;
+constexpr int K_ITEMS = V_CK * K_PH * V_Q;          // 432 float4 per chunk
+constexpr int K_PER_T = (K_ITEMS + 63) / 64;        // 7 per lane
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_small_ks_kernel(SmallArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_in[4][V_CK][K_PH][V_RS];      // 29.2 KB; later the partial sums
+  const __attribute__((address_space(4))) float* wk =
+      (const __attribute__((address_space(4))) float*)a.wt;           // OIHW, wave-uniform: scalar loads
+  const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;
+  const int tcx = lane & 15, tcy = lane >> 4;
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int x0 = tx * S_TW, y0 = ty * K_TH;
+  const int hw = a.h * a.w;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (long long)n * a.x_ns), 0, a.cin * hw * 4, 0x00020000);
+  unsigned voff[K_PER_T];
+  int lds_off[K_PER_T];
+#pragma unroll
+  for (int i = 0; i < K_PER_T; ++i) {
+    const int idx = lane + i * 64;
+    const int c = idx / (K_PH * V_Q), rem = idx - c * (K_PH * V_Q);
+    const int r = rem / V_Q, q = rem - r * V_Q;
+    const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
+    const bool ok = idx < K_ITEMS && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+    voff[i] = ok ? (unsigned)((c * hw + gy * a.w + gx) * 4) : V_OOB;
+    lds_off[i] = idx < K_ITEMS ? (c * K_PH + r) * V_RS + 4 * q : -1;
+  }
+  const unsigned plane = (unsigned)hw * 4u;
+  float* mine = &s_in[kg][0][0][0];
+  f32x4 rinA[K_PER_T], rinB[K_PER_T];
+  auto load_chunk = [&](f32x4 (&rin)[K_PER_T], int ch) {
+#pragma unroll
+    for (int i = 0; i < K_PER_T; ++i)       // channels past cin fall beyond num_records and read as 0
+      rin[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rsrc, (int)(voff[i] + (unsigned)(ch * V_CK) * plane), 0, 0));
+  };
+  auto store_chunk = [&](const f32x4 (&rin)[K_PER_T]) {
+#pragma unroll
+    for (int i = 0; i < K_PER_T; ++i)
+      if (lds_off[i] >= 0) *reinterpret_cast<f32x4*>(mine + lds_off[i]) = rin[i];
+  };
+  float acc[COUT][S_PXT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o)
+#pragma unroll
+    for (int p = 0; p < S_PXT; ++p) acc[o][p] = 0.f;
+  auto compute = [&](int ch) {
+#pragma unroll
+    for (int c = 0; c < V_CK; ++c) {
+      const int cg = ch * V_CK + c;
+      if (cg < a.cin) {
+        float wreg[COUT][9];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o)
+#pragma unroll
+          for (int t = 0; t < 9; ++t) wreg[o][t] = wk[(o * a.cin + cg) * 9 + t];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const float* row = mine + (c * K_PH + tcy + ky) * V_RS + tcx * S_PXT;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(row);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 4);
+          const float v2 = row[8];
+          const float in6[6] = {v0[3], v1[0], v1[1], v1[2], v1[3], v2};
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+              const float wv = wreg[o][ky * 3 + kx];
+#pragma unroll
+              for (int p = 0; p < S_PXT; ++p) acc[o][p] += wv * in6[p + kx];
+            }
+        }
+      }
+    }
+  };
+  // this wave's chunks kg, kg + 4, ...: one chunk in LDS, the next two in registers (A / B alternate).
+  // A wave's LDS operations execute in program order, so its own writes / reads need no barrier.
+  const int nchunk = cdiv(a.cin, V_CK);
+  int ch = kg;
+  if (ch < nchunk) {
+    load_chunk(rinA, ch);
+    if (ch + 4 < nchunk) load_chunk(rinB, ch + 4);
+    store_chunk(rinA);
+    for (;;) {
+      if (ch + 8 < nchunk) load_chunk(rinA, ch + 8);
+      compute(ch);
+      ch += 4;
+      if (ch >= nchunk) break;
+      store_chunk(rinB);
+      if (ch + 8 < nchunk) load_chunk(rinB, ch + 8);
+      compute(ch);
+      ch += 4;
+      if (ch >= nchunk) break;
+      store_chunk(rinA);
+    }
+  }
+  // ---- the four waves' sums meet in LDS: red[kg][o * 4 + p][lane]
+  __syncthreads();
+  float* red = &s_in[0][0][0][0];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o)
+#pragma unroll
+    for (int p = 0; p < S_PXT; ++p) red[(kg * COUT * S_PXT + o * S_PXT + p) * 64 + lane] = acc[o][p];
+  __syncthreads();
+  if (tid < 64 * COUT) {
+    const int o = tid >> 6;
+    const int py = y0 + tcy, px0 = x0 + tcx * S_PXT;      // (lane = tid & 63: the same pixel quad)
+    if (py < a.h && px0 < a.w) {
+      const float bb = a.bias ? a.bias[o] : 0.f;
+      f32x4 ov;
+#pragma unroll
+      for (int p = 0; p < S_PXT; ++p) {
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sum += red[(g * COUT * S_PXT + o * S_PXT + p) * 64 + lane];
+        ov[p] = apply_act(sum + bb, a.act);
+      }
+      const long long off = (long long)o * hw + (long long)py * a.w + px0;
+      if (a.res) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + (long long)n * a.res_ns + off);
+#pragma unroll
+        for (int p = 0; p < S_PXT; ++p) ov[p] += rv[p];
+      }
+      *reinterpret_cast<f32x4*>(a.y + (long long)n * a.y_ns + off) = ov;
+    }
+  }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -378,11 +518,11 @@ extern "C" int tg_conv3x3_small_fwd(const float* x, int64_t x_nstride, const flo
                                  nullptr, n, cin, cout, h, w, act, stream);
 }
 
-extern "C" int tg_conv3x3_small_fwd_u8(const float* x, int64_t x_nstride, const float* w_oihw,
-                                       const float* bias, const float* up_src, int up_mode,
-                                       int up_scale, float* y, int64_t y_nstride, uint8_t* u8_out,
-                                       int n, int cin, int cout, int h, int w, int act,
-                                       tg_stream_t stream) {
+static int small_launch(const float* x, int64_t x_nstride, const float* w_oihw,
+                        const float* bias, const float* up_src, int up_mode,
+                        int up_scale, float* y, int64_t y_nstride, uint8_t* u8_out,
+                        int n, int cin, int cout, int h, int w, int act,
+                        tg_stream_t stream, const float* res, int64_t res_nstride) {
   TG_REQUIRE(x && w_oihw && y, TG_E_ARG, "conv3x3_small_fwd: null pointer");
   TG_REQUIRE(n > 0 && cin > 0 && cin <= 64 && cout >= 1 && cout <= 4 && h > 0 && w > 0,
              TG_E_SHAPE, "conv3x3_small_fwd: n=%d cin=%d (<=64) cout=%d (<=4) h=%d w=%d", n, cin,
@@ -397,7 +537,7 @@ extern "C" int tg_conv3x3_small_fwd_u8(const float* x, int64_t x_nstride, const 
   a.x = x; a.wt = w_oihw; a.bias = bias; a.up = up_src; a.y = y; a.x_ns = x_nstride;
   a.y_ns = y_nstride; a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
   a.up_mode = up_mode; a.up_scale = up_scale;
-  a.u8 = u8_out;
+  a.u8 = u8_out; a.res = res; a.res_ns = res_nstride;
   a.tiles_x = cdiv(w, S_TW); a.tiles_y = cdiv(h, S_TH);
   long long blocks = (long long)a.tiles_x * a.tiles_y * n;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "conv3x3_small: grid %lld", blocks);
@@ -409,6 +549,22 @@ extern "C" int tg_conv3x3_small_fwd_u8(const float* x, int64_t x_nstride, const 
   TG_REQUIRE(!u8_out || (n == 1 && vec_ok && ((uintptr_t)u8_out % 4 == 0)), TG_E_ARG,
              "conv3x3_small_fwd_u8: the fused uint8 output needs n == 1, w %% 4 == 0 and aligned planes "
              "(tg_conv3x3_small_can_fuse_u8)");
+  TG_REQUIRE(!res || (vec_ok && !up_src && !u8_out && ((uintptr_t)res % 16 == 0) && res_nstride % 4 == 0), TG_E_ARG,
+             "conv3x3_small_fwd_res: the residual form needs w %% 4 == 0, aligned planes, no up_src / uint8 output");
+  // few 16-row tiles (the training frames): 4-row tiles, the four waves of a workgroup split the channels
+  if (vec_ok && !up_src && !u8_out && (res || blocks < 512)) {
+    a.tiles_y = cdiv(h, K_TH);
+    const long long kb = (long long)a.tiles_x * a.tiles_y * n;
+    TG_REQUIRE(kb < (1ll << 31), TG_E_SHAPE, "conv3x3_small: grid %lld", kb);
+    dim3 kgrid((unsigned)kb);
+    switch (cout) {
+      case 1: hipLaunchKernelGGL(conv3x3_small_ks_kernel<1>, kgrid, t, 0, s, a); break;
+      case 2: hipLaunchKernelGGL(conv3x3_small_ks_kernel<2>, kgrid, t, 0, s, a); break;
+      case 3: hipLaunchKernelGGL(conv3x3_small_ks_kernel<3>, kgrid, t, 0, s, a); break;
+      default: hipLaunchKernelGGL(conv3x3_small_ks_kernel<4>, kgrid, t, 0, s, a); break;
+    }
+    return check_launch("conv3x3_small_ks");
+  }
   if (vec_ok) {
     switch (cout) {
       case 1: hipLaunchKernelGGL(conv3x3_small_v2_kernel<1>, g, t, 0, s, a); break;
@@ -425,4 +581,23 @@ extern "C" int tg_conv3x3_small_fwd_u8(const float* x, int64_t x_nstride, const 
     default: hipLaunchKernelGGL(conv3x3_small_kernel<4>, g, t, 0, s, a); break;
   }
   return check_launch("conv3x3_small");
+}
+
+extern "C" int tg_conv3x3_small_fwd_u8(const float* x, int64_t x_nstride, const float* w_oihw,
+                                       const float* bias, const float* up_src, int up_mode,
+                                       int up_scale, float* y, int64_t y_nstride, uint8_t* u8_out,
+                                       int n, int cin, int cout, int h, int w, int act,
+                                       tg_stream_t stream) {
+  return small_launch(x, x_nstride, w_oihw, bias, up_src, up_mode, up_scale, y, y_nstride, u8_out, n, cin, cout, h, w,
+                      act, stream, nullptr, 0);
+}
+
+// y = act(conv3x3(x) + bias) + res  (res: (n, cout, h, w), e.g. the bicubic frame of `out += upsample_func(lr)`,
+// tecogan_nets.py:145, computed once per training step); w % 4 == 0, 16-byte aligned planes.
+extern "C" int tg_conv3x3_small_fwd_res(const float* x, int64_t x_nstride, const float* w_oihw, const float* bias,
+                                        const float* res, int64_t res_nstride, float* y, int64_t y_nstride, int n,
+                                        int cin, int cout, int h, int w, int act, tg_stream_t stream) {
+  TG_REQUIRE(res, TG_E_ARG, "conv3x3_small_fwd_res: null residual");
+  return small_launch(x, x_nstride, w_oihw, bias, nullptr, 0, 1, y, y_nstride, nullptr, n, cin, cout, h, w, act, stream,
+                      res, res_nstride);
 }

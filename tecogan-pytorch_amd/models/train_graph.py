@@ -426,11 +426,13 @@ def srnet_body(tape, srnet, lr, tran):
 
 def conv3x3_small(tape, layer, x, act=NONE, up_src=None, up_mode=ops.UP_NONE, up_scale=1, res=None):
     """cout <= 4 head (flow[2] / conv_out).  `up_src` is data (no gradient).  `res` (data as well): the
-    already up-sampled residual -- the forward then runs on the MFMA kernel (3 of 32 output columns
-    used, but 12 us instead of the 39 us of the 32-workgroup VALU launch on a 2 x 128 x 128 frame)."""
+    already up-sampled residual, added by the small-cout kernel's 4-row form (waves split the input
+    channels); shapes it does not take go to the MFMA kernel (3 of 32 output columns used)."""
     w, b = layer.weight, layer.bias
     cout, cin = w.shape[0], w.shape[1]
-    if res is not None and act in (NONE, RELU, LRELU):
+    if res is not None and cin <= 64 and ops.conv3x3_small_res_ok(x, res):
+        y = ops.conv3x3_small(x, w, b, act, res=res)
+    elif res is not None and act in (NONE, RELU, LRELU):
         pk, ocb = layer.packed()
         y = ops.conv3x3(x, pk, b, cin, cout, ocb, act, res=res, ksplit=1)
     else:

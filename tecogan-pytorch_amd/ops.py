@@ -227,14 +227,28 @@ def convt3x3s2(x, wpk, bias, cout, act=ACT_NONE, out=None):
     return out
 
 
+def conv3x3_small_res_ok(x, res):
+    """whether tg_conv3x3_small_fwd_res takes this launch (w % 4 == 0, aligned planes)"""
+    return x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and res.data_ptr() % 16 == 0 and \
+        (x.shape[1] * x.shape[2] * x.shape[3]) % 4 == 0 and (res.shape[1] * res.shape[2] * res.shape[3]) % 4 == 0
+
+
 def conv3x3_small(x, weight, bias, act=ACT_NONE, up_src=None, up_mode=UP_NONE, up_scale=1,
-                  out=None):
+                  out=None, res=None):
     _chk(x, 'x')
     w_ = _chk(weight.detach(), 'weight')
     n, cin, h, w = x.shape
     cout = w_.shape[0]
     if out is None:
         out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    if res is not None:         # explicit residual tensor instead of an up-sampled source
+        _chk(res, 'res')
+        if up_src is not None or tuple(res.shape) != (n, cout, h, w):
+            raise L.TecoganHipError('conv3x3_small: res must be (n, cout, h, w) and excludes up_src')
+        L.check(L.lib().tg_conv3x3_small_fwd_res(
+            x.data_ptr(), cin * h * w, w_.data_ptr(), _ptr(bias), res.data_ptr(), cout * h * w,
+            out.data_ptr(), cout * h * w, n, cin, cout, h, w, act, _stream()), 'tg_conv3x3_small_fwd_res')
+        return out
     if up_src is not None:
         _chk(up_src, 'up_src')
     L.check(L.lib().tg_conv3x3_small_fwd(

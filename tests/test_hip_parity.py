@@ -481,6 +481,28 @@ def test_conv3x3_small(ops, cin, cout, h, w, act, up):
     assert err(out, ref) <= tol, err(out, ref)
 
 
+@pytest.mark.parametrize('n,cin,cout,h,w,act,with_res', [
+    (2, 64, 3, 128, 128, 0, True), (2, 64, 3, 6, 64, 0, True), (3, 40, 2, 9, 12, 1, False), (1, 64, 4, 5, 200, 2, True),
+    (2, 3, 3, 10, 8, 0, False), (36, 32, 2, 16, 16, 3, False)])
+def test_conv3x3_small_four_row_form(ops, n, cin, cout, h, w, act, with_res):
+    """The small-cout kernel's form for launches of few tiles (4-row tiles, the waves of a workgroup split the
+    input channels): with an explicit residual tensor (tg_conv3x3_small_fwd_res, the training step's conv_out)
+    and without (picked by tg_conv3x3_small_fwd itself)."""
+    import torch.nn.functional as F
+    x = rs(1, (n, cin, h, w), -1, 1)
+    wt = rs(2, (cout, cin, 3, 3), -1, 1) / (3.0 * cin ** 0.5)
+    b = rs(3, (cout,), -0.5, 0.5)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    ref = {0: ref, 1: torch.relu(ref), 2: F.leaky_relu(ref, 0.2), 3: torch.tanh(ref) * 24}[act]
+    res = rs(4, (n, cout, h, w), -1, 1) if with_res else None
+    if with_res:
+        ref = ref + res.double()
+        assert ops.conv3x3_small_res_ok(dev(x), dev(res))
+    out = ops.conv3x3_small(dev(x), dev(wt), dev(b), act, res=dev(res) if with_res else None)
+    tol = 2e-4 if act == 3 else 1e-5
+    assert err(out, ref) <= tol, err(out, ref)
+
+
 @pytest.mark.parametrize('deg,s,h,w', [('BD', 4, 22, 40), ('BD', 4, 21, 37), ('BI', 2, 22, 40),
                                        ('BD', 2, 19, 33), ('BI', 4, 16, 24)])
 def test_fused_flowup_warp_s2d_vs_oracle(ops, deg, s, h, w):
