@@ -341,6 +341,13 @@ int tg_conv3x3_small_can_fuse_u8(const float* x, int64_t x_nstride, const float*
  * of 16 taps per pixel in every epilogue.  w % 4 == 0, 16-byte aligned planes.  (Launches of a few
  * workgroups -- the training frames -- run as 4-row tiles with the waves of a workgroup splitting the input
  * channels, with or without a residual: tg_conv3x3_small_fwd picks that form by itself.) */
+/* The mirror image: cin <= 4, any number of output channels, no bias / activation, optional ReLU mask
+ * (y = relu_mask > 0 ? conv : 0) -- the data gradient of a cout <= 4 head (conv_out 64 -> 3, the flow head
+ * 32 -> 2): w_oihw = (cout, cin, 3, 3) of THIS op, i.e. the layer's weights with the channel roles
+ * swapped and the taps rotated by 180 degrees.  w % 4 == 0, 16-byte aligned planes. */
+int tg_conv3x3_fewin_fwd(const float* x, int64_t x_nstride, const float* w_oihw, const float* relu_mask,
+                         int64_t mask_nstride, float* y, int64_t y_nstride, int n, int cin, int cout,
+                         int h, int w, tg_stream_t stream);
 int tg_conv3x3_small_fwd_res(const float* x, int64_t x_nstride, const float* w_oihw, const float* bias,
                              const float* res, int64_t res_nstride, float* y, int64_t y_nstride, int n,
                              int cin, int cout, int h, int w, int act, tg_stream_t stream);

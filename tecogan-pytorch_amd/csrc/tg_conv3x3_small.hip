@@ -499,6 +499,84 @@ __global__ __launch_bounds__(256) void conv3x3_small_ks_kernel(SmallArgs a) {
   }
 }
 
+// ---- the mirror image: cin <= 4, many output channels -- the data gradient of a small-cout head
+// (conv_out 64 -> 3: dX = conv(dZ (3 ch), rot180 weights) to 64 channels, masked by the ReLU of the
+// layer below).  On the MFMA kernel K = 27 is padded to a 72-deep chunk and the launch is bound by its
+// epilogue: 31.7 us for 2 x 256 x 256 (33.5 MB written, 33.5 MB of mask read: ~13 us of traffic).
+// Here: tile 4 rows x 64 columns, the 3 x 6 x 72 patch in LDS once, a thread keeps its 3 x 3 x 6 input
+// window in registers and walks its wave's output channels (wave k: channels 16 k .. 16 k + 15 of every
+// 64) with the 27 weights of a channel as scalar operands: 108 FMAs, one mask load, one 16-byte store.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_fewin_kernel(SmallArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_in[CIN][K_PH][V_RS];
+  const __attribute__((address_space(4))) float* wk =
+      (const __attribute__((address_space(4))) float*)a.wt;           // (cout, CIN, 3, 3)
+  const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 6;
+  const int tcx = lane & 15, tcy = lane >> 4;
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int x0 = tx * S_TW, y0 = ty * K_TH;
+  const int hw = a.h * a.w;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (long long)n * a.x_ns), 0, CIN * hw * 4, 0x00020000);
+  constexpr int ITEMS = CIN * K_PH * V_Q;                  // <= 432 float4
+#pragma unroll
+  for (int i = 0; i < (ITEMS + 255) / 256; ++i) {
+    const int idx = tid + i * 256;
+    const int c = idx / (K_PH * V_Q), rem = idx - c * (K_PH * V_Q);
+    const int r = rem / V_Q, q = rem - r * V_Q;
+    const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
+    const bool ok = idx < ITEMS && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w;
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  rsrc, ok ? (int)((c * hw + gy * a.w + gx) * 4) : (int)V_OOB, 0, 0));
+    if (idx < ITEMS) *reinterpret_cast<f32x4*>(&s_in[c][r][4 * q]) = v;
+  }
+  __syncthreads();
+  float in[CIN][3][6];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const float* row = &s_in[c][tcy + ky][tcx * S_PXT];
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(row);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + 4);
+      in[c][ky][0] = v0[3]; in[c][ky][1] = v1[0]; in[c][ky][2] = v1[1]; in[c][ky][3] = v1[2]; in[c][ky][4] = v1[3];
+      in[c][ky][5] = row[8];
+    }
+  const int py = y0 + tcy, px0 = x0 + tcx * S_PXT;
+  if (py >= a.h || px0 >= a.w) return;                    // (w % 4 == 0: the four pixels are all inside or outside)
+  const float* mn = a.res ? a.res + (long long)n * a.res_ns : nullptr;      // (the ReLU mask travels in `res`)
+  float* yn = a.y + (long long)n * a.y_ns;
+  for (int og = kg * 16; og < a.cout; og += 64) {
+#pragma unroll 4
+    for (int oo = 0; oo < 16; ++oo) {
+      const int o = og + oo;
+      if (o >= a.cout) break;
+      float acc[S_PXT] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float wv = wk[((o * CIN + c) * 3 + ky) * 3 + kx];
+#pragma unroll
+            for (int p = 0; p < S_PXT; ++p) acc[p] += wv * in[c][ky][p + kx];
+          }
+      const long long off = (long long)o * hw + (long long)py * a.w + px0;
+      f32x4 ov = {acc[0], acc[1], acc[2], acc[3]};
+      if (mn) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mn + off);
+#pragma unroll
+        for (int p = 0; p < S_PXT; ++p) ov[p] = m[p] > 0.f ? ov[p] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(yn + off) = ov;
+    }
+  }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -600,4 +678,34 @@ extern "C" int tg_conv3x3_small_fwd_res(const float* x, int64_t x_nstride, const
   TG_REQUIRE(res, TG_E_ARG, "conv3x3_small_fwd_res: null residual");
   return small_launch(x, x_nstride, w_oihw, bias, nullptr, 0, 1, y, y_nstride, nullptr, n, cin, cout, h, w, act, stream,
                       res, res_nstride);
+}
+
+// y = relu_mask > 0 ? conv3x3(x) : 0 for cin <= 4 and any number of output channels (no bias / activation):
+// the data gradient of a cout <= 4 head, w_oihw = (cout, cin, 3, 3) of THIS op (for a gradient: the layer's
+// weights with the channel roles swapped and the taps rotated).  w % 4 == 0, 16-byte aligned planes.
+extern "C" int tg_conv3x3_fewin_fwd(const float* x, int64_t x_nstride, const float* w_oihw, const float* relu_mask,
+                                    int64_t mask_nstride, float* y, int64_t y_nstride, int n, int cin, int cout,
+                                    int h, int w, tg_stream_t stream) {
+  TG_REQUIRE(x && w_oihw && y, TG_E_ARG, "conv3x3_fewin_fwd: null pointer");
+  TG_REQUIRE(n > 0 && cin >= 1 && cin <= 4 && cout >= 1 && h > 0 && w > 0, TG_E_SHAPE,
+             "conv3x3_fewin_fwd: n=%d cin=%d (<= 4) cout=%d h=%d w=%d", n, cin, cout, h, w);
+  TG_REQUIRE((w % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && (x_nstride % 4 == 0) &&
+                 (y_nstride % 4 == 0) && (!relu_mask || (((uintptr_t)relu_mask % 16 == 0) && mask_nstride % 4 == 0)) &&
+                 ((long long)cout * h * w * 4 < (1ll << 31)),
+             TG_E_ARG, "conv3x3_fewin_fwd: needs w %% 4 == 0 and 16-byte aligned planes");
+  SmallArgs a{};
+  a.x = x; a.wt = w_oihw; a.y = y; a.x_ns = x_nstride; a.y_ns = y_nstride; a.cin = cin; a.cout = cout; a.h = h; a.w = w;
+  a.res = relu_mask; a.res_ns = mask_nstride;
+  a.tiles_x = cdiv(w, S_TW); a.tiles_y = cdiv(h, K_TH);
+  const long long blocks = (long long)a.tiles_x * a.tiles_y * n;
+  TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "conv3x3_fewin: grid %lld", blocks);
+  dim3 g((unsigned)blocks), t(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (cin) {
+    case 1: hipLaunchKernelGGL(conv3x3_fewin_kernel<1>, g, t, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(conv3x3_fewin_kernel<2>, g, t, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(conv3x3_fewin_kernel<3>, g, t, 0, s, a); break;
+    default: hipLaunchKernelGGL(conv3x3_fewin_kernel<4>, g, t, 0, s, a); break;
+  }
+  return check_launch("conv3x3_fewin");
 }

@@ -448,11 +448,17 @@ def conv3x3_small(tape, layer, x, act=NONE, up_src=None, up_mode=ops.UP_NONE, up
         if w.requires_grad:
             tape.defer_wgrad(('w', id(layer), 0), dz, x, _grad_buf(w), 0)
             tape.defer_bias(_grad_buf(b), dz)
-        pkd = _CACHE.get(layer, ('dg', 0), _ver(w),
-                         lambda: ops.pack_conv3x3_dgrad(w.detach().contiguous()))
         fuse = id(x) in tape.relu_outputs        # x = relu(...): deliver dZ of that layer directly
-        tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, cin, pkd[3], ksplit=1,
-                                     relu_mask=x if fuse else None), masked=fuse)
+        if ops.conv3x3_fewin_ok(dz, cin) and (not fuse or x.data_ptr() % 16 == 0):
+            # few channels in, many out: the VALU kernel (the MFMA one pads K = 9 cout to a 72-deep chunk)
+            wd = _CACHE.get(layer, ('dgw',), _ver(w),
+                            lambda: w.detach().transpose(0, 1).flip(2, 3).contiguous())
+            tape.add_grad(x, ops.conv3x3_fewin(dz, wd, relu_mask=x if fuse else None), masked=fuse)
+        else:
+            pkd = _CACHE.get(layer, ('dg', 0), _ver(w),
+                             lambda: ops.pack_conv3x3_dgrad(w.detach().contiguous()))
+            tape.add_grad(x, ops.conv3x3(dz, pkd[0], None, cout, cin, pkd[3], ksplit=1,
+                                         relu_mask=x if fuse else None), masked=fuse)
     tape.record(bwd)
     return y
 

@@ -227,6 +227,34 @@ def convt3x3s2(x, wpk, bias, cout, act=ACT_NONE, out=None):
     return out
 
 
+def conv3x3_fewin_ok(x, cout, any_size=False):
+    """whether tg_conv3x3_fewin_fwd takes the launch -- and pays: below one 4 x 64 tile per CU the MFMA
+    kernel is faster (2 x 128 x 128: 8.7 against 11.2 us; 2 x 256 x 256: 27.9 against 18.8 us)"""
+    n, cin, h, w = x.shape
+    ok = cin <= 4 and w % 4 == 0 and x.data_ptr() % 16 == 0 and (cin * h * w) % 4 == 0 and (cout * h * w) % 4 == 0
+    return ok and (any_size or n * ((h + 3) // 4) * ((w + 63) // 64) >= 256)
+
+
+def conv3x3_fewin(x, w_oihw, relu_mask=None, out=None):
+    """tg_conv3x3_fewin_fwd: 3x3 conv from <= 4 input channels (w_oihw: (cout, cin, 3, 3)), no bias /
+    activation, y = relu_mask > 0 ? conv : 0 -- the data gradient of a small-cout head."""
+    _chk(x, 'x'); _chk(w_oihw, 'weight')
+    n, cin, h, w = x.shape
+    cout = w_oihw.shape[0]
+    if tuple(w_oihw.shape) != (cout, cin, 3, 3):
+        raise L.TecoganHipError(f'conv3x3_fewin: weight {tuple(w_oihw.shape)} for {cin} input channels')
+    if out is None:
+        out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    if relu_mask is not None:
+        _chk(relu_mask, 'relu_mask')
+        if relu_mask.shape != out.shape:
+            raise L.TecoganHipError('conv3x3_fewin: relu_mask shape mismatch')
+    L.check(L.lib().tg_conv3x3_fewin_fwd(x.data_ptr(), cin * h * w, w_oihw.data_ptr(), _ptr(relu_mask), cout * h * w,
+                                         out.data_ptr(), cout * h * w, n, cin, cout, h, w, _stream()),
+            'tg_conv3x3_fewin_fwd')
+    return out
+
+
 def conv3x3_small_res_ok(x, res):
     """whether tg_conv3x3_small_fwd_res takes this launch (w % 4 == 0, aligned planes)"""
     return x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and res.data_ptr() % 16 == 0 and \

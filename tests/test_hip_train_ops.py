@@ -701,3 +701,20 @@ def test_div_scalar_is_ieee_division(ops):
     z = torch.empty_like(x)
     ops.div_scalar_(z, 7.0, x)
     assert torch.equal(z.cpu(), x.cpu() / 7.0)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,mask', [(2, 64, 3, 24, 64, True), (2, 64, 3, 128, 128, True), (3, 32, 2, 9, 12, False),
+                                                 (1, 70, 4, 5, 136, True), (2, 16, 1, 7, 8, False)])
+def test_data_gradient_of_a_small_cout_head(ops, n, cin, cout, h, w, mask):
+    """tg_conv3x3_fewin_fwd: dX of a cout <= 4 conv (conv_out, the flow head) from its <= 4-channel dZ, with the
+    ReLU mask of the layer below, against autograd."""
+    z = rs(1, (n, cin, h, w), -1, 1)
+    x = (torch.relu(z) if mask else z).requires_grad_(True)
+    wt = rs(2, (cout, cin, 3, 3)) / (3.0 * cin ** 0.5)
+    dy = rs(3, (n, cout, h, w))
+    F.conv2d(x, wt, None, padding=1).backward(dy)
+    want = x.grad * (x.detach() > 0) if mask else x.grad
+    assert ops.conv3x3_fewin_ok(dev(dy), cin, any_size=True)
+    wd = dev(wt).transpose(0, 1).flip(2, 3).contiguous()
+    got = ops.conv3x3_fewin(dev(dy), wd, relu_mask=dev(x.detach()) if mask else None)
+    assert relerr(got, want) <= 1e-5, relerr(got, want)
