@@ -563,7 +563,26 @@ __global__ __launch_bounds__(256) void linear1_fwd_kernel(const float* __restric
   __shared__ float sm[4];
   const float* xr = x + (long long)blockIdx.x * k;
   float s = 0.f;
-  for (int i = threadIdx.x; i < k; i += 256) s += xr[i] * w[i];
+  // (the critic's last layer: 12 rows of 65536 at crop 256 -- one element per thread and iteration was a
+  //  chain of 256 dependent round trips, 92 us; 16-byte loads, eight in flight)
+  if ((k & 3) == 0 && ((reinterpret_cast<uintptr_t>(xr) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(xr);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(w);
+    const int k4 = k >> 2;
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < k4; i += 8 * 256) {
+      f32x4 a[8], c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = x4[i + u * 256]; c[u] = w4[i + u * 256]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u & 3] += (a[u][0] * c[u][0] + a[u][1] * c[u][1]) + (a[u][2] * c[u][2] + a[u][3] * c[u][3]);
+    }
+    for (; i < k4; i += 256) { const f32x4 a = x4[i], c = w4[i]; p[0] += (a[0] * c[0] + a[1] * c[1]) + (a[2] * c[2] + a[3] * c[3]); }
+    s = (p[0] + p[1]) + (p[2] + p[3]);
+  } else {
+    for (int i = threadIdx.x; i < k; i += 256) s += xr[i] * w[i];
+  }
   float r = block_sum(s, sm);
   if (threadIdx.x == 0) y[blockIdx.x] = r + (b ? b[0] : 0.f);
 }

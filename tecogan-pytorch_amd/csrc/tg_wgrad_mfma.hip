@@ -439,7 +439,8 @@ struct WgradSmallArgs {
   long long p_ns, q_ns;
   int ca, cb, cb_total, cb_off, n, h, w, tiles_x, tiles_y, ntiles, nblk, nbb;
 };
-template <bool VEC>
+// CA = gradient rows actually computed (a.ca <= CA): conv_out's three rows cost three quarters of four
+template <bool VEC, int CA>
 __global__ __launch_bounds__(256) void wgrad3x3_smallca_kernel(WgradSmallArgs a) {
   __shared__ float sQ[64 * SC_QCS];                 // 52.5 KB
   __shared__ __attribute__((aligned(16))) float sP[4 * SC_TR * SC_TW];
@@ -447,9 +448,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_smallca_kernel(WgradSmallArgs a)
   const int bb = blockIdx.x % a.nbb, blk = blockIdx.x / a.nbb;
   const int b0 = bb * 64;
   const int hw = a.h * a.w;
-  float acc[4][9];
+  float acc[CA][9];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < CA; ++i)
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[i][t] = 0.f;
   // staging through registers: ALL loads of a tile are issued before the first LDS store, and the
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_smallca_kernel(WgradSmallArgs a)
 #pragma unroll
       for (int k = 0; k < 3; ++k) w2[k] = q[k * SC_QRS + x + 2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < CA; ++i) {
         const float p = sP[(i * SC_TR + g) * SC_TW + x];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_smallca_kernel(WgradSmallArgs a)
   float* red = sQ;                                    // [3][64][36]
   if (g > 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < CA; ++i)
 #pragma unroll
       for (int t = 0; t < 9; ++t) red[((g - 1) * 64 + bl) * 36 + i * 9 + t] = acc[i][t];
   }
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_smallca_kernel(WgradSmallArgs a)
   if (g == 0 && b0 + bl < a.cb) {
     float* out = a.part + (long long)blk * a.ca * a.cb_total * 9;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < CA; ++i) {
       if (i >= a.ca) break;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -716,8 +717,14 @@ static void launch_smallca(const WgradSmallArgs& sa, int nseg, hipStream_t s) {
   for (int i = 0; i < nseg && vec; ++i)
     if (((uintptr_t)sa.pseg[i] | (uintptr_t)sa.qseg[i]) & 15) vec = false;
   static const int novec = TG_LAB_ENV("TG_WGRAD_NOVEC", 0);
-  if (vec && !novec) hipLaunchKernelGGL(wgrad3x3_smallca_kernel<true>, dim3((unsigned)(sa.nblk * sa.nbb)), dim3(256), 0, s, sa);
-  else hipLaunchKernelGGL(wgrad3x3_smallca_kernel<false>, dim3((unsigned)(sa.nblk * sa.nbb)), dim3(256), 0, s, sa);
+  const dim3 g((unsigned)(sa.nblk * sa.nbb)), t(256);
+  const bool v = vec && !novec;
+  switch (sa.ca) {
+    case 1: if (v) hipLaunchKernelGGL((wgrad3x3_smallca_kernel<true, 1>), g, t, 0, s, sa); else hipLaunchKernelGGL((wgrad3x3_smallca_kernel<false, 1>), g, t, 0, s, sa); break;
+    case 2: if (v) hipLaunchKernelGGL((wgrad3x3_smallca_kernel<true, 2>), g, t, 0, s, sa); else hipLaunchKernelGGL((wgrad3x3_smallca_kernel<false, 2>), g, t, 0, s, sa); break;
+    case 3: if (v) hipLaunchKernelGGL((wgrad3x3_smallca_kernel<true, 3>), g, t, 0, s, sa); else hipLaunchKernelGGL((wgrad3x3_smallca_kernel<false, 3>), g, t, 0, s, sa); break;
+    default: if (v) hipLaunchKernelGGL((wgrad3x3_smallca_kernel<true, 4>), g, t, 0, s, sa); else hipLaunchKernelGGL((wgrad3x3_smallca_kernel<false, 4>), g, t, 0, s, sa); break;
+  }
 }
 // the vector staging needs whole 16-byte groups: widths that are multiples of 4 and aligned planes
 static bool wgrad_vec_ok(const WgradArgs& a, int nseg) {

@@ -718,3 +718,12 @@ def test_data_gradient_of_a_small_cout_head(ops, n, cin, cout, h, w, mask):
     wd = dev(wt).transpose(0, 1).flip(2, 3).contiguous()
     got = ops.conv3x3_fewin(dev(dy), wd, relu_mask=dev(x.detach()) if mask else None)
     assert relerr(got, want) <= 1e-5, relerr(got, want)
+
+
+@pytest.mark.parametrize('rows,k', [(12, 65536), (5, 16388), (3, 1001), (2, 9216)])
+def test_linear1_forward_long_rows(ops, rows, k):
+    """The critic's dense layer on long rows (16-byte loads, eight in flight; odd lengths element-wise)."""
+    x, w, b = rs(1, (rows, k)), rs(2, (1, k)) / k ** 0.5, rs(3, (1,))
+    ref = (x.double() @ w.double().t() + b.double()).float()
+    got = ops.linear1_fwd(dev(x), dev(w), dev(b))
+    assert relerr(got, ref) <= 2e-6, relerr(got, ref)
