@@ -474,6 +474,13 @@ int tg_backward_warp_bwd(const float* x, const float* flow, const float* dy, flo
 /* inverse of tg_space_to_depth: x (n, s*s*c, h, w) -> y (n, c, s*h, s*w) */
 int tg_depth_to_space(const float* x, float* y, int n, int c, int h, int w, int scale,
                       tg_stream_t stream);
+/* tg_depth_to_space whose result is the gradient of an activation OUTPUT act_y (same shape as y): the
+ * result is multiplied by act'(.) on the way out (relu | lrelu 0.2, through the output as tg_act_bwd) -- one pass
+ * instead of depth_to_space + act_bwd.  scale 2 | 4, w % 4 == 0, 16-byte aligned tensors
+ * (tg_depth_to_space_act_bwd_supported). */
+int tg_depth_to_space_act_bwd_supported(const float* x, const float* act_y, const float* y, int w, int scale);
+int tg_depth_to_space_act_bwd(const float* x, const float* act_y, int act, float* y, int n, int c, int h,
+                              int w, int scale, tg_stream_t stream);
 /* CharbonnierLoss (optim/losses.py:31-50): *loss_accum += loss_scale * sum sqrt(d^2+eps),
  * dx = grad_scale * d / sqrt(d^2+eps)  (d = x - y); loss_accum or dx may be NULL. */
 int tg_charbonnier(const float* x, const float* y, int64_t n, float eps, float loss_scale,

@@ -99,6 +99,8 @@ SIGNATURES = {
     'tg_upsample_bwd': (I, [P, P, I, I, I, I, I, F, P]),
     'tg_backward_warp_bwd': (I, [P, P, P, P, P, I, I, I, I, P]),
     'tg_depth_to_space': (I, [P, P, I, I, I, I, I, P]),
+    'tg_depth_to_space_act_bwd_supported': (I, [P, P, P, I, I]),
+    'tg_depth_to_space_act_bwd': (I, [P, P, I, P, I, I, I, I, I, P]),
     'tg_charbonnier': (I, [P, P, I64, F, F, P, F, P, P]),
     'tg_channel_norm': (I, [P, P, P, P, I, I, I64, P]),
     'tg_cosine_loss': (I, [P, P, I, I, I64, F, F, P, F, P, P]),

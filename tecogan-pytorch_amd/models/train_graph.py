@@ -32,17 +32,33 @@ class Tape:
         # act_bwd pass unless some other contribution arrived unmasked.
         self.relu_outputs = set()
         self.unmasked = set()
+        # the same idea for the generic conv node's activations (ReLU or LeakyReLU): a conv3x3 node
+        # registers its activation output here; a producer of its gradient that can apply act'(.) itself
+        # (the depth-to-space of a strided conv's data gradient) delivers it with act_applied=True and the
+        # node skips act_bwd.  LeakyReLU' is not idempotent: add_grad brings any other contribution to the
+        # same tensor to the same form before it accumulates.
+        self.act_outputs = {}
+        self.act_applied = set()
         self.side = None        # side stream of the asynchronous weight-gradient flushes
         self._inflight = []     # tensors the side stream still reads (kept alive until the join)
 
     # -- gradient bookkeeping -------------------------------------------------
-    def add_grad(self, t, g, masked=False):
+    def add_grad(self, t, g, masked=False, act_applied=False):
         """Accumulate g into the gradient of t.  Takes ownership of g.  masked: g already carries
-        the ReLU-backward mask of t (t is in relu_outputs)."""
+        the ReLU-backward mask of t (t is in relu_outputs).  act_applied: g already is the gradient of
+        the pre-activation of t (t is in act_outputs)."""
         k = id(t)
         if not masked:
             self.unmasked.add(k)
         cur = self.grads.get(k)
+        if act_applied or k in self.act_applied:
+            # LeakyReLU' is not idempotent: every contribution must carry it exactly once
+            a = self.act_outputs[k]
+            if k in self.act_applied and not act_applied:
+                g = ops.act_bwd(g, t, a, out=g)
+            elif k not in self.act_applied and cur is not None:
+                ops.act_bwd(cur, t, a, out=cur)
+            self.act_applied.add(k)
         if cur is None:
             self.grads[k] = g
             self.keep.append(t)
@@ -229,6 +245,8 @@ def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=
     if tape is None:
         return y
     c1 = x.shape[1]
+    if act in (RELU, LRELU) and res is None:
+        tape.act_outputs[id(y)] = act
 
     def bwd():
         g = tape.pop_grad(y)
@@ -236,7 +254,10 @@ def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=
             return
         if res is not None:
             tape.add_grad(res, g.clone())
-        dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
+        if id(y) in tape.act_applied:            # the producer of g applied act'(.) already
+            dz = g
+        else:
+            dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
         if w.requires_grad:
             gw = _grad_buf(w)
             tape.defer_wgrad(('w', id(layer), 0), dz, x, gw, 0)
@@ -605,7 +626,14 @@ def conv4x4s2(tape, holder, x, need_dx=True):
                 ds = ops.conv3x3_phased(g, pkd[0], co, 4 * ci, pkd[3], 2, ci, ops.TAPS_01, ops.TAPS_12)
             else:
                 ds = ops.conv3x3(g, pkd[0], None, co, 4 * ci, pkd[3], ksplit=1)
-            tape.add_grad(x, ops.depth_to_space(ds, 2))
+            a = tape.act_outputs.get(id(x))
+            if a is not None and tape.grad(x) is None:
+                # x = act(conv(.)): the depth-to-space pass applies act'(x) on the way out (one pass over
+                # the HR tensor instead of three)
+                gx, fused = ops.depth_to_space(ds, 2, act_y=x, act=a)
+                tape.add_grad(x, gx, act_applied=fused)
+            else:
+                tape.add_grad(x, ops.depth_to_space(ds, 2))
     tape.record(bwd)
     return y
 

@@ -612,11 +612,23 @@ def backward_warp_bwd(x, flow, dy, need_img=True, need_flow=True, dflow_out=None
     return dimg, dflow
 
 
-def depth_to_space(x, scale):
+def depth_to_space(x, scale, act_y=None, act=ACT_NONE):
+    """act_y / act: the result is the gradient of the activation output act_y and leaves multiplied by
+    act'(.) (tg_depth_to_space_act_bwd); returns (y, fused) then."""
     _chk(x, 'x')
     n, cs, h, w = x.shape
     c = cs // (scale * scale)
     y = torch.empty(n, c, h * scale, w * scale, dtype=torch.float32, device=x.device)
+    if act_y is not None:
+        _chk(act_y, 'act_y')
+        lib = L.lib()
+        if act in (ACT_RELU, ACT_LRELU02) and act_y.shape == y.shape and \
+                lib.tg_depth_to_space_act_bwd_supported(x.data_ptr(), act_y.data_ptr(), y.data_ptr(), w, scale):
+            L.check(lib.tg_depth_to_space_act_bwd(x.data_ptr(), act_y.data_ptr(), act, y.data_ptr(), n, c, h, w,
+                                                  scale, _stream()), 'tg_depth_to_space_act_bwd')
+            return y, True
+        L.check(lib.tg_depth_to_space(x.data_ptr(), y.data_ptr(), n, c, h, w, scale, _stream()), 'tg_depth_to_space')
+        return y, False
     L.check(L.lib().tg_depth_to_space(x.data_ptr(), y.data_ptr(), n, c, h, w, scale, _stream()),
             'tg_depth_to_space')
     return y

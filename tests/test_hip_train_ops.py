@@ -727,3 +727,50 @@ def test_linear1_forward_long_rows(ops, rows, k):
     ref = (x.double() @ w.double().t() + b.double()).float()
     got = ops.linear1_fwd(dev(x), dev(w), dev(b))
     assert relerr(got, ref) <= 2e-6, relerr(got, ref)
+
+
+@pytest.mark.parametrize('act', [1, 2])
+def test_depth_to_space_with_the_activation_derivative(ops, act):
+    """tg_depth_to_space_act_bwd = depth_to_space followed by act_bwd; and the tape path: a strided conv on
+    an activation output delivers the gradient with act'(.) applied, a second consumer is brought to the same form."""
+    from tecogan_pytorch_amd.models import train_graph as TG
+    ds = dev(rs(1, (3, 4 * 8, 6, 12)))
+    y = dev(rs(2, (3, 8, 12, 24), -1, 1))
+    got, fused = ops.depth_to_space(ds, 2, act_y=y, act=act)
+    assert fused
+    want = ops.act_bwd(ops.depth_to_space(ds, 2), y, act)
+    assert torch.equal(got, want)
+
+    class Holder(torch.nn.Module):
+        def __init__(self, w):
+            super().__init__()
+            self.weight = torch.nn.Parameter(w)
+            self.bias = torch.nn.Parameter(torch.zeros(w.shape[0], device=w.device))
+            self.cin, self.cout = w.shape[1], w.shape[0]
+
+        def packed(self):
+            pk, _, _, ocb = ops.pack_conv3x3(self.weight)
+            return pk, ocb
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 16, 24, generator=g)
+    w3 = torch.randn(64, 16, 3, 3, generator=g) * 0.1
+    w4 = torch.randn(64, 64, 4, 4, generator=g) * 0.05
+    w3b = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    xr = x.clone().requires_grad_(True)
+    fa = (lambda t: torch.relu(t)) if act == 1 else (lambda t: F.leaky_relu(t, 0.2))
+    yr = fa(F.conv2d(xr, w3, None, padding=1))
+    out_r = F.conv2d(yr, w4, None, stride=2, padding=1).sum() * 0.5 + (F.conv2d(yr, w3b, None, padding=1) ** 2).sum() * 0.01
+    out_r.backward()
+    tape = TG.Tape()
+    c3, c4, c3b = Holder(w3.cuda()), Holder(w4.cuda()), Holder(w3b.cuda())
+    for m in (c3, c4, c3b):
+        m.weight.requires_grad_(False); m.bias.requires_grad_(False)
+    xd = x.cuda()
+    yd = TG.conv3x3(tape, c3, xd, act=act)
+    z3 = TG.conv3x3(tape, c3b, yd)
+    z4 = TG.conv4x4s2(tape, c4, yd)          # recorded last: its backward runs first
+    tape.add_grad(z4, torch.full_like(z4, 0.5))
+    tape.add_grad(z3, 0.02 * z3)
+    tape.backward()
+    assert id(yd) in tape.act_applied                    # (the strided conv's gradient arrived first, fused)
+    assert relerr(tape.grad(xd), xr.grad) <= 2e-5, relerr(tape.grad(xd), xr.grad)
