@@ -446,12 +446,14 @@ int tg_wgrad3x3_multi_phased(const float* const* p_list, const float* const* q_l
  *   grad[a][b][ky][kx] (+)= sum x[n][a][y][x] * dz[n][b][2y - 1 + ky][2x - 1 + kx]
  * x_list[i]: (n_per_seg, ci, h, w) inputs of the layer, dz_list[i]: (n_per_seg, co, 2h, 2w); grad in the
  * layer's own (ci, co, 3, 3) layout.  No space-to-depth copy of dZ, all nine taps in one balanced pass
- * (the phased form above spends 1 / 2 / 2 / 4 taps on its four channel blocks).  Workspace:
+ * (the phased form above spends 1 / 2 / 2 / 4 taps on its four channel blocks).  bias_grad (co floats, may be
+ * NULL): the layer's bias gradient (+)= sum of dZ over images and pixels, taken from the dZ values the kernel
+ * stages anyway (no second pass over the HR tensors: 637 MB per step at crop 256).  Workspace:
  * tg_wgrad3x3_convt_workspace_floats(total images, ci, co, h, w). */
 size_t tg_wgrad3x3_convt_workspace_floats(int n, int ci, int co, int h, int w);
 int tg_wgrad3x3_convt_multi(const float* const* x_list, const float* const* dz_list, int nseg, float* grad,
-                            float* workspace, int n_per_seg, int ci, int co, int h, int w, int accumulate,
-                            tg_stream_t stream);
+                            float* bias_grad, float* workspace, int n_per_seg, int ci, int co, int h, int w,
+                            int accumulate, tg_stream_t stream);
 int tg_bias_grad_multi(const float* const* dy_list, int nseg, float* db, int n_per_seg, int c,
                        int hw, int accumulate, tg_stream_t stream);
 /* dx = dy * act'(.), expressed through the activation OUTPUT y (ReLU, LeakyReLU(0.2),

@@ -91,7 +91,7 @@ SIGNATURES = {
     'tg_conv3x3_phased_pick_ksplit': (I, [I, I, I, I, I, I]),
     'tg_conv3x3_fwd_phased_splitk': (I, [P, I64, P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P]),
     'tg_wgrad3x3_convt_workspace_floats': (SZ, [I, I, I, I, I]),
-    'tg_wgrad3x3_convt_multi': (I, [P, P, I, P, P, I, I, I, I, I, I, P]),
+    'tg_wgrad3x3_convt_multi': (I, [P, P, I, P, P, P, I, I, I, I, I, I, P]),
     'tg_bias_grad_multi': (I, [P, I, P, I, I, I, I, P]),
     'tg_act_bwd': (I, [P, P, P, I64, I, P]),
     'tg_bias_grad': (I, [P, P, I, I, I, I, P]),

@@ -65,6 +65,10 @@ struct WgradArgs {
   // wave pairs that would multiply zero padding take alternate groups of 8 pixels instead and write
   // their sums as extra splits: partial index = split * KS + kid, KS = 2 or 4.
   int kmode;
+  // stride-2 form (dW of a transposed conv) with the vector staging: the sums of dZ over the pixels -- the
+  // layer's bias gradient -- are taken from the staged Q values on their way to LDS (every HR pixel belongs
+  // to exactly one tile's "own" rows / columns): bias_part[split][cb], added by bias_part_reduce_kernel.
+  float* bias_part;
 };
 
 enum { WTAPS_ALL = 0, WTAPS_01 = 1, WTAPS_12 = 2, WTAPS_1 = 3 };
@@ -234,9 +238,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     }
     }
   };
+  constexpr bool BIAS = VEC && G::S2 != 0;
+  float bsum[BIAS ? BV_PER_T : 1];
+#pragma unroll
+  for (int i = 0; i < (BIAS ? BV_PER_T : 1); ++i) bsum[i] = 0.f;
+  // rows 1, 2 of the 3-row patch and pairs 1..32 of a row are this tile's own HR pixels
+  const bool own = BIAS && a.bias_part && ab == 0 && vb_on && vb_r >= 1 && vb_k >= 1 && vb_k <= 32;
   auto store_tile = [&](int buf) {
     float* pa = sA + buf * G::A_FLOATS;
     float* pb = sB + buf * G::B_FLOATS;
+    if constexpr (BIAS) {
+      if (own) {
+#pragma unroll
+        for (int i = 0; i < BV_PER_T; ++i) bsum[i] += rb[2 * i] + rb[2 * i + 1];
+      }
+    }
     if constexpr (VEC) {
       float* qa = pa + va_c * G::CSA + va_r * G::TW + 4 * va_k;               // 16-byte aligned (CSA % 4 == 0)
 #pragma unroll
@@ -343,6 +359,42 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       }
     }
   }
+  if constexpr (BIAS) {
+    if (a.bias_part && ab == 0) {          // (block-uniform; the loop's last barrier has passed: LDS is free)
+      float* sb = smem;                    // [256 threads][33]
+#pragma unroll
+      for (int i = 0; i < BV_PER_T; ++i) sb[tid * 33 + i] = bsum[i];
+      __syncthreads();
+      if (tid < 64) {
+        const int grp = tid >> 5, i = tid & 31;
+        float v = 0.f;
+        for (int j = 0; j < 128; ++j) v += sb[(grp * 128 + j) * 33 + i];      // fixed order
+        if (b0 + tid < a.cb) a.bias_part[(long long)split * a.cb + b0 + tid] = v;
+      }
+    }
+  }
+}
+
+// (four waves take interleaved quarters of the splits, four independent chains each: a single chain over
+//  256 splits was 128 dependent round trips -- 65-165 us, more than the fused pass had saved)
+__global__ __launch_bounds__(256) void bias_part_reduce_kernel(const float* __restrict__ part, float* __restrict__ db,
+                                                               int nsplit, int cb, int accumulate) {
+  __shared__ float sm[4][64];
+  const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + o;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cb) {
+    const float* p = part + c;
+    int k = sg;
+    for (; k + 12 < nsplit; k += 16) {
+      s0 += p[(long long)k * cb]; s1 += p[(long long)(k + 4) * cb];
+      s2 += p[(long long)(k + 8) * cb]; s3 += p[(long long)(k + 12) * cb];
+    }
+    for (; k < nsplit; k += 4) s0 += p[(long long)k * cb];
+  }
+  sm[sg][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sg == 0 && c < cb) db[c] = (accumulate ? db[c] : 0.f) + ((sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]));
 }
 
 // the un-phased, un-layered launches in the other geometries
@@ -671,7 +723,8 @@ extern "C" size_t tg_wgrad3x3_workspace_floats(int n, int ca, int cb_total, int 
 
 extern "C" size_t tg_wgrad3x3_convt_workspace_floats(int n, int ci, int co, int h, int w) {
   if (n <= 0 || ci <= 0 || co <= 0 || h <= 0 || w <= 0) return 0;
-  return (size_t)wgrad_nsplit(n, h, w, ci, co, 3) * ci * co * 9;
+  const size_t ns = (size_t)wgrad_nsplit(n, h, w, ci, co, 3);
+  return ns * ci * co * 9 + ns * co;                 // + the bias-gradient partials
 }
 
 template <class G, bool VEC>
@@ -738,7 +791,7 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
                         int64_t p_nstride, int64_t q_nstride, float* grad, float* workspace,
                         int n_per_seg, int ca, int cb, int cb_total, int cb_off, int h, int w,
                         int accumulate, tg_stream_t stream, int cphase = 0, int set_p0 = 0,
-                        int set_p1 = 0, int stride2 = 0) {
+                        int set_p1 = 0, int stride2 = 0, float* bias_grad = nullptr) {
   TG_REQUIRE(p_list && q_list && grad && workspace, TG_E_ARG, "wgrad3x3: null pointer");
   TG_REQUIRE(nseg >= 1 && nseg <= WG_MAXSEG, TG_E_ARG, "wgrad3x3: %d segments (1..%d)", nseg, WG_MAXSEG);
   TG_REQUIRE(n_per_seg > 0 && ca > 0 && cb > 0 && h > 0 && w > 0 && cb_off >= 0 &&
@@ -828,7 +881,21 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
   } else if (geo == 2) {
     launch_geo<WgGeo<8, 8, 0>>(a, blocks, s, vec);
   } else {
+    // bias gradient of the transposed conv: out of the staged dZ when the vector form runs (and cb fits one block)
+    const bool fuse_b = bias_grad && vec && a.nbb == 1;
+    a.bias_part = fuse_b ? workspace + (size_t)a.nsplit * ca * cb_total * 9 : nullptr;
     launch_geo<WgGeo<1, 32, 1>>(a, blocks, s, vec);
+    if (bias_grad) {
+      int rb_ = check_launch("wgrad3x3_convt");
+      if (rb_ != TG_OK) return rb_;
+      if (fuse_b) {
+        hipLaunchKernelGGL(bias_part_reduce_kernel, dim3((unsigned)cdiv(cb, 64)), dim3(256), 0, s, a.bias_part, bias_grad,
+                           a.nsplit, cb, accumulate);
+      } else {      // element-wise staging / several channel blocks: the stand-alone reduction over the HR tensors
+        rb_ = tg_bias_grad_multi(q_list, nseg, bias_grad, n_per_seg, cb, 4 * h * w, accumulate, stream);
+        if (rb_ != TG_OK) return rb_;
+      }
+    }
   }
   int rc = check_launch("wgrad3x3_mfma");
   if (rc != TG_OK) return rc;
@@ -916,10 +983,10 @@ extern "C" int tg_wgrad3x3_multi_phased(const float* const* p_list, const float*
 // inputs, dz_list[i] (n_per_seg, co, 2h, 2w) = the gradients of its pre-activation; grad (ci, co, 3, 3)
 // in the layer's own weight layout.  No space-to-depth copy of dZ, the nine taps in one balanced pass.
 extern "C" int tg_wgrad3x3_convt_multi(const float* const* x_list, const float* const* dz_list, int nseg,
-                                       float* grad, float* workspace, int n_per_seg, int ci, int co, int h, int w,
-                                       int accumulate, tg_stream_t stream) {
+                                       float* grad, float* bias_grad, float* workspace, int n_per_seg, int ci, int co,
+                                       int h, int w, int accumulate, tg_stream_t stream) {
   return wgrad_launch(x_list, dz_list, nseg, (int64_t)ci * h * w, (int64_t)co * 4 * h * w, grad, workspace, n_per_seg,
-                      ci, co, co, 0, h, w, accumulate, stream, 0, 0, 0, 1);
+                      ci, co, co, 0, h, w, accumulate, stream, 0, 0, 0, 1, bias_grad);
 }
 
 extern "C" int tg_wgrad3x3_multi(const float* const* p_list, const float* const* q_list, int nseg,

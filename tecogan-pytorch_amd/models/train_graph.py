@@ -138,11 +138,13 @@ class Tape:
         for ent in self.deferred.values():
             multi = len(ent['p']) > 1 and same(ent['p']) and same(ent['q'])
             if ent.get('convt'):       # (x, dZ at twice the resolution) pairs of a transposed conv
+                # (`post` carries the layer's bias-gradient buffer: the same launch sums dZ)
                 if same(ent['p']) and same(ent['q']):
-                    ops.wgrad3x3_convt_multi(ent['p'], ent['q'], ent['target'], accumulate=True)
+                    ops.wgrad3x3_convt_multi(ent['p'], ent['q'], ent['target'], accumulate=True, bias_grad=ent['post'])
                 else:
                     for x_, d_ in zip(ent['p'], ent['q']):
-                        ops.wgrad3x3_convt_multi([x_.contiguous()], [d_.contiguous()], ent['target'], accumulate=True)
+                        ops.wgrad3x3_convt_multi([x_.contiguous()], [d_.contiguous()], ent['target'], accumulate=True,
+                                                 bias_grad=ent['post'])
             elif ent['post'] is None:
                 if multi:      # one launch over the per-frame tensors where they lie
                     ops.wgrad3x3_multi(ent['p'], ent['q'], ent['target'], cb_off=ent['cb_off'],
@@ -567,7 +569,7 @@ def convt3x3s2(tape, layer, x, act=RELU):
         if w.requires_grad:
             if direct:
                 # dW straight from dZ (tg_wgrad3x3_convt_multi): no s2d copy, no embedded gradient to gather back
-                tape.defer_wgrad(('ctw', id(layer)), x, dz, _grad_buf(w), convt=True)
+                tape.defer_wgrad(('ctw', id(layer)), x, dz, _grad_buf(w), convt=True, post=_grad_buf(b))
             else:
                 if s is None:
                     s = ops.space_to_depth(dz, 2)
@@ -576,7 +578,7 @@ def convt3x3s2(tape, layer, x, act=RELU):
                     _, inv = _embed_index('convt', ci, co, ge.device)
                     ops.index_gather(ge, inv, out=_grad_buf(w), accumulate=True)
                 tape.defer_wgrad(('ct', id(layer)), x, s, None, 0, post, phased=(co, ops.TAPS_1, ops.TAPS_01))
-            tape.defer_bias(_grad_buf(b), dz)
+                tape.defer_bias(_grad_buf(b), dz)
     tape.record(bwd)
     return y
 

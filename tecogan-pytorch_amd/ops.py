@@ -480,9 +480,10 @@ def wgrad3x3_multi(p_list, q_list, grad, cb_off=0, accumulate=True, phased=None)
     return grad
 
 
-def wgrad3x3_convt_multi(x_list, dz_list, grad, accumulate=True):
+def wgrad3x3_convt_multi(x_list, dz_list, grad, accumulate=True, bias_grad=None):
     """tg_wgrad3x3_convt_multi: grad (ci, co, 3, 3) (+)= dW of ConvTranspose2d(ci, co, 3, 2, 1, 1) over the
-    (input x_i (n, ci, h, w), output gradient dz_i (n, co, 2h, 2w)) pairs, straight from dZ."""
+    (input x_i (n, ci, h, w), output gradient dz_i (n, co, 2h, 2w)) pairs, straight from dZ; bias_grad (co,)
+    (+)= the sum of dZ (same launch)."""
     if len(x_list) != len(dz_list) or not x_list:
         raise L.TecoganHipError('wgrad3x3_convt_multi: empty or mismatched lists')
     for t in list(x_list) + list(dz_list):
@@ -498,9 +499,9 @@ def wgrad3x3_convt_multi(x_list, dz_list, grad, accumulate=True):
     for i in range(0, len(x_list), MAX_SEGS):
         xs, ds = x_list[i:i + MAX_SEGS], dz_list[i:i + MAX_SEGS]
         ws = _wgrad_workspace(grad.device, lib.tg_wgrad3x3_convt_workspace_floats(n * len(xs), ci, co, h, w))
-        L.check(lib.tg_wgrad3x3_convt_multi(_ptr_array(xs), _ptr_array(ds), len(xs), grad.data_ptr(), ws.data_ptr(),
-                                            n, ci, co, h, w, 1 if (accumulate or i > 0) else 0, _stream()),
-                'tg_wgrad3x3_convt_multi')
+        L.check(lib.tg_wgrad3x3_convt_multi(_ptr_array(xs), _ptr_array(ds), len(xs), grad.data_ptr(), _ptr(bias_grad),
+                                            ws.data_ptr(), n, ci, co, h, w, 1 if (accumulate or i > 0) else 0,
+                                            _stream()), 'tg_wgrad3x3_convt_multi')
     return grad
 
 

@@ -69,12 +69,15 @@ def test_convt_weight_gradient_straight_from_dz(ops, nseg, n, ci, co, h, w):
     xs = [rs(10 + i, (n, ci, h, w)) for i in range(nseg)]
     dzs = [rs(40 + i, (n, co, 2 * h, 2 * w)) for i in range(nseg)]
     wt = (rs(2, (ci, co, 3, 3)) / (3.0 * ci ** 0.5)).requires_grad_(True)
-    F.conv_transpose2d(torch.cat(xs), wt, None, stride=2, padding=1, output_padding=1).backward(torch.cat(dzs))
+    bt = torch.zeros(co, requires_grad=True)
+    F.conv_transpose2d(torch.cat(xs), wt, bt, stride=2, padding=1, output_padding=1).backward(torch.cat(dzs))
     g = torch.zeros(ci, co, 3, 3, device='cuda')
-    ops.wgrad3x3_convt_multi([dev(t) for t in xs], [dev(t) for t in dzs], g, accumulate=False)
+    db = torch.full((co,), 7.0, device='cuda')
+    ops.wgrad3x3_convt_multi([dev(t) for t in xs], [dev(t) for t in dzs], g, accumulate=False, bias_grad=db)
     assert relerr(g, wt.grad) <= 2e-5, relerr(g, wt.grad)
-    ops.wgrad3x3_convt_multi([dev(t) for t in xs], [dev(t) for t in dzs], g, accumulate=True)
-    assert relerr(g, 2 * wt.grad) <= 2e-5
+    assert relerr(db, bt.grad) <= 1e-5, relerr(db, bt.grad)                     # (accumulate=False overwrites)
+    ops.wgrad3x3_convt_multi([dev(t) for t in xs], [dev(t) for t in dzs], g, accumulate=True, bias_grad=db)
+    assert relerr(g, 2 * wt.grad) <= 2e-5 and relerr(db, 2 * bt.grad) <= 1e-5
 
 
 @pytest.mark.parametrize('cout,c1,c2,h,w', [(64, 3, 48, 16, 24), (64, 16, 16, 12, 40), (32, 12, 20, 9, 36), (48, 2, 30, 7, 21)])
