@@ -264,6 +264,11 @@ int tg_srnet_body_bwd(const tg_packed_layer* dgrad, int pack_layout, int nb, con
 size_t tg_wgrad3x3_body_workspace_floats(int nframes, int n_per_frame, int nlayers, int c, int h, int w);
 int tg_wgrad3x3_body(const float* const* dz_bases, const float* const* act_bases, int nframes, int64_t layer_stride, int nlayers, float* const* grads, float* workspace,
                      int n_per_frame, int c, int h, int w, int accumulate, tg_stream_t stream);
+/* ... and their bias gradients in the same pass: dbs[L - 1] (c floats) (+)= sum of dZ of layer L = 1..nlayers. */
+int tg_wgrad3x3_body_bias(const float* const* dz_bases, const float* const* act_bases, int nframes,
+                          int64_t layer_stride, int nlayers, float* const* grads, float* const* dbs,
+                          float* workspace, int n_per_frame, int c, int h, int w, int accumulate,
+                          tg_stream_t stream);
 int tg_bias_grad_body(const float* const* dz_bases, int nframes,
                       int64_t layer_stride, int nlayers, float* const* dbs, int n_per_frame, int c, int hw,
                       tg_stream_t stream);
@@ -433,6 +438,13 @@ int tg_wgrad3x3_multi(const float* const* p_list, const float* const* q_list, in
                       int64_t p_nstride, int64_t q_nstride, float* grad, float* workspace,
                       int n_per_seg, int ca, int cb, int cb_total, int cb_off, int h, int w,
                       int accumulate, tg_stream_t stream);
+/* tg_wgrad3x3_multi that also delivers the layer's bias gradient: bias_grad (ca floats) (+)= sum of p over
+ * images and pixels, taken from the p values the kernel stages anyway (vector staging: w % 4 == 0, aligned
+ * planes; other forms run tg_bias_grad_multi themselves) -- no second pass over dZ. */
+int tg_wgrad3x3_multi_bias(const float* const* p_list, const float* const* q_list, int nseg,
+                           int64_t p_nstride, int64_t q_nstride, float* grad, float* bias_grad,
+                           float* workspace, int n_per_seg, int ca, int cb, int cb_total, int cb_off,
+                           int h, int w, int accumulate, tg_stream_t stream);
 /* tg_wgrad3x3_multi for a space-to-depth embedded strided conv (see tg_conv3x3_fwd_phased): the
  * q channels come in 4 sub-pixel phases of `cphase` (multiple of 64) channels and only the taps
  * the phase owns are computed; the other entries of grad are written as 0. */

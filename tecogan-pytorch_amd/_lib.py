@@ -87,6 +87,7 @@ SIGNATURES = {
     'tg_wgrad3x3_workspace_floats': (SZ, [I, I, I, I, I]),
     'tg_wgrad3x3': (I, [P, I64, P, I64, P, P, I, I, I, I, I, I, I, I, P]),
     'tg_wgrad3x3_multi': (I, [P, P, I, I64, I64, P, P, I, I, I, I, I, I, I, I, P]),
+    'tg_wgrad3x3_multi_bias': (I, [P, P, I, I64, I64, P, P, P, I, I, I, I, I, I, I, I, P]),
     'tg_wgrad3x3_multi_phased': (I, [P, P, I, I64, I64, P, P, I, I, I, I, I, I, I, I, I, P]),
     'tg_conv3x3_phased_pick_ksplit': (I, [I, I, I, I, I, I]),
     'tg_conv3x3_fwd_phased_splitk': (I, [P, I64, P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P]),
@@ -133,6 +134,7 @@ SIGNATURES = {
     'tg_srnet_body_bwd': (I, [C.POINTER(PackedLayer), I, I, P, P, P, I, I, I, I, I, P, P, C.c_uint32, I, P]),
     'tg_wgrad3x3_body_workspace_floats': (SZ, [I, I, I, I, I, I]),
     'tg_wgrad3x3_body': (I, [P, P, I, I64, I, P, P, I, I, I, I, I, P]),
+    'tg_wgrad3x3_body_bias': (I, [P, P, I, I64, I, P, P, P, I, I, I, I, I, P]),
     'tg_bias_grad_body': (I, [P, I, I64, I, P, I, I, I, P]),
     'tg_conv3x3_prefers_wino': (I, [I, I, I, I, I]),
     'tg_pack_conv3x3_wino': (I, [P, P, I, I, I, P]),

@@ -238,12 +238,19 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     }
     }
   };
+  // Bias gradients out of the staged values (vector form; a.bias_part != null):
+  //   stride-2 form (dW of a transposed conv, db = sum of Q = dZ): rows 1, 2 of the 3-row patch and pairs
+  //     1..32 of a row are this tile's own HR pixels;
+  //   every other form (db = sum of P = dZ): the P tile has no halo, every staged value counts once
+  //     (the workgroups of b-channel block 0 do it).
   constexpr bool BIAS = VEC && G::S2 != 0;
-  float bsum[BIAS ? BV_PER_T : 1];
+  constexpr bool BIAS_A = VEC && G::S2 == 0;
+  constexpr int NBS = BIAS ? BV_PER_T : (BIAS_A ? AV_PER_T : 1);
+  float bsum[NBS];
 #pragma unroll
-  for (int i = 0; i < (BIAS ? BV_PER_T : 1); ++i) bsum[i] = 0.f;
-  // rows 1, 2 of the 3-row patch and pairs 1..32 of a row are this tile's own HR pixels
+  for (int i = 0; i < NBS; ++i) bsum[i] = 0.f;
   const bool own = BIAS && a.bias_part && ab == 0 && vb_on && vb_r >= 1 && vb_k >= 1 && vb_k <= 32;
+  const bool own_a = BIAS_A && a.bias_part && bb == 0;
   auto store_tile = [&](int buf) {
     float* pa = sA + buf * G::A_FLOATS;
     float* pb = sB + buf * G::B_FLOATS;
@@ -251,6 +258,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       if (own) {
 #pragma unroll
         for (int i = 0; i < BV_PER_T; ++i) bsum[i] += rb[2 * i] + rb[2 * i + 1];
+      }
+    }
+    if constexpr (BIAS_A) {
+      if (own_a) {
+#pragma unroll
+        for (int i = 0; i < AV_PER_T; ++i) bsum[i] += (ra[4 * i] + ra[4 * i + 1]) + (ra[4 * i + 2] + ra[4 * i + 3]);
       }
     }
     if constexpr (VEC) {
@@ -373,6 +386,22 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       }
     }
   }
+  if constexpr (BIAS_A) {
+    if (own_a) {                           // (block-uniform)
+      float* sb = smem;                    // [256 threads][AV_PER_T + 1]
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < AV_PER_T; ++i) sb[tid * (AV_PER_T + 1) + i] = bsum[i];
+      __syncthreads();
+      if (tid < 64) {                      // channel tid = vc + A_CSTEP * i was staged by the PIX / 4 threads of vc
+        const int vc = tid % A_CSTEP, i = tid / A_CSTEP;
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < G::PIX / 4; ++j) v += sb[(vc * (G::PIX / 4) + j) * (AV_PER_T + 1) + i];     // fixed order
+        if (a0 + tid < a.ca) a.bias_part[((long long)li * a.nsplit + split) * a.ca + a0 + tid] = v;
+      }
+    }
+  }
 }
 
 // (four waves take interleaved quarters of the splits, four independent chains each: a single chain over
@@ -394,6 +423,29 @@ __global__ __launch_bounds__(256) void bias_part_reduce_kernel(const float* __re
   }
   sm[sg][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
+  if (sg == 0 && c < cb) db[c] = (accumulate ? db[c] : 0.f) + ((sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]));
+}
+
+// the same for every layer of a layered launch: blockIdx.y = layer; part: [layer][split][c]
+struct WgradLayerBias { float* b[24]; };
+__global__ __launch_bounds__(256) void bias_part_reduce_layers_kernel(const float* __restrict__ part, WgradLayerBias bl,
+                                                                      int nsplit, int cb, int accumulate) {
+  __shared__ float sm[4][64];
+  const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + o;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cb) {
+    const float* p = part + (long long)blockIdx.y * nsplit * cb + c;
+    int k = sg;
+    for (; k + 12 < nsplit; k += 16) {
+      s0 += p[(long long)k * cb]; s1 += p[(long long)(k + 4) * cb];
+      s2 += p[(long long)(k + 8) * cb]; s3 += p[(long long)(k + 12) * cb];
+    }
+    for (; k < nsplit; k += 4) s0 += p[(long long)k * cb];
+  }
+  sm[sg][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  float* db = bl.b[blockIdx.y];
   if (sg == 0 && c < cb) db[c] = (accumulate ? db[c] : 0.f) + ((sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]));
 }
 
@@ -713,7 +765,7 @@ extern "C" size_t tg_wgrad3x3_workspace_floats(int n, int ca, int cb_total, int 
   // (the un-phased launch may fold the tile for a narrow map; phased launches use 2 x 32: the larger count)
   const int s0 = wgrad_nsplit(n, h, w, ca, cb_total), s1 = wgrad_nsplit(n, h, w, ca, cb_total, wgrad_geo(h, w));
   const int ks = (ca <= 32 ? 2 : 1) * (cb_total <= 64 ? 2 : 1);        // room for wgrad_kmode's extra partials
-  size_t need = (size_t)(s0 > s1 ? s0 : s1) * ks * ca * cb_total * 9;
+  size_t need = (size_t)(s0 > s1 ? s0 : s1) * ks * ca * cb_total * 9 + (size_t)256 * ca;      // + bias partials
   if (ca > 4) {        // a launch over <= 4 of the cb_total columns goes to the small-ca kernel, operands exchanged
     const size_t sw = (size_t)wgrad_nsplit(n, h, w, 4, ca) * 4 * ca * 9;
     if (sw > need) need = sw;
@@ -820,7 +872,9 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
     const long long total = (long long)ca * cb * 9;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, grad,
                        sa.nblk, ca, cb, cb_total, cb_off, accumulate, 0);
-    return check_launch("wgrad_reduce");
+    rc = check_launch("wgrad_reduce");
+    if (rc != TG_OK || !bias_grad) return rc;
+    return tg_bias_grad_multi(p_list, nseg, bias_grad, n_per_seg, ca, h * w, accumulate, stream);
   }
   if (cb <= 4 && !cphase && !stride2) {
     // few SHIFTED channels: the small-ca kernel with the operands exchanged (wgrad_reduce_swapped_kernel)
@@ -842,7 +896,9 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
     const long long total = (long long)ca * cb * 9;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace,
                        grad, sa.nblk, ca, cb, cb_total, cb_off, accumulate, 1);
-    return check_launch("wgrad_reduce(swapped)");
+    rc = check_launch("wgrad_reduce(swapped)");
+    if (rc != TG_OK || !bias_grad) return rc;
+    return tg_bias_grad_multi(p_list, nseg, bias_grad, n_per_seg, ca, h * w, accumulate, stream);
   }
   WgradArgs a{};
   for (int i = 0; i < nseg; ++i) {
@@ -874,6 +930,9 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
   const bool vec = !novec && wgrad_vec_ok(a, nseg);
   if (geo == 0 && !cphase) a.kmode = wgrad_kmode(ca, cb, cb_total);
   const int ks = a.kmode == 3 ? 4 : (a.kmode ? 2 : 1);
+  // bias gradient (db = sum of P = dZ over images and pixels): out of the P values the vector form stages
+  const bool fuse_a = bias_grad && !stride2 && vec && !cphase;
+  if (fuse_a) a.bias_part = workspace + (size_t)a.nsplit * ks * ca * cb_total * 9;
   if (geo == 0) {
     launch_std(a, blocks, s, vec);
   } else if (geo == 1) {
@@ -902,7 +961,14 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
   long long total = (long long)ca * cb * 9;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace,
                      grad, a.nsplit * ks, ca, cb, cb_total, cb_off, accumulate, 0);
-  return check_launch("wgrad_reduce");
+  rc = check_launch("wgrad_reduce");
+  if (rc != TG_OK || !bias_grad || stride2) return rc;
+  if (fuse_a) {
+    hipLaunchKernelGGL(bias_part_reduce_kernel, dim3((unsigned)cdiv(ca, 64)), dim3(256), 0, s, a.bias_part, bias_grad,
+                       a.nsplit, ca, accumulate);
+    return check_launch("bias_part_reduce");
+  }
+  return tg_bias_grad_multi(p_list, nseg, bias_grad, n_per_seg, ca, h * w, accumulate, stream);
 }
 
 // K split of a layered launch: ~5 rounds of workgroups over the device, whole tiles per workgroup
@@ -918,13 +984,14 @@ static int body_nsplit(int nframes, int n_per_frame, int nlayers, int c, int h, 
 
 extern "C" size_t tg_wgrad3x3_body_workspace_floats(int nframes, int n_per_frame, int nlayers, int c, int h, int w) {
   if (nframes <= 0 || n_per_frame <= 0 || nlayers <= 0 || c <= 0 || h <= 0 || w <= 0) return 0;
-  return (size_t)nlayers * body_nsplit(nframes, n_per_frame, nlayers, c, h, w) * c * c * 9;
+  const size_t ns = (size_t)body_nsplit(nframes, n_per_frame, nlayers, c, h, w);
+  return (size_t)nlayers * ns * c * c * 9 + (size_t)nlayers * ns * c;          // + bias partials
 }
 
-extern "C" int tg_wgrad3x3_body(const float* const* dz_bases, const float* const* act_bases,
-                                int nframes, int64_t layer_stride, int nlayers,
-                                float* const* grads, float* workspace, int n_per_frame, int c, int h, int w,
-                                int accumulate, tg_stream_t stream) {
+static int wgrad_body_impl(const float* const* dz_bases, const float* const* act_bases,
+                           int nframes, int64_t layer_stride, int nlayers,
+                           float* const* grads, float* const* dbs, float* workspace, int n_per_frame, int c, int h, int w,
+                           int accumulate, tg_stream_t stream) {
   TG_REQUIRE(dz_bases && act_bases && grads && workspace, TG_E_ARG, "wgrad3x3_body: null pointer");
   TG_REQUIRE(nframes >= 1 && nframes <= WG_MAXSEG && nlayers >= 1 && nlayers <= 24, TG_E_ARG,
              "wgrad3x3_body: %d frames (1..%d), %d layers (1..24)", nframes, WG_MAXSEG, nlayers);
@@ -952,13 +1019,55 @@ extern "C" int tg_wgrad3x3_body(const float* const* dz_bases, const float* const
   a.nlayer = nlayers; a.lstride = layer_stride;
   hipStream_t s = (hipStream_t)stream;
   static const int novec = TG_LAB_ENV("TG_WGRAD_NOVEC", 0);
-  launch_std(a, (unsigned)(nlayers * a.nab * a.nbb * a.nsplit), s, !novec && wgrad_vec_ok(a, nframes));
+  const bool vec = !novec && wgrad_vec_ok(a, nframes);
+  WgradLayerBias bl{};
+  if (dbs) {
+    for (int i = 0; i < nlayers; ++i) {
+      TG_REQUIRE(dbs[i], TG_E_ARG, "wgrad3x3_body: null bias gradient %d", i);
+      bl.b[i] = dbs[i];
+    }
+    if (vec) a.bias_part = workspace + (size_t)nlayers * a.nsplit * c * c * 9;
+  }
+  launch_std(a, (unsigned)(nlayers * a.nab * a.nbb * a.nsplit), s, vec);
   int rc = check_launch("wgrad3x3_body");
   if (rc != TG_OK) return rc;
   const long long total = (long long)c * c * 9;
   hipLaunchKernelGGL(wgrad_reduce_layers_kernel, dim3((unsigned)((total + 63) / 64), (unsigned)nlayers), dim3(256), 0, s,
                      workspace, gl, a.nsplit, c, c, accumulate);
-  return check_launch("wgrad_reduce_layers");
+  rc = check_launch("wgrad_reduce_layers");
+  if (rc != TG_OK || !dbs) return rc;
+  if (a.bias_part) {
+    hipLaunchKernelGGL(bias_part_reduce_layers_kernel, dim3((unsigned)cdiv(c, 64), (unsigned)nlayers), dim3(256), 0, s,
+                       a.bias_part, bl, a.nsplit, c, accumulate);
+    return check_launch("bias_part_reduce_layers");
+  }
+  // element-wise staging: the stand-alone reduction, layer by layer (dZ of layer L = 1..nlayers at base + L * stride)
+  const float* segs[WG_MAXSEG];
+  for (int L = 1; L <= nlayers; ++L) {
+    for (int f = 0; f < nframes; ++f) segs[f] = dz_bases[f] + (size_t)L * layer_stride;
+    rc = tg_bias_grad_multi(segs, nframes, dbs[L - 1], n_per_frame, c, h * w, accumulate, stream);
+    if (rc != TG_OK) return rc;
+  }
+  return TG_OK;
+}
+
+extern "C" int tg_wgrad3x3_body(const float* const* dz_bases, const float* const* act_bases,
+                                int nframes, int64_t layer_stride, int nlayers,
+                                float* const* grads, float* workspace, int n_per_frame, int c, int h, int w,
+                                int accumulate, tg_stream_t stream) {
+  return wgrad_body_impl(dz_bases, act_bases, nframes, layer_stride, nlayers, grads, nullptr, workspace, n_per_frame, c,
+                         h, w, accumulate, stream);
+}
+
+// ... and the bias gradients of the same layers (dbs[L - 1] (+)= sum of dZ of layer L = 1..nlayers) from the dZ
+// values the launch stages anyway -- tg_bias_grad_body then only has the chain's first layer left to do.
+extern "C" int tg_wgrad3x3_body_bias(const float* const* dz_bases, const float* const* act_bases,
+                                     int nframes, int64_t layer_stride, int nlayers,
+                                     float* const* grads, float* const* dbs, float* workspace, int n_per_frame, int c,
+                                     int h, int w, int accumulate, tg_stream_t stream) {
+  TG_REQUIRE(dbs, TG_E_ARG, "wgrad3x3_body_bias: null pointer");
+  return wgrad_body_impl(dz_bases, act_bases, nframes, layer_stride, nlayers, grads, dbs, workspace, n_per_frame, c,
+                         h, w, accumulate, stream);
 }
 
 extern "C" int tg_wgrad3x3(const float* p, int64_t p_nstride, const float* q, int64_t q_nstride,
@@ -977,6 +1086,16 @@ extern "C" int tg_wgrad3x3_multi_phased(const float* const* p_list, const float*
   TG_REQUIRE(cphase > 0, TG_E_ARG, "wgrad3x3_multi_phased: cphase=%d", cphase);
   return wgrad_launch(p_list, q_list, nseg, p_nstride, q_nstride, grad, workspace, n_per_seg, ca, cb,
                       cb, 0, h, w, accumulate, stream, cphase, taps_phase0, taps_phase1);
+}
+
+// tg_wgrad3x3_multi that also takes the layer's bias gradient (bias_grad (ca,) (+)= sum of P over images and
+// pixels) from the P values it stages anyway; forms without the vector staging run the stand-alone reduction.
+extern "C" int tg_wgrad3x3_multi_bias(const float* const* p_list, const float* const* q_list, int nseg,
+                                      int64_t p_nstride, int64_t q_nstride, float* grad, float* bias_grad,
+                                      float* workspace, int n_per_seg, int ca, int cb, int cb_total, int cb_off,
+                                      int h, int w, int accumulate, tg_stream_t stream) {
+  return wgrad_launch(p_list, q_list, nseg, p_nstride, q_nstride, grad, workspace, n_per_seg, ca, cb,
+                      cb_total, cb_off, h, w, accumulate, stream, 0, 0, 0, 0, bias_grad);
 }
 
 // dW of ConvTranspose2d(ci, co, 3, 2, 1, output_padding 1): x_list[i] (n_per_seg, ci, h, w) = the layer's

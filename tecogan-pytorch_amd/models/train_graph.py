@@ -118,9 +118,11 @@ class Tape:
     # are collected during the reverse sweep and reduced by ONE wgrad launch per layer
     # over the concatenated batch: 19x fewer launches / split-K reductions, and enough
     # pixel tiles per launch to fill the GPU.
-    def defer_wgrad(self, key, p, q, target, cb_off=0, post=None, phased=None, convt=False):
+    def defer_wgrad(self, key, p, q, target, cb_off=0, post=None, phased=None, convt=False, bias=None):
+        """bias: the layer's bias-gradient buffer -- db = sum of p = dZ comes out of the same launch
+        (instead of defer_bias: a second pass over every dZ)."""
         ent = self.deferred.setdefault(key, {'p': [], 'q': [], 'target': target, 'cb_off': cb_off,
-                                             'post': post, 'phased': phased, 'convt': convt})
+                                             'post': post, 'phased': phased, 'convt': convt, 'bias': bias})
         ent['p'].append(p)
         ent['q'].append(q)
 
@@ -148,11 +150,11 @@ class Tape:
             elif ent['post'] is None:
                 if multi:      # one launch over the per-frame tensors where they lie
                     ops.wgrad3x3_multi(ent['p'], ent['q'], ent['target'], cb_off=ent['cb_off'],
-                                       accumulate=True)
+                                       accumulate=True, bias_grad=ent.get('bias'))
                 else:
                     P = ent['p'][0] if len(ent['p']) == 1 else torch.cat(ent['p'], 0)
                     Q = ent['q'][0] if len(ent['q']) == 1 else torch.cat(ent['q'], 0)
-                    ops.wgrad3x3(P, Q, ent['target'], cb_off=ent['cb_off'], accumulate=True)
+                    ops.wgrad3x3(P, Q, ent['target'], cb_off=ent['cb_off'], accumulate=True, bias_grad=ent.get('bias'))
             else:
                 p0, q0 = ent['p'][0], ent['q'][0]
                 # accumulate=False below: every tap the post hook reads is overwritten
@@ -175,8 +177,8 @@ class Tape:
             layers = ent['layers']
             if not layers[1].weight.requires_grad:
                 continue
-            ops.wgrad3x3_body(ent['dz'], ent['acts'], [_grad_buf(m.weight) for m in layers[1:]])
-            ops.bias_grad_body(ent['dz'], [_grad_buf(m.bias) for m in layers])
+            ops.wgrad3x3_body(ent['dz'], ent['acts'], [_grad_buf(m.weight) for m in layers[1:]],
+                              dbs=[_grad_buf(m.bias) for m in layers[1:]])
         self.deferred_body = {}
         for buf, dzs in self.deferred_bias.values():
             if len(dzs) > 1 and same(dzs):
@@ -262,10 +264,10 @@ def conv3x3(tape, layer, x, act=NONE, x2=None, res=None, need_dx=True, need_dx2=
             dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
         if w.requires_grad:
             gw = _grad_buf(w)
-            tape.defer_wgrad(('w', id(layer), 0), dz, x, gw, 0)
+            # (the bias gradient rides on one of the layer's weight-gradient launches)
+            tape.defer_wgrad(('w', id(layer), 0), dz, x, gw, 0, bias=None if x2 is not None else _grad_buf(b))
             if x2 is not None:
-                tape.defer_wgrad(('w', id(layer), 1), dz, x2, gw, c1)
-            tape.defer_bias(_grad_buf(b), dz)
+                tape.defer_wgrad(('w', id(layer), 1), dz, x2, gw, c1, bias=_grad_buf(b))
         wd = w.detach()
         if need_dx and c1 <= 4 and cout <= 64 and x2 is None:
             # data gradient onto an image (VGG's first conv): cout -> <=4 channels is the small
@@ -306,13 +308,11 @@ def resblock(tape, conv1, conv2, x):
         if g is None:
             return
         if w2.requires_grad:
-            tape.defer_wgrad(('w', id(conv2), 0), g, y1, _grad_buf(w2), 0)
-            tape.defer_bias(_grad_buf(b2), g)
+            tape.defer_wgrad(('w', id(conv2), 0), g, y1, _grad_buf(w2), 0, bias=_grad_buf(b2))
         pk2 = _CACHE.get(conv2, ('dg', 0), _ver(w2), lambda: ops.pack_conv3x3_dgrad(w2.detach().contiguous()))
         dz1 = ops.conv3x3(g, pk2[0], None, c, c, pk2[3], relu_mask=y1)
         if w1.requires_grad:
-            tape.defer_wgrad(('w', id(conv1), 0), dz1, x, _grad_buf(w1), 0)
-            tape.defer_bias(_grad_buf(b1), dz1)
+            tape.defer_wgrad(('w', id(conv1), 0), dz1, x, _grad_buf(w1), 0, bias=_grad_buf(b1))
         pk1 = _CACHE.get(conv1, ('dg', 0), _ver(w1), lambda: ops.pack_conv3x3_dgrad(w1.detach().contiguous()))
         tape.add_grad(x, ops.conv3x3(dz1, pk1[0], None, c, w1.shape[1], pk1[3], res=g))
     tape.record(bwd)
@@ -437,9 +437,9 @@ def srnet_body(tape, srnet, lr, tran):
         if conv_in.weight.requires_grad:
             gw = _grad_buf(conv_in.weight)
             tape.defer_wgrad(('w', id(conv_in), 0), dz[0], lr, gw, 0)
-            tape.defer_wgrad(('w', id(conv_in), 1), dz[0], tran, gw, c_lr)
-            # the residual-block convs' weight gradients and ALL the bias gradients (conv_in's too)
-            # are taken from the per-frame blocks by one launch each when the tape is flushed
+            tape.defer_wgrad(('w', id(conv_in), 1), dz[0], tran, gw, c_lr, bias=_grad_buf(conv_in.bias))
+            # the residual-block convs' weight AND bias gradients are taken from the per-frame blocks by
+            # one launch when the tape is flushed (conv_in's bias gradient rides on its own launch above)
             tape.defer_body(id(srnet), layers, acts, dz)
         tape.add_grad(tran, d_tran)
     tape.record(bwd)
@@ -469,8 +469,7 @@ def conv3x3_small(tape, layer, x, act=NONE, up_src=None, up_mode=ops.UP_NONE, up
             return
         dz = ops.act_bwd(g, y, act, out=g) if act != NONE else g
         if w.requires_grad:
-            tape.defer_wgrad(('w', id(layer), 0), dz, x, _grad_buf(w), 0)
-            tape.defer_bias(_grad_buf(b), dz)
+            tape.defer_wgrad(('w', id(layer), 0), dz, x, _grad_buf(w), 0, bias=_grad_buf(b))
         fuse = id(x) in tape.relu_outputs        # x = relu(...): deliver dZ of that layer directly
         if ops.conv3x3_fewin_ok(dz, cin) and (not fuse or x.data_ptr() % 16 == 0):
             # few channels in, many out: the VALU kernel (the MFMA one pads K = 9 cout to a 72-deep chunk)

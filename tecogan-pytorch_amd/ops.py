@@ -417,8 +417,11 @@ def _wgrad_workspace(device, nfloats):
     return ws
 
 
-def wgrad3x3(p, q, grad, cb_off=0, accumulate=True):
-    """grad[a, cb_off:cb_off+cb, ky, kx] (+)= sum p[n,a,y,x] * q[n,b,y+ky-1,x+kx-1]."""
+def wgrad3x3(p, q, grad, cb_off=0, accumulate=True, bias_grad=None):
+    """grad[a, cb_off:cb_off+cb, ky, kx] (+)= sum p[n,a,y,x] * q[n,b,y+ky-1,x+kx-1];
+    bias_grad (ca,) (+)= sum of p (same launch, tg_wgrad3x3_multi_bias)."""
+    if bias_grad is not None:
+        return wgrad3x3_multi([p], [q], grad, cb_off=cb_off, accumulate=accumulate, bias_grad=bias_grad)
     _chk(p, 'p'); _chk(q, 'q'); _chk(grad, 'grad')
     n, ca, h, w = p.shape
     cb = q.shape[1]
@@ -441,7 +444,7 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def wgrad3x3_multi(p_list, q_list, grad, cb_off=0, accumulate=True, phased=None):
+def wgrad3x3_multi(p_list, q_list, grad, cb_off=0, accumulate=True, phased=None, bias_grad=None):
     """wgrad3x3 over the concatenation of equally shaped (p_i, q_i) pairs without concatenating
     them: one launch reads up to MAX_SEGS separately allocated segments.
     phased = (cphase, taps_phase0, taps_phase1): q is a space-to-depth embedded tensor; only the
@@ -474,6 +477,12 @@ def wgrad3x3_multi(p_list, q_list, grad, cb_off=0, accumulate=True, phased=None)
                                                  int(phased[1]), int(phased[2]), _stream()),
                     'tg_wgrad3x3_multi_phased')
             continue
+        if bias_grad is not None:       # the layer's bias gradient out of the same pass over p = dZ
+            L.check(lib.tg_wgrad3x3_multi_bias(_ptr_array(ps), _ptr_array(qs), len(ps), ca * h * w, cb * h * w,
+                                               grad.data_ptr(), bias_grad.data_ptr(), ws.data_ptr(), n, ca, cb,
+                                               cb_total, cb_off, h, w, 1 if (accumulate or i > 0) else 0,
+                                               _stream()), 'tg_wgrad3x3_multi_bias')
+            continue
         L.check(lib.tg_wgrad3x3_multi(_ptr_array(ps), _ptr_array(qs), len(ps), ca * h * w, cb * h * w,
                                       grad.data_ptr(), ws.data_ptr(), n, ca, cb, cb_total, cb_off, h, w,
                                       1 if (accumulate or i > 0) else 0, _stream()), 'tg_wgrad3x3_multi')
@@ -505,7 +514,7 @@ def wgrad3x3_convt_multi(x_list, dz_list, grad, accumulate=True, bias_grad=None)
     return grad
 
 
-def wgrad3x3_body(dz_list, acts_list, grads, accumulate=True):
+def wgrad3x3_body(dz_list, acts_list, grads, accumulate=True, dbs=None):
     """tg_wgrad3x3_body: weight gradients of the chained SRNet body's 2*nb residual-block convs over ALL
     unrolled frames in one launch.  dz_list[f] / acts_list[f]: (1 + 2nb, n, c, h, w) blocks of frame f
     (dz[2nb] = gradient of the body's output); grads: the 2nb weight-gradient tensors."""
@@ -524,6 +533,11 @@ def wgrad3x3_body(dz_list, acts_list, grads, accumulate=True):
     for i in range(0, len(dz_list), MAX_SEGS):
         dzs, acs = dz_list[i:i + MAX_SEGS], acts_list[i:i + MAX_SEGS]
         ws = _wgrad_workspace(grads[0].device, lib.tg_wgrad3x3_body_workspace_floats(len(dzs), n, nl - 1, c, h, w))
+        if dbs is not None:         # dbs[L - 1] (+)= bias gradient of layer L = 1 .. 2nb, same launch
+            L.check(lib.tg_wgrad3x3_body_bias(_ptr_array(dzs), _ptr_array(acs), len(dzs), n * c * h * w,
+                                              nl - 1, _ptr_array(grads), _ptr_array(dbs), ws.data_ptr(), n, c, h, w,
+                                              1 if (accumulate or i > 0) else 0, _stream()), 'tg_wgrad3x3_body_bias')
+            continue
         L.check(lib.tg_wgrad3x3_body(_ptr_array(dzs), _ptr_array(acs), len(dzs), n * c * h * w,
                                      nl - 1, _ptr_array(grads), ws.data_ptr(), n, c, h, w,
                                      1 if (accumulate or i > 0) else 0, _stream()), 'tg_wgrad3x3_body')

@@ -777,3 +777,37 @@ def test_depth_to_space_with_the_activation_derivative(ops, act):
     tape.backward()
     assert id(yd) in tape.act_applied                    # (the strided conv's gradient arrived first, fused)
     assert relerr(tape.grad(xd), xr.grad) <= 2e-5, relerr(tape.grad(xd), xr.grad)
+
+
+@pytest.mark.parametrize('nseg,n,ca,cb,h,w', [(3, 2, 64, 64, 16, 24), (1, 4, 64, 27, 12, 40), (2, 3, 32, 32, 9, 36),
+                                               (1, 5, 128, 64, 16, 16), (1, 6, 256, 128, 8, 8), (2, 2, 64, 3, 10, 8),
+                                               (1, 2, 3, 64, 8, 12), (1, 2, 64, 48, 7, 21)])
+def test_bias_gradient_rides_on_the_weight_gradient_launch(ops, nseg, n, ca, cb, h, w):
+    """tg_wgrad3x3_multi_bias: db out of the staged dZ on every form of the launch (vector / element-wise
+    staging, folded tiles, shared pixels, exchanged operands, small-ca) = tg_bias_grad_multi."""
+    ps = [dev(rs(10 + i, (n, ca, h, w))) for i in range(nseg)]
+    qs = [dev(rs(40 + i, (n, cb, h, w))) for i in range(nseg)]
+    g1, g2 = torch.zeros(ca, cb, 3, 3, device='cuda'), torch.zeros(ca, cb, 3, 3, device='cuda')
+    db1, db2 = torch.full((ca,), 3.0, device='cuda'), torch.full((ca,), 3.0, device='cuda')
+    ops.wgrad3x3_multi(ps, qs, g1, accumulate=True, bias_grad=db1)
+    ops.wgrad3x3_multi(ps, qs, g2, accumulate=True)
+    ops.bias_grad_multi(ps, db2, accumulate=True)
+    assert torch.equal(g1, g2)
+    assert relerr(db1, db2) <= 1e-5, relerr(db1, db2)
+
+
+def test_body_bias_gradients_ride_on_the_layered_launch(ops):
+    nf, nl, n, h, w, frames = 64, 5, 2, 16, 24, 3
+    acts = [dev(rs(10 + f, (nl, n, nf, h, w))) for f in range(frames)]
+    dz = [dev(rs(50 + f, (nl, n, nf, h, w))) for f in range(frames)]
+    g1 = [torch.zeros(nf, nf, 3, 3, device='cuda') for _ in range(nl - 1)]
+    g2 = [torch.zeros(nf, nf, 3, 3, device='cuda') for _ in range(nl - 1)]
+    db1 = [torch.zeros(nf, device='cuda') for _ in range(nl - 1)]
+    db2 = [torch.zeros(nf, device='cuda') for _ in range(nl)]
+    ops.wgrad3x3_body(dz, acts, g1, dbs=db1)
+    ops.wgrad3x3_body(dz, acts, g2)
+    ops.bias_grad_body(dz, db2)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    for L_ in range(1, nl):
+        assert relerr(db1[L_ - 1], db2[L_]) <= 1e-5, L_
