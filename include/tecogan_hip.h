@@ -485,6 +485,10 @@ int tg_upsample_bwd(const float* dy, float* dx, int nc, int h, int w, int scale,
  * dimg (n,c,h,w) and/or dflow (n,2,h,w); either may be NULL. */
 int tg_backward_warp_bwd(const float* x, const float* flow, const float* dy, float* dimg,
                          float* dflow, int n, int c, int h, int w, tg_stream_t stream);
+/* the same, but the image gradient is ADDED to what dimg_acc already holds (no zeroing, no separate
+ * accumulation pass: the frame a warp reads usually has a gradient of its own loss term already). */
+int tg_backward_warp_bwd_acc(const float* x, const float* flow, const float* dy, float* dimg_acc, float* dflow,
+                             int n, int c, int h, int w, tg_stream_t stream);
 /* inverse of tg_space_to_depth: x (n, s*s*c, h, w) -> y (n, c, s*h, s*w) */
 int tg_depth_to_space(const float* x, float* y, int n, int c, int h, int w, int scale,
                       tg_stream_t stream);

@@ -709,17 +709,30 @@ extern "C" int tg_upsample_bwd(const float* dy, float* dx, int nc, int h, int w,
   return check_launch("upsample_bwd");
 }
 
-extern "C" int tg_backward_warp_bwd(const float* x, const float* flow, const float* dy, float* dimg,
-                                    float* dflow, int n, int c, int h, int w, tg_stream_t stream) {
+static int warp_bwd_impl(const float* x, const float* flow, const float* dy, float* dimg,
+                         float* dflow, int n, int c, int h, int w, tg_stream_t stream, bool zero_img) {
   TG_REQUIRE(x && flow && dy && (dimg || dflow), TG_E_ARG, "backward_warp_bwd: null pointer");
   TG_REQUIRE(n > 0 && c > 0 && h >= 2 && w >= 2, TG_E_SHAPE, "backward_warp_bwd: shape");
-  if (dimg) {
+  if (dimg && zero_img) {
     hipError_t e = hipMemsetAsync(dimg, 0, (size_t)n * c * h * w * sizeof(float), ST);
     TG_REQUIRE(e == hipSuccess, TG_E_HIP, "backward_warp_bwd: memset: %s", hipGetErrorString(e));
   }
   dim3 g(cdiv(w, 64), cdiv(h, 4), n), t(256);
   hipLaunchKernelGGL(backward_warp_bwd_kernel, g, t, 0, ST, x, flow, dy, dimg, dflow, n, c, h, w);
   return check_launch("backward_warp_bwd");
+}
+
+extern "C" int tg_backward_warp_bwd(const float* x, const float* flow, const float* dy, float* dimg,
+                                    float* dflow, int n, int c, int h, int w, tg_stream_t stream) {
+  return warp_bwd_impl(x, flow, dy, dimg, dflow, n, c, h, w, stream, true);
+}
+
+// the image gradient is ADDED to what dimg holds (the scatter uses atomic adds anyway): the frame a
+// warp reads usually has a gradient already (its own loss term) -- no memset, no separate accumulation pass
+extern "C" int tg_backward_warp_bwd_acc(const float* x, const float* flow, const float* dy, float* dimg_acc,
+                                        float* dflow, int n, int c, int h, int w, tg_stream_t stream) {
+  TG_REQUIRE(dimg_acc, TG_E_ARG, "backward_warp_bwd_acc: null pointer");
+  return warp_bwd_impl(x, flow, dy, dimg_acc, dflow, n, c, h, w, stream, false);
 }
 
 extern "C" int tg_depth_to_space(const float* x, float* y, int n, int c, int h, int w, int scale,

@@ -39,6 +39,10 @@ class Tape:
         # same tensor to the same form before it accumulates.
         self.act_outputs = {}
         self.act_applied = set()
+        # a consumer that will copy the gradient of t into a buffer of its own anyway (the chained body puts
+        # the gradient of its output into the last slot of its dZ block) may reserve that buffer here; a
+        # producer that can write into a given tensor then delivers the gradient in place
+        self.reserved = {}
         self.side = None        # side stream of the asynchronous weight-gradient flushes
         self._inflight = []     # tensors the side stream still reads (kept alive until the join)
 
@@ -416,17 +420,20 @@ def srnet_body(tape, srnet, lr, tran):
     out = acts[nl - 1]
     if tape is None:
         return out
+    dz = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=lr.device)
+    tape.reserved[id(out)] = dz[nl - 1]    # the gradient of the body's output lives in the block's last slot
 
     def bwd():
         g = tape.pop_grad(out)
+        tape.reserved.pop(id(out), None)
         if g is None:
             return
         dg = (L.PackedLayer * nl)()
         hold = dgp
         for i in range(nl):
             dg[i].w = dgp[i].data_ptr()
-        dz = torch.empty(nl, n, nf, h, w, dtype=torch.float32, device=g.device)
-        dz[nl - 1].copy_(g)       # the gradient of the body's output lives in the block's last slot
+        if g.data_ptr() != dz[nl - 1].data_ptr():
+            dz[nl - 1].copy_(g)   # (a producer that could not write in place)
         d_tran = torch.empty(n, c_tran, h, w, dtype=torch.float32, device=g.device)
         fl, er, ep = _ChainState.buffers(nl + 1, n, h, w, g.device)
         L.check(L.lib().tg_srnet_body_bwd(dg, layout, nb, acts.data_ptr(), dz.data_ptr(), d_tran.data_ptr(),
@@ -555,7 +562,8 @@ def convt3x3s2(tape, layer, x, act=RELU):
             # small frames: the gradient taken directly as a stride-2 conv of dZ (K = 9 co) -- 11 us
             # instead of 27 us for the 32-chunk phased form on s2d(dZ)
             wk = _CACHE.get(layer, ('ctd',), _ver(w), lambda: ops.pack_conv3x3(w.detach().contiguous(), ocb=64)[0])
-            tape.add_grad(x, ops.conv3x3s2(dz, wk, co, ci, relu_mask=x if fuse else None), masked=fuse)
+            buf = tape.reserved.get(id(x)) if tape.grad(x) is None else None
+            tape.add_grad(x, ops.conv3x3s2(dz, wk, co, ci, relu_mask=x if fuse else None, out=buf), masked=fuse)
         else:
             s = ops.space_to_depth(dz, 2)                          # (n, 4co, h, w)
             we = _CACHE.get(layer, ('cte',), _ver(w), lambda: ops.pack_conv3x3(_convt_embed(w.detach())))
@@ -674,9 +682,18 @@ def backward_warp(tape, x, flow, need_dimg=True, need_dflow=True, dflow_out=None
             g = tape.pop_grad(y)
             if g is None:
                 return
-            dimg, dflow = ops.backward_warp_bwd(x, flow, g, need_dimg, need_dflow,
-                                                dflow_out() if dflow_out is not None else None)
-            if need_dimg:
+            cur = tape.grad(x) if need_dimg else None
+            if cur is not None and cur.is_contiguous() and id(x) not in tape.act_applied:
+                # x has a gradient already (its own loss term): the scatter adds into it -- no memset of a new
+                # tensor, no accumulation pass
+                tape.unmasked.add(id(x))
+                _, dflow = ops.backward_warp_bwd(x, flow, g, True, need_dflow,
+                                                 dflow_out() if dflow_out is not None else None, dimg_acc=cur)
+                dimg = None
+            else:
+                dimg, dflow = ops.backward_warp_bwd(x, flow, g, need_dimg, need_dflow,
+                                                    dflow_out() if dflow_out is not None else None)
+            if need_dimg and dimg is not None:
                 tape.add_grad(x, dimg)
             if need_dflow and dflow_out is None:
                 tape.add_grad(flow, dflow)

@@ -197,7 +197,7 @@ def conv3x3s2_supported(n, cin, cout, h_out, w_out):
     return bool(L.lib().tg_conv3x3s2_supported(n, cin, cout, h_out, w_out))
 
 
-def conv3x3s2(x, wpk, cin, cout, relu_mask=None):
+def conv3x3s2(x, wpk, cin, cout, relu_mask=None, out=None):
     """Stride-2 3x3 conv (tg_conv3x3s2_fwd): x (n, cin, 2h, 2w) -> (n, cout, h, w); the data gradient of
     ConvTranspose2d(k3, s2, p1, op1) with wpk = pack_conv3x3(W viewed as (cout = ci, cin = co), ocb 64)."""
     _chk(x, 'x')
@@ -205,7 +205,12 @@ def conv3x3s2(x, wpk, cin, cout, relu_mask=None):
     if c != cin or h2 % 2 or w2 % 2:
         raise L.TecoganHipError(f'conv3x3s2: x {tuple(x.shape)} cin {cin}')
     h, w = h2 // 2, w2 // 2
-    out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(n, cout, h, w, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (n, cout, h, w):
+        raise L.TecoganHipError(f'conv3x3s2: out {tuple(out.shape)}')
+    else:
+        _chk(out, 'out')
     if relu_mask is not None:
         _chk(relu_mask, 'relu_mask')
         if relu_mask.shape != out.shape:
@@ -611,11 +616,21 @@ def upsample_bwd(dy, scale, up_mode, mul=1.0):
     return dx
 
 
-def backward_warp_bwd(x, flow, dy, need_img=True, need_flow=True, dflow_out=None):
+def backward_warp_bwd(x, flow, dy, need_img=True, need_flow=True, dflow_out=None, dimg_acc=None):
     """`dflow_out`: write the flow gradient into this (contiguous, flow-shaped) buffer instead
-    of a new tensor (a slice of the frame-major gradient of the training unroll)."""
+    of a new tensor (a slice of the frame-major gradient of the training unroll).  `dimg_acc`: ADD the
+    image gradient to this tensor (the gradient x already has) instead of returning a new one."""
     _chk(x, 'x'); _chk(flow, 'flow'); _chk(dy, 'dy')
     n, c, h, w = x.shape
+    if dimg_acc is not None:
+        _chk(dimg_acc, 'dimg_acc')
+        assert dimg_acc.shape == x.shape
+        dflow = None
+        if need_flow:
+            dflow = _chk(dflow_out, 'dflow_out') if dflow_out is not None else torch.empty_like(flow)
+        L.check(L.lib().tg_backward_warp_bwd_acc(x.data_ptr(), flow.data_ptr(), dy.data_ptr(), dimg_acc.data_ptr(),
+                                                 _ptr(dflow), n, c, h, w, _stream()), 'tg_backward_warp_bwd_acc')
+        return dimg_acc, dflow
     dimg = torch.empty_like(x) if need_img else None
     if need_flow and dflow_out is not None:
         dflow = _chk(dflow_out, 'dflow_out')
