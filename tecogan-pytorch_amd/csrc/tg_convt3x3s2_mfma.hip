@@ -252,6 +252,138 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
   }
 }
 
+// ---- small frames (the training unroll: 2 x 32 x 32 .. 2 x 64 x 64 inputs per launch) ----------------
+// The kernel above gives 32-128 workgroups there, each wave walking the 8 channel chunks of its row one
+// after the other (288 dependent MFMAs = 8.8 us, 15-16 us per launch with 12 % of the SIMDs busy).  The
+// one-shot scheme of tg_conv3x3_mfma.hip instead: a workgroup = ONE input row x 32 pixels x 64 channels
+// x 4 phases, all 8 chunks of the 2-row patch staged at once (12 loads per thread, all in flight), the 8
+// waves = 2 oc halves x 4 K groups of two chunks (72 MFMAs each, weights straight from L2 into
+// registers), the K groups meet in LDS in a fixed order and every wave finishes one (output row, half
+// of the accumulator registers) pair: bias, activation, 8-byte stores.
+constexpr int TOS_CH_FLOATS = 2 * 2 * TRS * 4;        // one chunk of the patch: 2 rows x 2 halves x 34 slots x 4
+__global__ __launch_bounds__(512) void convt3x3s2_oneshot_kernel(ConvTArgs a) {
+  constexpr int KG = 4, W_FLOATS = 9 * CK * TOCB;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_in = smem;                                 // [8 chunks][TOS_CH_FLOATS]
+  float* red = smem + 8 * TOS_CH_FLOATS;              // [2 oc halves][4 K groups][4 phases][16][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+  const int lh = lane >> 5, ll = lane & 31;
+  int b = blockIdx.x;
+  const int tx = b % a.tiles_x; b /= a.tiles_x;
+  const int ty = b % a.tiles_y;
+  const int n = b / a.tiles_y;
+  const int x0 = tx * TTW, y0 = ty;
+  const int hw = a.h * a.w;
+  const unsigned plane = (unsigned)hw * 4u;
+  const int nchunk = a.nchunk;
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (long long)n * a.x_ns), 0, a.cin * hw * 4, 0x00020000);
+  // ---- this wave's weights: chunks 2 wk, 2 wk + 1
+  const f32x4* wl = reinterpret_cast<const f32x4*>(a.wpk) + (lh * TOCB + wn * 32 + ll);
+  f32x4 aw[2][9];
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int c = wk * 2 + ci;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < nchunk) v = wl[(size_t)c * (W_FLOATS / 4) + tap * (2 * TOCB)];
+      aw[ci][tap] = v;
+    }
+  }
+  // ---- the patch: item q = (chunk, row r, half hf, col) -> 4 channel planes, all loads before the first store
+  constexpr int ITEMS_PER_CH = 2 * 2 * TPW;            // 132
+  constexpr int MAXQ = (8 * ITEMS_PER_CH + 511) / 512;  // 3
+  const int total = nchunk * ITEMS_PER_CH;
+  f32x4 v[MAXQ];
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k) {
+    const int q = tid + k * 512;
+    const int ch = q / ITEMS_PER_CH, rem = q - ch * ITEMS_PER_CH;
+    const int r = rem / (2 * TPW), rem2 = rem - r * (2 * TPW);
+    const int hf = rem2 / TPW, col = rem2 - hf * TPW;
+    const int gy = y0 + r, gx = x0 + col;
+    const bool ok = q < total && gy < a.h && gx < a.w;
+    const unsigned base = ok ? (unsigned)(((ch * CK + 4 * hf) * hw + gy * a.w + gx) * 4) : TOOB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      v[k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, (int)(base + (unsigned)j * plane), 0, 0));
+  }
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k) {
+    const int q = tid + k * 512;
+    const int ch = q / ITEMS_PER_CH, rem = q - ch * ITEMS_PER_CH;
+    const int r = rem / (2 * TPW), rem2 = rem - r * (2 * TPW);
+    const int hf = rem2 / TPW, col = rem2 - hf * TPW;
+    if (q < total) *reinterpret_cast<f32x4*>(s_in + ch * TOS_CH_FLOATS + ((r * 2 + hf) * TRS + col) * 4) = v[k];
+  }
+  __syncthreads();
+  // ---- MFMAs: acc[phase = py * 2 + px], 32 oc x 32 input pixels each
+  f32x16 acc[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+#define TG_CTO_TAP(P, TAP, BV)                                                             \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) acc[P] =                                \
+      __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ci][TAP][kk], BV[kk], acc[P], 0, 0, 0);
+#pragma unroll
+  for (int ci = 0; ci < 2; ++ci) {
+    const int c = wk * 2 + ci;
+    if (c < nchunk) {
+      const float* si = s_in + c * TOS_CH_FLOATS + (lh * TRS + ll) * 4;
+      const f32x4 b00 = *reinterpret_cast<const f32x4*>(si);
+      const f32x4 b01 = *reinterpret_cast<const f32x4*>(si + 4);
+      const f32x4 b10 = *reinterpret_cast<const f32x4*>(si + 2 * TRS * 4);
+      const f32x4 b11 = *reinterpret_cast<const f32x4*>(si + 2 * TRS * 4 + 4);
+      TG_CTO_TAP(0, 4, b00)   // (py0,px0): ky1,kx1 in[y][x]
+      TG_CTO_TAP(1, 3, b01)   // (py0,px1): ky1,kx0 in[y][x+1]
+      TG_CTO_TAP(1, 5, b00)   //            ky1,kx2 in[y][x]
+      TG_CTO_TAP(2, 1, b10)   // (py1,px0): ky0,kx1 in[y+1][x]
+      TG_CTO_TAP(2, 7, b00)   //            ky2,kx1 in[y][x]
+      TG_CTO_TAP(3, 0, b11)   // (py1,px1): ky0,kx0 in[y+1][x+1]
+      TG_CTO_TAP(3, 2, b10)   //            ky0,kx2 in[y+1][x]
+      TG_CTO_TAP(3, 6, b01)   //            ky2,kx0 in[y][x+1]
+      TG_CTO_TAP(3, 8, b00)   //            ky2,kx2 in[y][x]
+    }
+  }
+#undef TG_CTO_TAP
+  // ---- the K groups meet in LDS; wave (wn, wk) finishes output row py = wk & 1, registers [8 (wk >> 1), +8)
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(((wn * KG + wk) * 4 + p) * 16 + r) * 64 + lane] = acc[p][r];
+  __syncthreads();
+  const int fpy = wk & 1, r0 = 8 * (wk >> 1);
+  const int px = x0 + ll, py = y0;
+  if (px < a.w && py < a.h) {
+    const float slope = act_slope(a.act);
+    const int ow = 2 * a.w;
+    const long long ohw = 4ll * hw;
+    float* yb = a.y + (long long)n * a.y_ns + (long long)(2 * py + fpy) * ow + 2 * px;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = r0 + rr;
+      const int oc = wn * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {                   // fixed order
+        s0 += red[(((wn * KG + g) * 4 + fpy * 2 + 0) * 16 + r) * 64 + lane];
+        s1 += red[(((wn * KG + g) * 4 + fpy * 2 + 1) * 16 + r) * 64 + lane];
+      }
+      if (oc < a.cout) {
+        const float bb = a.bias ? a.bias[oc] : 0.f;
+        float2 o;
+        s0 += bb; s1 += bb;
+        o.x = s0 >= 0.f ? s0 : s0 * slope + 0.f;
+        o.y = s1 >= 0.f ? s1 : s1 * slope + 0.f;
+        *reinterpret_cast<float2*>(yb + (long long)oc * ohw) = o;
+      }
+    }
+  }
+}
+
 // A operand of the Z-mode contraction: wz[(half*16 + r)*64 + l] = Wout[o][c][tap] for tap-plane
 // row m = l & 31 (m = tap*cz + o < 9*cz, else 0) and channel c = half*32 + (r&3) + 8*(r>>2) +
 // 4*(l>>5) (< nf, else 0).  Wout is the output conv's OIHW weight (cz, nf, 3, 3).
@@ -379,6 +511,20 @@ extern "C" int tg_convt3x3s2_fwd(const float* x, int64_t x_nstride, const float*
   a.tiles_x = cdiv(w, TTW);
   a.nocg = cdiv(cout, TOCB);
   a.nchunk = cdiv(cin, CK);
+  // at most one one-row tile per CU (the training frames): everything in flight at once
+  if (cin <= 64 && cout <= 64 && (long long)a.tiles_x * h * n <= 256) {
+    a.tiles_y = h;
+    const size_t lds1 = (size_t)(8 * TOS_CH_FLOATS + 2 * 4 * 4 * 16 * 64) * sizeof(float);      // 148 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convt3x3s2_oneshot_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(convt3x3s2_oneshot_kernel, dim3((unsigned)(a.tiles_x * h * n)), dim3(512), lds1,
+                       (hipStream_t)stream, a);
+    return check_launch("convt3x3s2_oneshot");
+  }
   // 4-row workgroups (8 waves) unless that leaves fewer than two workgroups per CU: a 134x320
   // input is 340 of them = 1.33 per CU (the CUs with two finish last: 66 % balance); 2-row
   // workgroups (670 = 2.62 per CU, 87 %) take the small frames.  TG_CONVT_ROWS overrides (lab).

@@ -446,7 +446,11 @@ def test_conv3x3_inplace_residual(ops):
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w', [(1, 64, 64, 12, 20), (2, 64, 64, 7, 35),
-                                            (1, 64, 64, 33, 64), (1, 16, 40, 5, 6)])
+                                            (1, 64, 64, 33, 64), (1, 16, 40, 5, 6),
+                                            # > 256 one-row tiles: the chunk-by-chunk kernel (2- and 4-row workgroups)
+                                            (2, 64, 64, 70, 66), (3, 64, 64, 130, 40), (1, 72, 64, 9, 33),
+                                            # the training frames: one-shot kernel
+                                            (2, 64, 64, 32, 32), (2, 64, 64, 64, 64), (2, 51, 37, 11, 70)])
 def test_convt3x3s2_mfma(ops, n, cin, cout, h, w):
     import torch.nn.functional as F
     x = rs(1, (n, cin, h, w), -1, 1)
