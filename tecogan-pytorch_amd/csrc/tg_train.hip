@@ -470,6 +470,64 @@ __global__ void div_scalar_kernel(float* __restrict__ y, const float* __restrict
 
 // ---- BatchNorm2d (train) + LeakyReLU(0.2) fused ---------------------------------
 // stats: one block per channel -> mean, invstd (biased var), running stats update
+// One pass over channel `ch` of n images (plane hw) of NA arrays that share the element offset:
+// acc(t) is called once per element with t[a] = arr[a][element].  Four images at a time, 16-byte loads
+// when the plane allows: 4 NA independent loads in flight per thread instead of one dependent load per
+// iteration (the per-channel BatchNorm reductions were chains of n * hw / threads round trips: 16 us for 3 MB).
+template <int NA, class Acc>
+__device__ __forceinline__ void bn_sweep(const float* const (&arr)[NA], int n, int c, int ch, int hw, Acc&& acc) {
+  bool vec = (hw & 3) == 0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) vec = vec && (reinterpret_cast<uintptr_t>(arr[a]) & 15) == 0;
+  if (vec) {
+    const int hw4 = hw >> 2;
+    int b = 0;
+    for (; b + 3 < n; b += 4) {
+      for (int i = threadIdx.x; i < hw4; i += blockDim.x) {
+        f32x4 v[4][NA];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int a = 0; a < NA; ++a)
+            v[u][a] = reinterpret_cast<const f32x4*>(arr[a] + ((long long)(b + u) * c + ch) * hw)[i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t[NA];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) t[a] = v[u][a][e];
+            acc(t);
+          }
+      }
+    }
+    for (; b < n; ++b) {
+      for (int i = threadIdx.x; i < hw4; i += blockDim.x) {
+        f32x4 v[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) v[a] = reinterpret_cast<const f32x4*>(arr[a] + ((long long)b * c + ch) * hw)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t[NA];
+#pragma unroll
+          for (int a = 0; a < NA; ++a) t[a] = v[a][e];
+          acc(t);
+        }
+      }
+    }
+    return;
+  }
+  for (int b = 0; b < n; ++b) {
+    const long long off = ((long long)b * c + ch) * hw;
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+      float t[NA];
+#pragma unroll
+      for (int a = 0; a < NA; ++a) t[a] = arr[a][off + i];
+      acc(t);
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict__ x, int n, int c,
                                                        int hw, float eps, float momentum,
                                                        float* __restrict__ save_mean,
@@ -480,20 +538,15 @@ __global__ __launch_bounds__(1024) void bn_stats_kernel(const float* __restrict_
   __shared__ float s_mean;
   int ch = blockIdx.x;
   float s = 0.f;
-  for (int b = 0; b < n; ++b) {
-    const float* p = x + ((long long)b * c + ch) * hw;
-    for (int i = threadIdx.x; i < hw; i += blockDim.x) s += p[i];
-  }
+  const float* const xs[1] = {x};
+  bn_sweep<1>(xs, n, c, ch, hw, [&](const float (&t)[1]) { s += t[0]; });
   float tot = block_sum(s, sm);
   const float cnt = (float)n * (float)hw;
   if (threadIdx.x == 0) s_mean = tot / cnt;
   __syncthreads();
   const float mean = s_mean;
   float q = 0.f;
-  for (int b = 0; b < n; ++b) {
-    const float* p = x + ((long long)b * c + ch) * hw;
-    for (int i = threadIdx.x; i < hw; i += blockDim.x) { float d = p[i] - mean; q += d * d; }
-  }
+  bn_sweep<1>(xs, n, c, ch, hw, [&](const float (&t)[1]) { const float d = t[0] - mean; q += d * d; });
   float sq = block_sum(q, sm);
   if (threadIdx.x == 0) {
     float var = sq / cnt;
@@ -533,15 +586,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(
   const long long base = (long long)blockIdx.y * n * c * hw;
   sum_dz += (long long)blockIdx.y * 2 * c;
   sum_dz_xhat += (long long)blockIdx.y * 2 * c;
-  for (int b = 0; b < n; ++b) {
-    const long long off = base + ((long long)b * c + ch) * hw;
-    for (int i = threadIdx.x; i < hw; i += blockDim.x) {
-      float g = dy[off + i];
-      float dz = y[off + i] > 0.f ? g : g * slope;
-      a += dz;
-      bq += dz * (x[off + i] - mu) * is;
-    }
-  }
+  const float* const arrs[3] = {dy + base, y + base, x + base};
+  bn_sweep<3>(arrs, n, c, ch, hw, [&](const float (&t)[3]) {
+    const float dz = t[1] > 0.f ? t[0] : t[0] * slope;
+    a += dz;
+    bq += dz * (t[2] - mu) * is;
+  });
   float r0 = block_sum(a, sm), r1 = block_sum(bq, sm);
   if (threadIdx.x == 0) { sum_dz[ch] = r0; sum_dz_xhat[ch] = r1; }
 }
@@ -978,19 +1028,14 @@ __global__ __launch_bounds__(1024) void bn_local_stats_kernel(const float* __res
   x += (long long)blockIdx.y * n * c * hw;
   stats2c += (long long)blockIdx.y * 2 * c;
   float s = 0.f;
-  for (int b = 0; b < n; ++b) {
-    const float* p = x + ((long long)b * c + ch) * hw;
-    for (int i = threadIdx.x; i < hw; i += blockDim.x) s += p[i];
-  }
+  const float* const xs[1] = {x};
+  bn_sweep<1>(xs, n, c, ch, hw, [&](const float (&t)[1]) { s += t[0]; });
   float tot = block_sum(s, sm);
   if (threadIdx.x == 0) s_mean = tot / ((float)n * (float)hw);
   __syncthreads();
   const float mean = s_mean;
   float q = 0.f;
-  for (int b = 0; b < n; ++b) {
-    const float* p = x + ((long long)b * c + ch) * hw;
-    for (int i = threadIdx.x; i < hw; i += blockDim.x) { float d = p[i] - mean; q += d * d; }
-  }
+  bn_sweep<1>(xs, n, c, ch, hw, [&](const float (&t)[1]) { const float d = t[0] - mean; q += d * d; });
   float sq = block_sum(q, sm);
   if (threadIdx.x == 0) { stats2c[ch] = mean; stats2c[c + ch] = sq; }
 }
