@@ -564,6 +564,20 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float* __restrict__ y,
                                 long long total, int c, int hw, float slope) {
+  if ((hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+    const long long total4 = total >> 2;              // 16-byte groups never straddle a channel plane
+    const int hw4 = hw >> 2;
+    TG_GRID_STRIDE(i, total4) {
+      const int ch = (int)((i / hw4) % c);
+      const float is = invstd[ch], ga = gamma[ch], mu = mean[ch], be = beta[ch];
+      const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float v = (xv[e] - mu) * is * ga + be; o[e] = v >= 0.f ? v : v * slope; }     // (the scalar form's order)
+      reinterpret_cast<f32x4*>(y)[i] = o;
+    }
+    return;
+  }
   TG_GRID_STRIDE(i, total) {
     int ch = (int)((i / hw) % c);
     float v = (x[i] - mean[ch]) * invstd[ch] * gamma[ch] + beta[ch];
@@ -610,6 +624,27 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ sum_dz,
                                     const float* __restrict__ sum_dz_xhat, float* __restrict__ dx,
                                     long long total, int c, int hw, float slope, float inv_cnt) {
+  if ((hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                         reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
+    const long long total4 = total >> 2;
+    const int hw4 = hw >> 2;
+    TG_GRID_STRIDE(i, total4) {
+      const int ch = (int)((i / hw4) % c);
+      const float mu = mean[ch], is = invstd[ch], gs = gamma[ch] * is;
+      const float m0 = sum_dz[ch] * inv_cnt, sx = sum_dz_xhat[ch];
+      const f32x4 gv = reinterpret_cast<const f32x4*>(dy)[i], yv = reinterpret_cast<const f32x4*>(y)[i],
+                  xv = reinterpret_cast<const f32x4*>(x)[i];
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dz = yv[e] > 0.f ? gv[e] : gv[e] * slope;
+        const float xhat = (xv[e] - mu) * is;
+        o[e] = gs * (dz - m0 - xhat * sx * inv_cnt);              // (the scalar form's order)
+      }
+      reinterpret_cast<f32x4*>(dx)[i] = o;
+    }
+    return;
+  }
   TG_GRID_STRIDE(i, total) {
     int ch = (int)((i / hw) % c);
     float g = dy[i];
