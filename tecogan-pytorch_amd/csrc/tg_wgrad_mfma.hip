@@ -67,7 +67,7 @@ struct WgradArgs {
   int kmode;
   // stride-2 form (dW of a transposed conv) with the vector staging: the sums of dZ over the pixels -- the
   // layer's bias gradient -- are taken from the staged Q values on their way to LDS (every HR pixel belongs
-  // to exactly one tile's "own" rows / columns): bias_part[split][cb], added by bias_part_reduce_kernel.
+  // to exactly one tile's "own" rows / columns): bias_part[split][cb], added by the tail blocks of wgrad_reduce_kernel.
   float* bias_part;
 };
 
@@ -404,28 +404,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   }
 }
 
-// (four waves take interleaved quarters of the splits, four independent chains each: a single chain over
-//  256 splits was 128 dependent round trips -- 65-165 us, more than the fused pass had saved)
-__global__ __launch_bounds__(256) void bias_part_reduce_kernel(const float* __restrict__ part, float* __restrict__ db,
-                                                               int nsplit, int cb, int accumulate) {
-  __shared__ float sm[4][64];
-  const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + o;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (c < cb) {
-    const float* p = part + c;
-    int k = sg;
-    for (; k + 12 < nsplit; k += 16) {
-      s0 += p[(long long)k * cb]; s1 += p[(long long)(k + 4) * cb];
-      s2 += p[(long long)(k + 8) * cb]; s3 += p[(long long)(k + 12) * cb];
-    }
-    for (; k < nsplit; k += 4) s0 += p[(long long)k * cb];
-  }
-  sm[sg][o] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (sg == 0 && c < cb) db[c] = (accumulate ? db[c] : 0.f) + ((sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]));
-}
-
+// (the bias partials [split][c] of an un-layered launch are added by the tail blocks of wgrad_reduce_kernel)
 // the same for every layer of a layered launch: blockIdx.y = layer; part: [layer][split][c]
 struct WgradLayerBias { float* b[24]; };
 __global__ __launch_bounds__(256) void bias_part_reduce_layers_kernel(const float* __restrict__ part, WgradLayerBias bl,
@@ -489,11 +468,32 @@ __global__ __launch_bounds__(256) void wgrad3x3_mfma_vec_kernel(WgradArgs a) { w
 // swapped (a launch with <= 4 SHIFTED channels, run by the small-ca kernel with the operands exchanged):
 //   G[a][b][ky][kx] = sum P[a](y, x) Q[b](y + ky - 1, x + kx - 1) seen from Q's side is G'[b][a][2 - ky][2 - kx];
 //   the partials are [split][cb][ca][9] and entry (b, a, 8 - t) goes to grad[a][cb_off + b][t].
+// The blocks past `gblocks` add the bias-gradient partials of the same launch ([bsplit][bn] -> db): one launch
+// less per layer.
+struct BiasTail { const float* part; float* db; int nsplit, n, gblocks; };
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part,
                                                            float* __restrict__ g, int nsplit, int ca,
                                                            int cb, int cb_total, int cb_off,
-                                                           int accumulate, int swapped) {
+                                                           int accumulate, int swapped, BiasTail bt) {
   __shared__ float sm[4][64];
+  if (bt.part && (int)blockIdx.x >= bt.gblocks) {
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int c = ((int)blockIdx.x - bt.gblocks) * 64 + o;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < bt.n) {
+      const float* p = bt.part + c;
+      int k = sg;
+      for (; k + 12 < bt.nsplit; k += 16) {
+        s0 += p[(long long)k * bt.n]; s1 += p[(long long)(k + 4) * bt.n];
+        s2 += p[(long long)(k + 8) * bt.n]; s3 += p[(long long)(k + 12) * bt.n];
+      }
+      for (; k < bt.nsplit; k += 4) s0 += p[(long long)k * bt.n];
+    }
+    sm[sg][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sg == 0 && c < bt.n) bt.db[c] = (accumulate ? bt.db[c] : 0.f) + ((sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]));
+    return;
+  }
   const long long stride = swapped ? (long long)cb * ca * 9 : (long long)ca * cb_total * 9;
   const long long total = (long long)ca * cb * 9;
   const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
@@ -871,7 +871,7 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
     if (rc != TG_OK) return rc;
     const long long total = (long long)ca * cb * 9;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, grad,
-                       sa.nblk, ca, cb, cb_total, cb_off, accumulate, 0);
+                       sa.nblk, ca, cb, cb_total, cb_off, accumulate, 0, BiasTail{});
     rc = check_launch("wgrad_reduce");
     if (rc != TG_OK || !bias_grad) return rc;
     return tg_bias_grad_multi(p_list, nseg, bias_grad, n_per_seg, ca, h * w, accumulate, stream);
@@ -895,7 +895,7 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
     if (rc != TG_OK) return rc;
     const long long total = (long long)ca * cb * 9;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace,
-                       grad, sa.nblk, ca, cb, cb_total, cb_off, accumulate, 1);
+                       grad, sa.nblk, ca, cb, cb_total, cb_off, accumulate, 1, BiasTail{});
     rc = check_launch("wgrad_reduce(swapped)");
     if (rc != TG_OK || !bias_grad) return rc;
     return tg_bias_grad_multi(p_list, nseg, bias_grad, n_per_seg, ca, h * w, accumulate, stream);
@@ -944,30 +944,25 @@ static int wgrad_launch(const float* const* p_list, const float* const* q_list, 
     const bool fuse_b = bias_grad && vec && a.nbb == 1;
     a.bias_part = fuse_b ? workspace + (size_t)a.nsplit * ca * cb_total * 9 : nullptr;
     launch_geo<WgGeo<1, 32, 1>>(a, blocks, s, vec);
-    if (bias_grad) {
+    if (bias_grad && !fuse_b) {      // element-wise staging / several channel blocks: the stand-alone reduction over the HR tensors
       int rb_ = check_launch("wgrad3x3_convt");
       if (rb_ != TG_OK) return rb_;
-      if (fuse_b) {
-        hipLaunchKernelGGL(bias_part_reduce_kernel, dim3((unsigned)cdiv(cb, 64)), dim3(256), 0, s, a.bias_part, bias_grad,
-                           a.nsplit, cb, accumulate);
-      } else {      // element-wise staging / several channel blocks: the stand-alone reduction over the HR tensors
-        rb_ = tg_bias_grad_multi(q_list, nseg, bias_grad, n_per_seg, cb, 4 * h * w, accumulate, stream);
-        if (rb_ != TG_OK) return rb_;
-      }
+      rb_ = tg_bias_grad_multi(q_list, nseg, bias_grad, n_per_seg, cb, 4 * h * w, accumulate, stream);
+      if (rb_ != TG_OK) return rb_;
     }
   }
   int rc = check_launch("wgrad3x3_mfma");
   if (rc != TG_OK) return rc;
   long long total = (long long)ca * cb * 9;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace,
-                     grad, a.nsplit * ks, ca, cb, cb_total, cb_off, accumulate, 0);
+  // the bias partials of the launch (db over ca: P = dZ; stride-2 form: over cb, Q = dZ) are added by the tail
+  // blocks of the same reduce launch
+  BiasTail bt{};
+  const int gblocks = (int)((total + 63) / 64);
+  if (a.bias_part) { bt.part = a.bias_part; bt.db = bias_grad; bt.nsplit = a.nsplit; bt.n = stride2 ? cb : ca; bt.gblocks = gblocks; }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(gblocks + (a.bias_part ? cdiv(bt.n, 64) : 0))), dim3(256), 0, s,
+                     workspace, grad, a.nsplit * ks, ca, cb, cb_total, cb_off, accumulate, 0, bt);
   rc = check_launch("wgrad_reduce");
-  if (rc != TG_OK || !bias_grad || stride2) return rc;
-  if (fuse_a) {
-    hipLaunchKernelGGL(bias_part_reduce_kernel, dim3((unsigned)cdiv(ca, 64)), dim3(256), 0, s, a.bias_part, bias_grad,
-                       a.nsplit, ca, accumulate);
-    return check_launch("bias_part_reduce");
-  }
+  if (rc != TG_OK || !bias_grad || stride2 || fuse_a) return rc;
   return tg_bias_grad_multi(p_list, nseg, bias_grad, n_per_seg, ca, h * w, accumulate, stream);
 }
 
