@@ -193,6 +193,28 @@ int64_t tg_conv3x3_wino_chain_flag_ints(int n_layers, int n, int h, int w);
 int tg_conv3x3_wino_chain(const tg_wino_layer* layers, int n_layers, int n, int cout, int h, int w,
                           int32_t* flags, int epoch, tg_stream_t stream);
 
+/* The same DEPENDENT layers of ONE frame (n = 1) on persistent, LDS-RESIDENT workgroups (round 4;
+ * tg_conv3x3_wino_res.hip): one workgroup per CU owns an 8 x 24 pixel block of the frame for ALL the
+ * layers; the 64-channel block (+ a one-pixel ring) of the current and of the next layer live in LDS,
+ * and between two layers only the block's outermost pixels travel through an exchange buffer in
+ * global memory (16 KB per workgroup instead of 11 MB written + 11 MB read per layer at 134x320).
+ * Same arithmetic in the same order as tg_conv3x3_wino_fwd: BIT-IDENTICAL results.
+ *   supported: n == 1, cout == 64, even h and w, ceil(h/8) * ceil(w/24) <= CUs - 8 (every workgroup must
+ *              be resident at once: neighbours wait for each other).  134x320 -> 238 workgroups.
+ *   layers:    as tg_conv3x3_wino_chain with the buffer pattern of the reference's SRNet made a
+ *              REQUIREMENT: layers[i].x == layers[i-1].y, layers[i].res in {NULL, layers[i-1].x},
+ *              cin == 64 for i > 0, bias non-NULL.  Only layers[0].x / x2 are read and only
+ *              layers[n_layers-1].y is written: the intermediate tensors never reach memory.
+ *   workspace: tg_conv3x3_wino_resident_ws_bytes(h, w) bytes, 256-byte aligned, caller owned, zeroed ONCE
+ *              before the first call; its last 256 bytes hold a fault counter (int32) the caller MUST
+ *              read after synchronising (non-zero: a workgroup gave up waiting for a neighbour; the
+ *              results are then undefined.  The frame plan does this for its own launch).
+ *   epoch:     1, 2, 3, ... strictly increasing per call on one workspace. */
+int tg_conv3x3_wino_resident_supported(int n, int cout, int h, int w);
+int64_t tg_conv3x3_wino_resident_ws_bytes(int h, int w);
+int tg_conv3x3_wino_resident(const tg_wino_layer* layers, int n_layers, int cout, int h, int w,
+                             void* workspace, int epoch, tg_stream_t stream);
+
 /* Dependent 3x3 layers of SMALL frames (the training unroll: 2 x 32 x 32 / 2 x 64 x 64 LR pixels per
  * frame, tecogan_nets.py:174-225) in ONE launch: one persistent workgroup per (image row, 32-pixel
  * segment[, 32-channel half]) walks all the layers and exchanges halo rows with its neighbours

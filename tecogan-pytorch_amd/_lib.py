@@ -124,6 +124,9 @@ SIGNATURES = {
     'tg_conv3x3_wino_packed_floats': (I64, [I, I]),
     'tg_conv3x3_wino_chain_flag_ints': (I64, [I, I, I, I]),
     'tg_conv3x3_wino_chain': (I, [C.POINTER(WinoLayer), I, I, I, I, I, P, I, P]),
+    'tg_conv3x3_wino_resident_supported': (I, [I, I, I, I]),
+    'tg_conv3x3_wino_resident_ws_bytes': (I64, [I, I]),
+    'tg_conv3x3_wino_resident': (I, [C.POINTER(WinoLayer), I, I, I, I, P, I, P]),
     'tg_conv3x3_chain_flag_ints': (I64, [I, I, I, I]),
     'tg_conv3x3_chain_supported': (I, [I, I, I, I]),
     'tg_conv3x3_pack16_floats': (SZ, []),

@@ -33,6 +33,8 @@ struct tg_frnet_plan {
   bool chain_ready;                 // flags zeroed
   unsigned epoch;                   // one per chained launch
   int chain_layers;                 // layers in the chained launch of this plan's shape (0: none)
+  void* RESWS;                      // workspace of the LDS-resident SRNet body launch (exchange buffer + flags)
+  bool res_ready;                   // its flags zeroed
   // fail-safe of the chained launch: fault counter in pinned host memory (the kernel adds to it
   // with system scope), looked at by every later call on the plan
   int32_t* chain_err;               // hipHostMalloc, 64 bytes; null when the allocation failed (chain then off)
@@ -40,8 +42,8 @@ struct tg_frnet_plan {
   int chain_faults;                 // faults reported so far
   int chain_poll_limit;
   int fh, fw, launches;
-  int st_launch[16];
-  double st_flops[16], st_bytes[16];
+  int st_launch[24];
+  double st_flops[24], st_bytes[24];
 };
 
 // phase bits: 1 = FNet (lr_curr, lr_prev -> flow slot), 2 = warp + SRNet (flow slot, hr_prev -> hr_out)
@@ -91,7 +93,7 @@ static size_t fnet_partial_floats(const tg_frnet_cfg* c) {
 }
 
 static const int CHAIN_MAX_LAYERS = 24;
-static void carve(const tg_frnet_cfg* c, size_t off[14]) {
+static void carve(const tg_frnet_cfg* c, size_t off[15]) {
   size_t hw = (size_t)c->h * c->w, n = c->n;
   size_t o = 0;
   const size_t sr = c->fnet_only ? 0 : 1;                      // an FNet-only plan has no SRNet regions
@@ -109,7 +111,12 @@ static void carve(const tg_frnet_cfg* c, size_t off[14]) {
   off[11] = o; o += sr * 2048;                                 // WZ (A operand of the fused output-conv contraction)
   off[12] = o;                                                 // CHAINF (int32 flags: 24 layers x 16-tile workgroups + error counter)
   o += sr * align64((size_t)CHAIN_MAX_LAYERS * n * ((c->h + 1) / 2) * ((c->w + 31) / 32) + 16);
-  off[13] = o;
+  off[13] = o;                                                 // RESWS (tg_conv3x3_wino_res.hip: exchange buffer + flags; n == 1 only)
+  {
+    const int64_t rb = (sr && n == 1) ? tg::conv3x3_wino_resident_ws_bytes(c->h, c->w) : 0;
+    o += align64((size_t)(rb + 3) / 4);
+  }
+  off[14] = o;
 }
 
 static int cfg_ok(const tg_frnet_cfg* c) {
@@ -121,9 +128,9 @@ static int cfg_ok(const tg_frnet_cfg* c) {
 
 extern "C" size_t tg_frnet_workspace_floats(const tg_frnet_cfg* cfg) {
   if (!cfg_ok(cfg)) return 0;
-  size_t off[14];
+  size_t off[15];
   carve(cfg, off);
-  return off[13];
+  return off[14];
 }
 
 extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weights* layers,
@@ -141,9 +148,10 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   TG_REQUIRE(p, TG_E_ARG, "frnet_plan_create: out of host memory");
   p->cfg = *cfg;
   p->L.assign(layers, layers + n_layers);
-  size_t off[14];
+  size_t off[15];
   carve(cfg, off);
   p->WZ = workspace + off[11]; p->wz_ready = false;
+  p->RESWS = workspace + off[13]; p->res_ready = false;
   p->CHAINF = reinterpret_cast<int32_t*>(workspace + off[12]); p->chain_ready = false; p->epoch = 0; p->chain_layers = 0;
   p->chain_err = nullptr; p->chain_disabled = false; p->chain_faults = 0; p->chain_poll_limit = tg::TG_CHAIN_POLL_LIMIT_DEFAULT;
   if (!cfg->fnet_only) {
@@ -162,13 +170,13 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   p->S2D = workspace + off[3]; p->U1 = workspace + off[4];
   p->U2 = cfg->scale == 4 ? workspace + off[5] : nullptr;
   p->fh = cfg->h / 8 * 8; p->fw = cfg->w / 8 * 8;
-  for (int k = 0; k < 16; ++k) { p->st_launch[k] = 0; p->st_flops[k] = 0; p->st_bytes[k] = 0; }
+  for (int k = 0; k < 24; ++k) { p->st_launch[k] = 0; p->st_flops[k] = 0; p->st_bytes[k] = 0; }
   // dry run: per-kernel-class launch counts, algorithmic flops and bytes of one frame
   // (dummy non-null pointers; nothing is dereferenced or launched)
   static float dummy;
   step_impl(p, &dummy, &dummy, &dummy, &dummy, nullptr, nullptr, 0, true);
   p->launches = 0;
-  for (int k = 0; k < 16; ++k) p->launches += p->st_launch[k];
+  for (int k = 0; k < 24; ++k) p->launches += p->st_launch[k];
   p->launches -= p->st_launch[8];  // quantise only runs when a u8 output is requested
   *out = p;
   return TG_OK;
@@ -201,7 +209,8 @@ enum {
   K_CONV_ONESHOT = 13,  // conv3x3_oneshot_kernel: few tiles, cin <= 64, whole K range in flight
   K_CONV_WINO = 14,     // conv3x3_wino_kernel: Winograd F(2x2,3x3) form of the large 64-channel-group layers
   K_WINO_CHAIN = 15,    // conv3x3_wino_chain_kernel: SRNet's conv_in + residual blocks as ONE launch
-  K_COUNT = 16
+  K_WINO_RES = 16,      // conv3x3_wino_resident_kernel: the same layers on persistent, LDS-resident workgroups (one 134x320-class frame)
+  K_COUNT = 17
 };
 
 // The HR stage as two launches instead of three and without the 64-channel HR tensor: the last
@@ -220,6 +229,13 @@ static bool chain_wanted(long long ntile) {
   static const int v = [] { const char* e = getenv("TG_WINO_CHAIN"); return e ? atoi(e) : -1; }();
   if (v >= 0) return v != 0;
   return ntile > 768 && ntile <= 3000;
+}
+// The LDS-resident form (tg_conv3x3_wino_res.hip) whenever the frame fits one 8x24 block per CU and is large
+// enough for the Winograd form to be the per-layer choice (a single 134x320-class frame).  TG_WINO_RES=0
+// selects the per-layer / chained launches, 1 the resident launch wherever it is supported (A/B runs, tests).
+static bool resident_wanted(bool layer_prefers_wino) {
+  static const int v = [] { const char* e = getenv("TG_WINO_RES"); return e ? atoi(e) : -1; }();
+  return v >= 0 ? v != 0 : layer_prefers_wino;     // 1: whenever supported (tests run small frames through it)
 }
 // the fused tail writes (n, H, W, c) uint8 frames for any n; the unfused quantise pass only n == 1
 static bool plan_u8_ok(const tg_frnet_plan* p) {
@@ -362,6 +378,10 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
                chain_wanted((long long)n * tg::cdiv(h, 2) * tg::cdiv(w, 32)) &&
                tg_conv3x3_prefers_wino(n, nf, nf, h, w);
   for (int i = skip; i < 1 + 2 * c.nb && chain; ++i) chain = p->L[li + i].u != nullptr;
+  bool resident = p->chain_err && !p->chain_disabled && n == 1 && nchain >= 2 && nchain <= CHAIN_MAX_LAYERS &&
+                  resident_wanted(tg_conv3x3_prefers_wino(n, nf, nf, h, w) != 0) && (skip || c.in_nc + s2dc <= 64) && tg::conv3x3_wino_resident_ok(n, nf, h, w);
+  for (int i = skip; i < 1 + 2 * c.nb && resident; ++i) resident = p->L[li + i].u != nullptr && p->L[li + i].b != nullptr;
+  if (resident) chain = true;
   if (chain) {
     if (skip)
       conv(lr_curr, c.in_nc * hw, c.in_nc, p->S2D, s2dc * hw, c.in_nc + s2dc, nf, h, w, TG_ACT_RELU,
@@ -390,6 +410,18 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     }
     li += nchain;
     p->chain_layers = nchain;
+    if (resident) {
+      go(K_WINO_RES, fl, by, [&] {
+        if (!p->res_ready) {
+          if (hipMemsetAsync(p->RESWS, 0, (size_t)tg::conv3x3_wino_resident_ws_bytes(h, w), (hipStream_t)st) != hipSuccess)
+            return tg::check_launch("wino_resident workspace memset");
+          p->res_ready = true;
+        }
+        if (++p->epoch == 0) p->epoch = 1;
+        return tg::conv3x3_wino_resident_launch(cl, nchain, nf, h, w, p->RESWS, p->chain_err, p->epoch << 5,
+                                                p->chain_poll_limit, st);
+      });
+    } else
     go(K_WINO_CHAIN, fl, by, [&] {
       if (!p->chain_ready) {
         const size_t ints = (size_t)tg_conv3x3_wino_chain_flag_ints(nchain, n, h, w);
@@ -561,7 +593,7 @@ extern "C" const char* tg_frnet_kind_name(int kind) {
       "maxpool2_kernel",             "upsample_kernel",            "quantize_u8_hwc_kernel",
       "splitk_finalize_kernel",      "conv3x3_mfma_kernel<1,2,1,KS=2>",
       "convt3x3s2_mfma_kernel<Z>",   "convout_tail_kernel",        "conv3x3_oneshot_kernel",
-      "conv3x3_wino_kernel",         "conv3x3_wino_chain_kernel"};
+      "conv3x3_wino_kernel",         "conv3x3_wino_chain_kernel",  "conv3x3_wino_resident_kernel"};
   return (kind >= 0 && kind < K_COUNT) ? names[kind] : "?";
 }
 

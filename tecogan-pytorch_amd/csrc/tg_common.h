@@ -76,6 +76,13 @@ constexpr int TG_CHAIN_POLL_LIMIT_DEFAULT = 1 << 21;
 int conv3x3_wino_chain_launch(const tg_wino_layer* layers, int n_layers, int n, int cout, int h, int w,
                               int32_t* flags, int32_t* err, unsigned epoch, int poll_limit, tg_stream_t stream);
 
+// SRNet's conv_in + residual-block convs of one frame as ONE launch of persistent, LDS-resident workgroups
+// (tg_conv3x3_wino_res.hip): supported shapes, workspace (exchange buffer + flags + 256 bytes), launch
+bool conv3x3_wino_resident_ok(int n, int cout, int h, int w);
+int64_t conv3x3_wino_resident_ws_bytes(int h, int w);
+int conv3x3_wino_resident_launch(const tg_wino_layer* layers, int n_layers, int cout, int h, int w, void* ws,
+                                 int32_t* err, unsigned base, int poll_limit, tg_stream_t stream);
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

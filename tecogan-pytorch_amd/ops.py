@@ -1054,3 +1054,27 @@ class WinoChain:
 
     def bailouts(self):
         return int(self.flags[-16].item())
+
+
+class WinoResident(WinoChain):
+    """tg_conv3x3_wino_resident: the same dependent layers of ONE frame on persistent, LDS-resident
+    workgroups (tg_conv3x3_wino_res.hip).  Only layers[0]['x'] / ['x2'] are read and only
+    layers[-1]['y'] is written."""
+
+    def __init__(self, layers, cout, h, w):
+        WinoChain.__init__(self, layers, 1, cout, h, w)
+        nbytes = L.lib().tg_conv3x3_wino_resident_ws_bytes(h, w)
+        self.ws = torch.zeros(nbytes // 4, dtype=torch.int32, device=layers[0]['x'].device)
+
+    @staticmethod
+    def supported(cout, h, w, n=1):
+        return bool(L.lib().tg_conv3x3_wino_resident_supported(n, cout, h, w))
+
+    def run(self):
+        self.epoch += 1
+        L.check(L.lib().tg_conv3x3_wino_resident(self.arr, len(self.keep), self.cout, self.h, self.w,
+                                                 self.ws.data_ptr(), self.epoch, _stream()),
+                'tg_conv3x3_wino_resident')
+
+    def bailouts(self):
+        return int(self.ws[-64].item())

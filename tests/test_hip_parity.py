@@ -256,6 +256,72 @@ def test_winograd_chained_launch_equals_separate_launches(ops, n, h, w):
     assert chain.bailouts() == 0
 
 
+@pytest.mark.parametrize('h,w,nb,first', [(134, 320, 10, 'dual'), (26, 70, 4, 'dual'), (30, 50, 3, 'dual'), (8, 24, 2, 'dual'),
+                                          (2, 2, 2, 'single'), (64, 96, 3, 'single'), (134, 320, 2, 'narrow')])
+def test_winograd_resident_launch_equals_separate_launches(ops, h, w, nb, first):
+    """tg_conv3x3_wino_resident (round 4): SRNet's conv_in + residual blocks of ONE frame on persistent,
+    LDS-resident workgroups (8 x 24 pixel blocks, ring exchange through global memory, monotonic flags)
+    must reproduce the per-layer Winograd launches BIT FOR BIT, launch after launch -- full blocks,
+    partial blocks at the right / bottom border, a single block, the two-source 51-channel first
+    layer, a 64-channel first layer read from global memory (the 2x plan's form) and a 15-channel one
+    (4 K steps instead of 16)."""
+    if not ops.WinoResident.supported(64, h, w):
+        pytest.skip('frame does not fit one block per CU on this device')
+    g = torch.Generator().manual_seed(23)
+    cin0 = {'dual': 51, 'single': 64, 'narrow': 15}[first]
+    c1 = {'dual': 3, 'single': 64, 'narrow': 3}[first]
+    lr = dev(torch.rand(1, c1, h, w, generator=g))
+    s2d = dev(torch.rand(1, cin0 - c1, h, w, generator=g)) if cin0 > c1 else None
+    ws = [dev(torch.randn(64, cin0, 3, 3, generator=g) * 0.04)] + \
+         [dev(torch.randn(64, 64, 3, 3, generator=g) * 0.03) for _ in range(2 * nb)]
+    bs = [dev(torch.randn(64, generator=g) * 0.1) for _ in range(2 * nb + 1)]
+    us = [ops.pack_conv3x3_wino(x) for x in ws]
+
+    def make(A, B):
+        layers = [dict(x=lr, x2=s2d, u=us[0], bias=bs[0], cin=cin0, act=1, y=A)]
+        for b in range(nb):
+            layers.append(dict(x=A, u=us[1 + 2 * b], bias=bs[1 + 2 * b], cin=64, act=1, y=B))
+            layers.append(dict(x=B, u=us[2 + 2 * b], bias=bs[2 + 2 * b], cin=64, act=0, res=A, y=A))
+        return layers
+    A1, B1, A2, B2 = (torch.empty(1, 64, h, w, device='cuda') for _ in range(4))
+    seq, res = make(A1, B1), ops.WinoResident(make(A2, B2), 64, h, w)
+    for it in range(8):
+        lr.uniform_(-1, 1)
+        if s2d is not None:
+            s2d.uniform_(-1, 1)
+        A2.fill_(float('nan'))                   # the launch must write every pixel of its output
+        for d in seq:
+            ops.conv3x3_wino(d['x'], d['u'], d['bias'], d['cin'], 64, d['act'], x2=d.get('x2'), res=d.get('res'),
+                             out=d['y'])
+        res.run()
+        torch.cuda.synchronize()
+        assert res.bailouts() == 0
+        assert torch.equal(A1, A2), (it, (A1 - A2).abs().max().item(), int((A1 != A2).sum()))
+
+
+def test_winograd_resident_rejects_foreign_buffer_patterns(ops):
+    """The resident launch keeps the intermediate tensors in LDS, so it insists on the chain pattern of
+    the reference's SRNet (tecogan_nets.py:85-100): anything else is refused, not silently mis-computed."""
+    from tecogan_pytorch_amd import _lib
+    h, w = 16, 48
+    if not ops.WinoResident.supported(64, h, w):
+        pytest.skip('not supported on this device')
+    x, A, B, C = (torch.zeros(1, 64, h, w, device='cuda') for _ in range(4))
+    u = ops.pack_conv3x3_wino(torch.zeros(64, 64, 3, 3, device='cuda'))
+    b = torch.zeros(64, device='cuda')
+    ok = [dict(x=x, u=u, bias=b, cin=64, act=1, y=A), dict(x=A, u=u, bias=b, cin=64, act=0, res=x, y=B)]
+    ops.WinoResident(ok, 64, h, w).run()
+    bad_dep = [dict(x=x, u=u, bias=b, cin=64, act=1, y=A), dict(x=C, u=u, bias=b, cin=64, act=0, y=B)]
+    bad_res = [dict(x=x, u=u, bias=b, cin=64, act=1, y=A), dict(x=A, u=u, bias=b, cin=64, act=0, res=C, y=B)]
+    no_bias = [dict(x=x, u=u, cin=64, act=1, y=A)]
+    for layers in (bad_dep, bad_res, no_bias):
+        with pytest.raises(_lib.TecoganHipError):
+            ops.WinoResident(layers, 64, h, w).run()
+    assert not ops.WinoResident.supported(64, 15, 48) and not ops.WinoResident.supported(32, 16, 48)
+    assert not ops.WinoResident.supported(64, 16, 48, n=2) and not ops.WinoResident.supported(64, 268, 640)
+    torch.cuda.synchronize()
+
+
 def test_winograd_chain_numerics_at_trained_activation_scale(ops):
     """SRNet's 20 residual-block layers at the activation magnitudes of a TRAINED model (|x| grows
     from ~10^2 to ~10^3 along the residual chain; the procedural parity weights stay O(1)): the
@@ -292,6 +358,18 @@ def test_winograd_chain_numerics_at_trained_activation_scale(ops):
     chain.run()
     torch.cuda.synchronize()
     assert chain.bailouts() == 0
+    A3, B3 = dev(x).clone(), torch.empty(1, nf, h, w, device='cuda')
+    bz = torch.zeros(nf, device='cuda')
+    layers3 = []
+    for b in range(nb):
+        layers3.append(dict(x=A3, u=us[2 * b], bias=bz, cin=nf, act=1, y=B3))
+        layers3.append(dict(x=B3, u=us[2 * b + 1], bias=bz, cin=nf, act=0, res=A3, y=A3))
+    if ops.WinoResident.supported(nf, h, w):
+        resident = ops.WinoResident(layers3, nf, h, w)
+        resident.run()
+        torch.cuda.synchronize()
+        assert resident.bailouts() == 0
+        assert torch.equal(wino, A3)                              # resident launch == separate launches
     e = {k: (v.double().cpu() - ref).abs() for k, v in (('direct', direct), ('wino', wino), ('chain', A))}
     scale = ref.abs().max().item()
     for k in e:
@@ -323,6 +401,84 @@ def test_plan_with_chained_srnet_launch(tmp_path):
         subprocess.run([sys.executable, '-c', script, out], check=True, env=env, timeout=600)
         outs.append(torch.load(out))
     assert outs[0].shape == outs[1].shape and torch.equal(outs[0], outs[1])
+
+
+def test_plan_with_resident_srnet_launch(tmp_path):
+    """The frame plan with SRNet's body as the LDS-resident launch (the default for one 134x320-class frame)
+    against the plan with one launch per layer (TG_WINO_RES=0): bit-identical uint8 AND fp32 frames of a
+    recurrent clip, serial and pipelined, and the plan statistics name the class.  (The switch is read
+    once per process: two subprocesses.)"""
+    import subprocess
+    import sys
+    script = (
+        "import sys, ctypes, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from tests.test_hip_parity import make_net, smooth_clip\n"
+        "from tecogan_pytorch_amd import _lib\n"
+        "net, _ = make_net('BD', 4)\n"
+        "dev = torch.device('cuda', 0)\n"
+        "x = smooth_clip(7, 3, 70, 120, seed=5).cuda()\n"
+        "y0 = net.infer_sequence(x, dev, return_device_tensor=True, pipeline=False)\n"
+        "y1 = net.infer_sequence(x, dev, return_device_tensor=True, pipeline=True)\n"
+        "z = torch.rand(1, 3, 280, 480, device='cuda')\n"
+        "f = net.step(x[1:2], x[0:1], z)\n"
+        "torch.cuda.synchronize(); net.check_faults()\n"
+        "plan = net._get_plan(1, 70, 120, dev)\n"
+        "lib = _lib.lib()\n"
+        "names = [lib.tg_frnet_kind_name(k).decode() for k in range(lib.tg_frnet_plan_kinds())]\n"
+        "nl = ctypes.c_int()\n"
+        "_lib.check(lib.tg_frnet_plan_kind_stats(plan.handle, names.index('conv3x3_wino_resident_kernel'), ctypes.byref(nl), None, None), 'ks')\n"
+        "torch.save(dict(y0=y0.cpu(), y1=y1.cpu(), f=f.cpu(), resident=nl.value, state=plan.chain_state()), sys.argv[1])\n"
+        % (ROOT_DIR, GOLDEN_DIR))
+    outs = []
+    for flag in ('0', '1'):
+        env = dict(os.environ, TG_WINO_RES=flag, TG_CONV_WINO='1')
+        out = str(tmp_path / ('y%s.pt' % flag))
+        subprocess.run([sys.executable, '-c', script, out], check=True, env=env, timeout=600)
+        outs.append(torch.load(out))
+    assert outs[0]['resident'] == 0 and outs[1]['resident'] == 1, (outs[0]['resident'], outs[1]['resident'])
+    assert outs[1]['state'] == (0, True), outs[1]['state']
+    for k in ('y0', 'y1', 'f'):
+        assert outs[0][k].shape == outs[1][k].shape and torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_resident_launch_fault_surfaces_and_falls_back(tmp_path):
+    """Fail-safe of the LDS-resident SRNet launch: with fault injection (negative poll limit) the error
+    surfaces on the host-output path / on the next call, the plan then runs one launch per layer and
+    reproduces a never-resident run bit for bit."""
+    import subprocess
+    import sys
+    script = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from tests.test_hip_parity import make_net, smooth_clip\n"
+        "from tecogan_pytorch_amd import _lib\n"
+        "E = _lib.TecoganHipError\n"
+        "dev = torch.device('cuda', 0)\n"
+        "x = smooth_clip(5, 3, 40, 72, seed=5).cuda()\n"
+        "def fresh(inject):\n"
+        "    net, _ = make_net('BD', 4)\n"
+        "    plan = net._get_plan(1, 40, 72, dev)\n"
+        "    assert plan.chain_state() == (0, True), plan.chain_state()\n"
+        "    if inject: _lib.check(_lib.lib().tg_frnet_plan_set_chain_poll_limit(plan.handle, -1), 'limit')\n"
+        "    return net, plan\n"
+        "def raises(fn):\n"
+        "    try: fn()\n"
+        "    except E as e: return 'timed out' in str(e)\n"
+        "    return False\n"
+        "ref_net, _ = fresh(False)\n"
+        "ref = ref_net.infer_sequence(x, dev)\n"
+        "net, plan = fresh(True)\n"
+        "assert raises(lambda: net.infer_sequence(x, dev)), 'no error on the host-output path'\n"
+        "torch.cuda.synchronize()\n"
+        "f, active = plan.chain_state(); assert f > 0 and not active, (f, active)\n"
+        "assert np.array_equal(net.infer_sequence(x, dev), ref), 'fallback differs'\n"
+        "net, plan = fresh(True)\n"
+        "y = net.infer_sequence(x[:1], dev, return_device_tensor=True); torch.cuda.synchronize()\n"
+        "assert raises(lambda: net.infer_sequence(x[:1], dev, return_device_tensor=True)), 'next call silent'\n"
+        "print('FAILSAFE-OK')\n" % (ROOT_DIR, GOLDEN_DIR))
+    env = dict(os.environ, TG_WINO_RES='1', TG_CONV_WINO='1')
+    r = subprocess.run([sys.executable, '-c', script], env=env, timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0 and 'FAILSAFE-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_chained_launch_fault_surfaces_on_every_path(tmp_path):
@@ -405,10 +561,15 @@ def test_winograd_rule_and_plan_use(ops):
                                             None, None), 'kind_stats')
     _lib.check(lib.tg_frnet_plan_kind_stats(plan.handle, names.index('conv3x3_wino_chain_kernel'),
                                             ctypes.byref(nc), None, None), 'kind_stats')
-    # SRNet conv_in + 10 residual blocks (21 launches, or one chained launch under TG_WINO_CHAIN=1) and
-    # FNet's four 67x160 layers
+    nr = ctypes.c_int()
+    _lib.check(lib.tg_frnet_plan_kind_stats(plan.handle, names.index('conv3x3_wino_resident_kernel'),
+                                            ctypes.byref(nr), None, None), 'kind_stats')
+    # SRNet conv_in + 10 residual blocks (21 launches, or one chained launch under TG_WINO_CHAIN=1, or --
+    # the default for one 134x320 frame since round 4 -- one LDS-resident launch) and FNet's four 67x160 layers
     if 'TG_CONV_WINO' not in os.environ:        # (a forced rule changes the mix)
-        assert nl.value + 21 * nc.value == 25 and nc.value in (0, 1)
+        assert nl.value + 21 * (nc.value + nr.value) == 25 and nc.value + nr.value in (0, 1)
+        if 'TG_WINO_RES' not in os.environ and 'TG_WINO_CHAIN' not in os.environ:
+            assert nr.value == 1
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,ks,pool', [
