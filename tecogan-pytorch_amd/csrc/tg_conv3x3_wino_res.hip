@@ -29,6 +29,11 @@
 
 #include "tg_common.h"
 
+#ifndef TG_WRES_LAB
+#define TG_WRES_LAB 0   // 1: ablation switches (env TG_WRES_ABL) compiled in -- tools/build_lab_libs.sh, timing only
+#endif
+#define RABL(bit) (TG_WRES_LAB && (a.abl & (bit)))
+
 namespace tg {
 
 constexpr int WR_TH = 4, WR_TW = 12;             // Winograd tiles per block
@@ -44,6 +49,14 @@ constexpr int WR_SC1 = 16;                        // agent-scope cache policy bi
 constexpr size_t WR_LDS_BYTES = (size_t)2 * WR_NC * WR_CS * sizeof(float);   // 147 456
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#if TG_WRES_LAB
+// lab: s_memtime stamps of every wave of workgroup 100, 8 per layer (tools/wino_res_lab.py --stamps)
+__device__ long long g_wres_dbg[12 * 24 * 8];
+#define RSTAMP(k) do { if (blockIdx.x == 100 && l == 0) g_wres_dbg[(wv * 24 + L) * 8 + (k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RSTAMP(k) do { } while (0)
+#endif
 
 struct WResLayer {
   const float* u;      // tg_pack_conv3x3_wino form
@@ -64,6 +77,7 @@ struct WResArgs {
   unsigned base;       // flag value before this launch's first layer
   int poll_limit;
   int nlayer, h, w, nbx, nby, c1, cin0;
+  int abl;             // lab builds only: 1 no flag wait / ring loads, 2 no MFMA, 4 no weight loads, 8 no ring stores, 16 no window reads, 32 no hand-over at all
 };
 
 __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WResArgs a) {
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
   const size_t ulane = (size_t)(q * 4) * 64 + l;               // this lane's 16 bytes inside a K step's block
   constexpr size_t USTEP = (size_t)4 * 4 * 64;                  // f32x4 per K step (64 output channels)
   auto load_u = [&](const f32x4* ub, int ks, int nks, f32x4 (&u)[4]) {
-    if (ks >= nks) return;
+    if (ks >= nks || (RABL(4) && ks > 1)) return;
     const f32x4* p = ub + (size_t)ks * USTEP;
     u[0] = p[0]; u[1] = p[64]; u[2] = p[128]; u[3] = p[192];
   };
@@ -154,13 +168,17 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
     const f32x4* ub = reinterpret_cast<const f32x4*>(lay.u) + ulane;
     const int nks = lay.nks;
 
+    RSTAMP(0);
     f32x4 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one K step: window of channel 4 ks + kk -> B^T d B in registers -> 16 MFMAs
+    // one K step: window of channel 4 ks + kk -> B^T d B in registers -> 16 MFMAs.  (fp32 MFMAs and VALU
+    // instructions of the waves of a SIMD do NOT overlap on gfx950 -- tools/valu_lab.hip: 16 MFMAs + 32
+    // adds take exactly the sum of both -- so the order inside a step matters little; a burst form with
+    // the next window prefetched measured slower: 24.4 vs 21.5 us per layer, it costs registers.)
     auto kstep = [&](int ks, const f32x4 (&u)[4]) {
-      const float* sp = src + rb + ks * (4 * WR_CS);
+      const float* sp = src + rb + (RABL(16) ? 0 : ks * (4 * WR_CS));
       float d[4][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -180,6 +198,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
         bq[2] = f32x4{qa[0] - qa[2], qa[1] + qa[2], qa[2] - qa[1], qa[1] - qa[3]};
         bq[3] = f32x4{qb[0] - qb[2], qb[1] + qb[2], qb[2] - qb[1], qb[1] - qb[3]};
       }
+      if (RABL(2)) { acc[0] += bq[0] + bq[1] + bq[2] + bq[3] + u[0] + u[1] + u[2] + u[3]; return; }
 #pragma unroll
       for (int p = 0; p < 16; ++p)
         acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[p >> 2][p & 3], bq[p >> 2][p & 3], acc[p], 0, 0, 0);
@@ -193,6 +212,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
       __builtin_amdgcn_sched_barrier(0);
       load_u(ub, ks + 3, nks, u1);
     }
+    RSTAMP(1);
     // ---- inverse transform A^T m A, bias / activation / residual -----------------------------
     const bool last = L + 1 == a.nlayer;
     const float slope = act_slope(lay.act);
@@ -252,6 +272,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
         auto pub = [&](int slot, int i, int j) {
           const u32x4 dd = {__builtin_bit_cast(unsigned, v[0][i][j]), __builtin_bit_cast(unsigned, v[1][i][j]),
                             __builtin_bit_cast(unsigned, v[2][i][j]), __builtin_bit_cast(unsigned, v[3][i][j])};
+          if (RABL(8) && dd[0] != 0x12345678u) return;
           __builtin_amdgcn_raw_buffer_store_b128(dd, rxb, (int)(pb + (unsigned)slot * (WR_NC * 4u)), 0, WR_SC1);
         };
         if (e_top) { pub(2 * tx, 0, 0); pub(2 * tx + 1, 0, 1); }
@@ -260,14 +281,18 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
         if (e_rgt) { pub(2 * WR_BW + WR_BH + 2 * ty, 0, 1); pub(2 * WR_BW + WR_BH + 2 * ty + 1, 1, 1); }
       }
     }
+    RSTAMP(2);
     if (last) break;
+    if (RABL(32)) { __syncthreads(); continue; }
 
     // ---- hand-over: ring stores acknowledged (every wave), flag, neighbours' flags, their rings ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RSTAMP(3);
     __syncthreads();                          // also: every read of src and every write of dst of this layer is done
+    RSTAMP(4);
     const unsigned target = a.base + (unsigned)(L + 1);
     if (t == 0) __hip_atomic_store(a.flags + wg, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t >= 64 && t < 72) {
+    if (t >= 64 && t < 72 && !RABL(1)) {
       const int d8 = t - 64, dd = d8 + (d8 >= 4);          // 0..8 without the centre
       const int ny = by - 1 + dd / 3, nx = bx - 1 + dd % 3;
       if (ny >= 0 && ny < a.nby && nx >= 0 && nx < a.nbx) {
@@ -282,6 +307,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
       }
     }
     __syncthreads();
+    RSTAMP(5);
     // ring of dst: 68 pixels x 16 channel quads, one 16-byte agent-scope load each
     {
       constexpr int NRING = 2 * (WR_BW + 2) + 2 * WR_BH;           // 68
@@ -303,7 +329,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
         const int gy = Y0 - 1 + ry, gx = X0 - 1 + rx;
         ho[k] = -1;
         hv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (item < ITEMS && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w) {
+        if (item < ITEMS && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && !RABL(1)) {
           const int sby = gy / WR_BH, sbx = gx / WR_BW;
           const int ly = gy - sby * WR_BH, lx = gx - sbx * WR_BW;
           // which of the owner's published rows / columns holds the pixel
@@ -320,7 +346,9 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
           for (int e = 0; e < 4; ++e) dst[ho[k] + e * WR_CS] = hv[k][e];
         }
     }
+    RSTAMP(6);
     __syncthreads();
+    RSTAMP(7);
   }
 }
 
@@ -391,6 +419,9 @@ int conv3x3_wino_resident_launch(const tg_wino_layer* layers, int n_layers, int 
   a.xbuf = static_cast<float*>(ws);
   a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + 2 * nb * WR_SLOTS * WR_NC * 4);
   a.err = err; a.base = base; a.poll_limit = poll_limit;
+#if TG_WRES_LAB
+  { static const int abl = [] { const char* e = getenv("TG_WRES_ABL"); return e ? atoi(e) : 0; }(); a.abl = abl; }
+#endif
   hipLaunchKernelGGL(conv3x3_wino_resident_kernel, dim3((unsigned)nb), dim3(WR_THREADS), WR_LDS_BYTES,
                      (hipStream_t)stream, a);
   return check_launch("conv3x3_wino_resident");
@@ -399,6 +430,12 @@ int conv3x3_wino_resident_launch(const tg_wino_layer* layers, int n_layers, int 
 }  // namespace tg
 
 using namespace tg;
+
+#if TG_WRES_LAB
+extern "C" int tg_lab_wres_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wres_dbg), sizeof(long long) * 12 * 24 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int tg_conv3x3_wino_resident_supported(int n, int cout, int h, int w) {
   return conv3x3_wino_resident_ok(n, cout, h, w) ? 1 : 0;

@@ -24,3 +24,7 @@ OBJS=$(ls tg_*.o | grep -v tg_conv3x3_wino.o)
 mkdir -p $OUT/lab_objs
 for f in tg_*.hip; do /opt/rocm/bin/hipcc $FLAGS -DTG_LAB=1 -c $f -o $OUT/lab_objs/${f%.hip}.o & done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libtecogan_lab.so $OUT/lab_objs/*.o -ldl
+# LDS-resident SRNet body with its ablation switches (TG_WRES_ABL): TECOGAN_HIP_LIB=tools/_lab_libs/libtecogan_wres_lab.so
+/opt/rocm/bin/hipcc $FLAGS -DTG_WRES_LAB=1 -c tg_conv3x3_wino_res.hip -o $OUT/tg_conv3x3_wino_res_lab.o
+OBJS=$(ls tg_*.o | grep -v tg_conv3x3_wino_res.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libtecogan_wres_lab.so $OBJS $OUT/tg_conv3x3_wino_res_lab.o -ldl

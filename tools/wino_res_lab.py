@@ -62,6 +62,24 @@ def main():
         print('per-layer launches: %.1f us (%.2f us/layer)   resident: %.1f us (%.2f us/layer)   ratio %.3f'
               % (t_seq, t_seq / nl, t_res, t_res / nl, t_res / t_seq))
     print('bailouts', res.bailouts())
+    if '--stamps' in sys.argv or os.environ.get('WRES_STAMPS'):
+        import ctypes
+        import numpy as np
+        from tecogan_pytorch_amd import _lib
+        lib = ctypes.CDLL(_lib.LIB_PATH)
+        buf = (ctypes.c_longlong * (12 * 24 * 8))()
+        res.run(); torch.cuda.synchronize()
+        assert lib.tg_lab_wres_stamps(buf) == 0
+        st = np.array(buf, dtype=np.int64).reshape(12, 24, 8)
+        names = ['K loop', 'epilogue+publish', 'vmcnt(0)', 'barrier 1', 'flag+poll+barrier 2', 'ring loads', 'barrier 3']
+        for wv in (0, 1, 5, 8, 11):
+            for L in (3, 4, 9, 10):
+                d = np.diff(st[wv, L])
+                nxt = st[wv, L + 1, 0] - st[wv, L, 0]
+                print('wave %2d layer %2d: ' % (wv, L) + '  '.join('%s %d' % (n, v) for n, v in zip(names, d)) + '  | layer period %d ticks' % nxt)
+        t0 = st[:, 4, 0].min()
+        print('layer 4 start skew over waves (ticks):', (st[:, 4, 0] - t0).tolist())
+        print('layer 4 K-loop end (ticks after first start):', (st[:, 4, 1] - t0).tolist())
 
 
 if __name__ == '__main__':
