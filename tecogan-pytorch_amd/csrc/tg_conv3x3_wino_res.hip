@@ -46,7 +46,19 @@ constexpr int WR_THREADS = 768;                   // 12 waves: 3 per SIMD
 constexpr int WR_MAXL = 24;
 constexpr int WR_SLOTS = 64;                      // published ring pixels of a block: top 24, bottom 24, left 8, right 8
 constexpr int WR_SC1 = 16;                        // agent-scope cache policy bit of the buffer instructions
-constexpr size_t WR_LDS_BYTES = (size_t)2 * WR_NC * WR_CS * sizeof(float);   // 147 456
+constexpr int WR_ACT_FLOATS = 2 * WR_NC * WR_CS;   // the two activation buffers: 147 456 bytes
+constexpr int WR_BIAS_OFF = WR_ACT_FLOATS;          // [layer][64] biases (read once per launch)
+constexpr int WR_SYNC_OFF = WR_BIAS_OFF + WR_MAXL * WR_NC;   // 16 bytes: arrival counter of the boundary waves
+constexpr size_t WR_LDS_BYTES = (size_t)(WR_SYNC_OFF + 4) * sizeof(float);   // 153 616 of 163 840
+
+// Tile (ty * 12 + tx) of lane n = 0..15 of group g.  Group 2 holds INTERIOR tiles only (rows 1-2, columns
+// 1..10: their 4x4 windows never touch the ring), so its four waves start the next layer right behind the
+// workgroup barrier while the waves of groups 0 and 1 wait for the neighbours' rings.  Chosen (brute force)
+// so that the 32 lanes of a ds_read_b64 group hit distinct bank pairs but for four two-way collisions.
+__constant__ unsigned char WR_TILE[48] = {
+    0, 1, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 24, 39,
+    2, 8, 16, 23, 35, 36, 37, 38, 40, 41, 42, 43, 44, 45, 46, 47,
+    17, 18, 19, 20, 21, 22, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34};
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -71,10 +83,9 @@ struct WResArgs {
   const float* x;      // first layer's input, channels [0, c1)
   const float* x2;     // channels [c1, cin0) or null
   float* y;            // last layer's output (64 x h x w)
-  float* xbuf;         // exchange: [parity 2][block][slot 64][channel 64]
-  unsigned* flags;     // [block], monotonic: base + layers finished
+  float* xbuf;         // exchange: [parity 2][block][slot 64][channel pair 32]{value, tag, value, tag}
   int* err;            // fault counter (pinned host memory or device memory)
-  unsigned base;       // flag value before this launch's first layer
+  unsigned base;       // tag of layer l of this launch = base + l + 1 (strictly increasing over launches)
   int poll_limit;
   int nlayer, h, w, nbx, nby, c1, cin0;
   int abl;             // lab builds only: 1 no flag wait / ring loads, 2 no MFMA, 4 no weight loads, 8 no ring stores, 16 no window reads, 32 no hand-over at all
@@ -95,8 +106,11 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
   // ---- zero both buffers (rings at the image border and pixels outside the image stay 0) ----
   {
     f32x4* z = reinterpret_cast<f32x4*>(s_act);
-    for (int i = t; i < 2 * WR_NC * WR_CS / 4; i += WR_THREADS) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = t; i < WR_ACT_FLOATS / 4; i += WR_THREADS) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = t; i < a.nlayer * WR_NC; i += WR_THREADS) s_act[WR_BIAS_OFF + i] = a.L[i >> 6].bias[i & 63];
+    if (t == 0) *reinterpret_cast<unsigned*>(s_act + WR_SYNC_OFF) = 0u;
   }
+  unsigned* const s_cnt = reinterpret_cast<unsigned*>(s_act + WR_SYNC_OFF);
   __syncthreads();
   // ---- first layer's input block (+ ring) from global memory into buffer 0 ---------------
   // (bounds-checked buffer loads: zero padding, and the channels of the other source tensor, read 0;
@@ -134,8 +148,9 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
   __syncthreads();
 
   // ---- per-lane geometry ---------------------------------------------------------------------
-  const int T = 16 * g + (l & 15);            // tile of the block: row-major 4 x 12
+  const int T = WR_TILE[16 * g + (l & 15)];   // tile of the block (row-major 4 x 12)
   const int ty = T / WR_TW, tx = T - ty * WR_TW;
+  const bool interior = g == 2;               // wave-uniform
   const int kk = l >> 4;                      // K index inside a K step (B operand) / output-channel quad (D)
   const int rb = kk * WR_CS + (2 * ty) * WR_RS + 2 * tx;        // window origin in the resident block (floats)
   const int oc_base = 16 * q + 4 * kk;
@@ -144,7 +159,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
   const bool live = gy0 < a.h && gx0 < a.w;                     // h, w even: a tile is inside or outside as a whole
   const bool e_top = ty == 0, e_bot = ty == WR_TH - 1, e_lft = tx == 0, e_rgt = tx == WR_TW - 1;
   const __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc(
-      a.xbuf, 0, (unsigned)(2u * nwg * WR_SLOTS * WR_NC * 4u), 0x00020000);
+      a.xbuf, 0, (unsigned)(2u * nwg * WR_SLOTS * WR_NC * 8u), 0x00020000);
 
   const size_t ulane = (size_t)(q * 4) * 64 + l;               // this lane's 16 bytes inside a K step's block
   constexpr size_t USTEP = (size_t)4 * 4 * 64;                  // f32x4 per K step (64 output channels)
@@ -218,7 +233,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
     const float slope = act_slope(lay.act);
     float bz[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bz[r] = lay.bias[oc_base + r];
+    for (int r = 0; r < 4; ++r) bz[r] = s_act[WR_BIAS_OFF + L * WR_NC + oc_base + r];
     float v[4][2][2];                         // [channel r][row i][column j]
     auto epilogue = [&](auto has_res) {
       constexpr bool RES = decltype(has_res)::value;
@@ -267,13 +282,19 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
             dst[wb + r * WR_CS + i * WR_RS] = v[r][i][0];
             dst[wb + r * WR_CS + i * WR_RS + 1] = v[r][i][1];
           }
-        // publish the block's outermost pixels: slot pixel-major, 4 consecutive channels = one 16-byte store
-        const unsigned pb = ((unsigned)((L & 1) * nwg + wg) * WR_SLOTS * WR_NC + oc_base) * 4u;
+        // publish the block's outermost pixels as SELF-VALIDATING granules: {value, tag} pairs, two pairs
+        // (channels c, c + 1) per 16-byte agent-scope store; tag = base + layer + 1 is unique per launch and
+        // layer, so the reader needs no flag and the writer no acknowledgement (RCCL's LL idea; a 16-byte
+        // sc1 store is observed untorn on gfx950).  Slot pixel-major: [slot 64][channel pair 32][4 dwords].
+        const unsigned tag = a.base + (unsigned)(L + 1);
+        const unsigned pb = ((unsigned)((L & 1) * nwg + wg) * WR_SLOTS * (WR_NC / 2) + (unsigned)(oc_base >> 1)) * 16u;
         auto pub = [&](int slot, int i, int j) {
-          const u32x4 dd = {__builtin_bit_cast(unsigned, v[0][i][j]), __builtin_bit_cast(unsigned, v[1][i][j]),
-                            __builtin_bit_cast(unsigned, v[2][i][j]), __builtin_bit_cast(unsigned, v[3][i][j])};
-          if (RABL(8) && dd[0] != 0x12345678u) return;
-          __builtin_amdgcn_raw_buffer_store_b128(dd, rxb, (int)(pb + (unsigned)slot * (WR_NC * 4u)), 0, WR_SC1);
+          if (RABL(8)) return;
+          const u32x4 d0 = {__builtin_bit_cast(unsigned, v[0][i][j]), tag, __builtin_bit_cast(unsigned, v[1][i][j]), tag};
+          const u32x4 d1 = {__builtin_bit_cast(unsigned, v[2][i][j]), tag, __builtin_bit_cast(unsigned, v[3][i][j]), tag};
+          const unsigned o = pb + (unsigned)slot * (WR_NC / 2 * 16u);
+          __builtin_amdgcn_raw_buffer_store_b128(d0, rxb, (int)o, 0, WR_SC1);
+          __builtin_amdgcn_raw_buffer_store_b128(d1, rxb, (int)(o + 16u), 0, WR_SC1);
         };
         if (e_top) { pub(2 * tx, 0, 0); pub(2 * tx + 1, 0, 1); }
         if (e_bot) { pub(WR_BW + 2 * tx, 1, 0); pub(WR_BW + 2 * tx + 1, 1, 1); }
@@ -285,69 +306,86 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
     if (last) break;
     if (RABL(32)) { __syncthreads(); continue; }
 
-    // ---- hand-over: ring stores acknowledged (every wave), flag, neighbours' flags, their rings ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- hand-over -------------------------------------------------------------------------------
+    // Every wave: the workgroup barrier (all of dst's own pixels are written, all reads of src are
+    // done).  The four INTERIOR waves go straight on to the next layer: their windows never touch the
+    // ring.  The eight BOUNDARY waves fetch the ring -- 68 pixels x 32 channel pairs, one 16-byte
+    // agent-scope load per item, re-issued until both tags of the item carry this layer's value --
+    // store it into dst and meet at an LDS arrival counter, while the interior waves already keep the
+    // matrix pipe busy.
     RSTAMP(3);
-    __syncthreads();                          // also: every read of src and every write of dst of this layer is done
-    RSTAMP(4);
-    const unsigned target = a.base + (unsigned)(L + 1);
-    if (t == 0) __hip_atomic_store(a.flags + wg, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t >= 64 && t < 72 && !RABL(1)) {
-      const int d8 = t - 64, dd = d8 + (d8 >= 4);          // 0..8 without the centre
-      const int ny = by - 1 + dd / 3, nx = bx - 1 + dd % 3;
-      if (ny >= 0 && ny < a.nby && nx >= 0 && nx < a.nbx) {
-        const unsigned* f = a.flags + ny * a.nbx + nx;
-        int polls = 0;
-        bool fault = a.poll_limit < 0;
-        while (!fault && (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-          __builtin_amdgcn_s_sleep(2);
-          fault = ++polls > a.poll_limit;
-        }
-        if (fault) __hip_atomic_fetch_add(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
     __syncthreads();
-    RSTAMP(5);
-    // ring of dst: 68 pixels x 16 channel quads, one 16-byte agent-scope load each
+    RSTAMP(4);
+    if (interior) continue;
     {
       constexpr int NRING = 2 * (WR_BW + 2) + 2 * WR_BH;           // 68
-      constexpr int ITEMS = NRING * (WR_NC / 4);                   // 1088
-      constexpr int PER_T = (ITEMS + WR_THREADS - 1) / WR_THREADS; // 2
-      f32x4 hv[PER_T];
+      constexpr int ITEMS = NRING * (WR_NC / 2);                   // 2176
+      constexpr int NBT = 512;
+      constexpr int PER_T = (ITEMS + NBT - 1) / NBT;               // 5 (4.25 on average)
+      const unsigned target = a.base + (unsigned)(L + 1);
+      unsigned off[PER_T];
       int ho[PER_T];
+      unsigned pend = 0;
       int tt = t;
       asm volatile("" : "+v"(tt));            // keeps this geometry out of the K loop's register budget (it would be hoisted and spilled)
 #pragma unroll
       for (int k = 0; k < PER_T; ++k) {
-        const int item = tt + k * WR_THREADS;
-        const int pi = item >> 4, c4 = item & 15;
+        const int item = tt + k * NBT;
+        const int pi = item >> 5, c2 = item & 31;
         int ry, rx;
         if (pi < WR_BW + 2) { ry = 0; rx = pi; }
         else if (pi < 2 * (WR_BW + 2)) { ry = WR_BH + 1; rx = pi - (WR_BW + 2); }
         else if (pi < 2 * (WR_BW + 2) + WR_BH) { ry = pi - 2 * (WR_BW + 2) + 1; rx = 0; }
         else { ry = pi - 2 * (WR_BW + 2) - WR_BH + 1; rx = WR_BW + 1; }
         const int gy = Y0 - 1 + ry, gx = X0 - 1 + rx;
-        ho[k] = -1;
-        hv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        off[k] = 0u; ho[k] = 0;
         if (item < ITEMS && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w && !RABL(1)) {
           const int sby = gy / WR_BH, sbx = gx / WR_BW;
           const int ly = gy - sby * WR_BH, lx = gx - sbx * WR_BW;
           // which of the owner's published rows / columns holds the pixel
           const int slot = ry == 0 ? WR_BW + lx : (ry == WR_BH + 1 ? lx : (rx == 0 ? 2 * WR_BW + WR_BH + ly : 2 * WR_BW + ly));
-          const unsigned off = ((unsigned)(((L & 1) * nwg + sby * a.nbx + sbx) * WR_SLOTS + slot) * WR_NC + 4u * c4) * 4u;
-          hv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)off, 0, WR_SC1));
-          ho[k] = (4 * c4) * WR_CS + ry * WR_RS + rx;
+          off[k] = ((unsigned)(((L & 1) * nwg + sby * a.nbx + sbx) * WR_SLOTS + slot) * (WR_NC / 2) + (unsigned)c2) * 16u;
+          ho[k] = (2 * c2) * WR_CS + ry * WR_RS + rx;
+          pend |= 1u << k;
         }
       }
+      // (plain scalars, initialised: with a vector array left undefined for items that are not pending the
+      // compiler stored element 0 of an item into BOTH channels of its pair -- found on the GPU, round 4)
+      unsigned q0[PER_T], q1[PER_T], q2[PER_T], q3[PER_T];
 #pragma unroll
-      for (int k = 0; k < PER_T; ++k)
-        if (ho[k] >= 0) {
+      for (int k = 0; k < PER_T; ++k) { q0[k] = 0u; q1[k] = 0u; q2[k] = 0u; q3[k] = 0u; }
+      int polls = 0;
+      bool fault = a.poll_limit < 0;
+      while (pend != 0u && !fault) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dst[ho[k] + e * WR_CS] = hv[k][e];
+        for (int k = 0; k < PER_T; ++k)
+          if (pend & (1u << k)) {
+            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)off[k], 0, WR_SC1);
+            q0[k] = q[0]; q1[k] = q[1]; q2[k] = q[2]; q3[k] = q[3];
+          }
+#pragma unroll
+        for (int k = 0; k < PER_T; ++k)
+          if ((pend & (1u << k)) && q1[k] == target && q3[k] == target) {
+            dst[ho[k]] = __builtin_bit_cast(float, q0[k]);
+            dst[ho[k] + WR_CS] = __builtin_bit_cast(float, q2[k]);
+            pend &= ~(1u << k);
+          }
+        if (pend != 0u) {
+          __builtin_amdgcn_s_sleep(1);
+          fault = ++polls > a.poll_limit;
         }
+      }
+      if (fault && pend != 0u) __hip_atomic_fetch_add(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     RSTAMP(6);
-    __syncthreads();
+    // arrival counter of the eight boundary waves (monotonic over the launch): a wave's LDS stores are
+    // ordered before its increment, so whoever reads the full count sees every ring pixel
+    if (l == 0) __hip_atomic_fetch_add(s_cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    {
+      const unsigned want = 8u * (unsigned)(L + 1);
+      while ((int)(__hip_atomic_load(s_cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - want) < 0)
+        __builtin_amdgcn_s_sleep(1);
+    }
     RSTAMP(7);
   }
 }
@@ -382,7 +420,7 @@ bool conv3x3_wino_resident_ok(int n, int cout, int h, int w) {
 
 int64_t conv3x3_wino_resident_ws_bytes(int h, int w) {
   const long long nb = wres_blocks(h, w);
-  return 2 * nb * WR_SLOTS * WR_NC * 4 + ((nb * 4 + 255) / 256) * 256 + 256;   // exchange + flags + fault counter
+  return 2 * nb * WR_SLOTS * WR_NC * 8 + 256;   // exchange granules ({value, tag} pairs) + fault counter
 }
 
 int conv3x3_wino_resident_launch(const tg_wino_layer* layers, int n_layers, int cout, int h, int w, void* ws,
@@ -417,7 +455,6 @@ int conv3x3_wino_resident_launch(const tg_wino_layer* layers, int n_layers, int 
   a.x = layers[0].x; a.x2 = layers[0].x2; a.c1 = layers[0].x2 ? layers[0].c1 : layers[0].cin; a.cin0 = layers[0].cin;
   a.y = layers[n_layers - 1].y;
   a.xbuf = static_cast<float*>(ws);
-  a.flags = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + 2 * nb * WR_SLOTS * WR_NC * 4);
   a.err = err; a.base = base; a.poll_limit = poll_limit;
 #if TG_WRES_LAB
   { static const int abl = [] { const char* e = getenv("TG_WRES_ABL"); return e ? atoi(e) : 0; }(); a.abl = abl; }

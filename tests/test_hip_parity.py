@@ -419,7 +419,7 @@ def test_plan_with_resident_srnet_launch(tmp_path):
         "x = smooth_clip(7, 3, 70, 120, seed=5).cuda()\n"
         "y0 = net.infer_sequence(x, dev, return_device_tensor=True, pipeline=False)\n"
         "y1 = net.infer_sequence(x, dev, return_device_tensor=True, pipeline=True)\n"
-        "z = torch.rand(1, 3, 280, 480, device='cuda')\n"
+        "z = torch.rand(1, 3, 280, 480, generator=torch.Generator().manual_seed(3)).cuda()\n"
         "f = net.step(x[1:2], x[0:1], z)\n"
         "torch.cuda.synchronize(); net.check_faults()\n"
         "plan = net._get_plan(1, 70, 120, dev)\n"
