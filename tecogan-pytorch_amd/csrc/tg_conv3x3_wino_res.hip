@@ -29,6 +29,15 @@
 
 #include "tg_common.h"
 
+#ifndef WR_POLL_SLEEP
+#define WR_POLL_SLEEP 2   // s_sleep units (64 cycles) between two polls of the ring
+#endif
+#ifndef WR_PRIO_B
+#define WR_PRIO_B 0     // s_setprio of the boundary waves (the interior waves stay at 0)
+#endif
+#ifndef WR_USETS
+#define WR_USETS 2      // weight blocks (K steps) in flight per wave: 2 or 3
+#endif
 #ifndef TG_WRES_LAB
 #define TG_WRES_LAB 0   // 1: ablation switches (env TG_WRES_ABL) compiled in -- tools/build_lab_libs.sh, timing only
 #endif
@@ -151,6 +160,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
   const int T = WR_TILE[16 * g + (l & 15)];   // tile of the block (row-major 4 x 12)
   const int ty = T / WR_TW, tx = T - ty * WR_TW;
   const bool interior = g == 2;               // wave-uniform
+  if (WR_PRIO_B > 0 && !interior) __builtin_amdgcn_s_setprio(WR_PRIO_B);
   const int kk = l >> 4;                      // K index inside a K step (B operand) / output-channel quad (D)
   const int rb = kk * WR_CS + (2 * ty) * WR_RS + 2 * tx;        // window origin in the resident block (floats)
   const int oc_base = 16 * q + 4 * kk;
@@ -170,10 +180,16 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
   };
 
   f32x4 u0[4], u1[4];
+#if WR_USETS == 3
+  f32x4 u2[4];
+#endif
   {
     const f32x4* ub = reinterpret_cast<const f32x4*>(a.L[0].u) + ulane;
     load_u(ub, 0, a.L[0].nks, u0);
     load_u(ub, 1, a.L[0].nks, u1);
+#if WR_USETS == 3
+    load_u(ub, 2, a.L[0].nks, u2);
+#endif
   }
 
   for (int L = 0; L < a.nlayer; ++L) {
@@ -219,6 +235,25 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
         acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[p >> 2][p & 3], bq[p >> 2][p & 3], acc[p], 0, 0, 0);
     };
 
+#if WR_USETS == 3
+    {   // three weight blocks in flight (two K steps of distance): a wave that runs alone on its SIMD -- the
+        // interior waves during the hand-over -- otherwise waits for L2 every K step
+      int ks = 0;
+      for (; ks + 3 <= nks; ks += 3) {
+        kstep(ks, u0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(ub, ks + 3, nks, u0);
+        kstep(ks + 1, u1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(ub, ks + 4, nks, u1);
+        kstep(ks + 2, u2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(ub, ks + 5, nks, u2);
+      }
+      if (ks < nks) kstep(ks, u0);
+      if (ks + 1 < nks) kstep(ks + 1, u1);
+    }
+#else
     for (int ks = 0; ks < nks; ks += 2) {
       kstep(ks, u0);
       __builtin_amdgcn_sched_barrier(0);
@@ -227,6 +262,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
       __builtin_amdgcn_sched_barrier(0);
       load_u(ub, ks + 3, nks, u1);
     }
+#endif
     RSTAMP(1);
     // ---- inverse transform A^T m A, bias / activation / residual -----------------------------
     const bool last = L + 1 == a.nlayer;
@@ -265,6 +301,9 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
       const f32x4* un = reinterpret_cast<const f32x4*>(a.L[L + 1].u) + ulane;
       load_u(un, 0, a.L[L + 1].nks, u0);
       load_u(un, 1, a.L[L + 1].nks, u1);
+#if WR_USETS == 3
+      load_u(un, 2, a.L[L + 1].nks, u2);
+#endif
     }
     if (live) {
       if (last) {
@@ -354,24 +393,32 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
       unsigned q0[PER_T], q1[PER_T], q2[PER_T], q3[PER_T];
 #pragma unroll
       for (int k = 0; k < PER_T; ++k) { q0[k] = 0u; q1[k] = 0u; q2[k] = 0u; q3[k] = 0u; }
+      // While the neighbours are still computing, a thread polls ONE of its items (512 16-byte loads per
+      // round and workgroup instead of 2176: the poll traffic queued in front of the interior waves'
+      // weight loads was several times the weight traffic itself); once that one carries the tag the
+      // rest is fetched in one go.
       int polls = 0;
       bool fault = a.poll_limit < 0;
+      bool probe = true;
       while (pend != 0u && !fault) {
+        const unsigned want_mask = probe ? (pend & (0u - pend)) : pend;      // lowest pending item | all of them
 #pragma unroll
         for (int k = 0; k < PER_T; ++k)
-          if (pend & (1u << k)) {
+          if (want_mask & (1u << k)) {
             const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rxb, (int)off[k], 0, WR_SC1);
             q0[k] = q[0]; q1[k] = q[1]; q2[k] = q[2]; q3[k] = q[3];
           }
+        const unsigned before = pend;
 #pragma unroll
         for (int k = 0; k < PER_T; ++k)
-          if ((pend & (1u << k)) && q1[k] == target && q3[k] == target) {
+          if ((want_mask & (1u << k)) && q1[k] == target && q3[k] == target) {
             dst[ho[k]] = __builtin_bit_cast(float, q0[k]);
             dst[ho[k] + WR_CS] = __builtin_bit_cast(float, q2[k]);
             pend &= ~(1u << k);
           }
-        if (pend != 0u) {
-          __builtin_amdgcn_s_sleep(1);
+        if (probe && pend != before) probe = false;
+        else if (pend != 0u) {
+          __builtin_amdgcn_s_sleep(WR_POLL_SLEEP);
           fault = ++polls > a.poll_limit;
         }
       }
