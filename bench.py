@@ -66,6 +66,8 @@ def parse():
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the secondary protocols (step protocol, 4-clip batch): counter passes then '
                          'see only the launches of the headline workload')
+    ap.add_argument('--no-parity-check', action='store_true',
+                    help='skip the untimed parity check (profiling passes: only the launches of the timed workload)')
     ap.add_argument('--aten-frames', type=int, default=30,
                     help='frames of the ATen/MIOpen-on-GPU context baseline (0 disables)')
     return ap.parse_args()
@@ -112,6 +114,28 @@ def kernel_table(net, plan, bufs, reps=20):
     return rows
 
 
+def _csrc_hashes():
+    """sha1 of every kernel source: tools/summarize_pmc.py stamps them into profiles/pmc_traffic.json
+    ("_sources") so that a traffic figure measured on OTHER kernel code is reported as stale."""
+    import hashlib
+    d = os.path.join(ROOT, 'tecogan-pytorch_amd', 'csrc')
+    out = {}
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            out[f] = hashlib.sha1(open(os.path.join(d, f), 'rb').read()).hexdigest()[:16]
+    return out
+
+
+def pmc_traffic_stale():
+    """True when the committed counter passes were collected on different kernel sources (or carry no stamp)."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            stamp = json.load(f).get('_sources')
+    except Exception:
+        return True
+    return stamp != _csrc_hashes()
+
+
 def pmc_traffic(kernel, tag=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
     (profiles/pmc_traffic.json, written by tools/summarize_pmc.py); None if absent.  The launches of
@@ -122,6 +146,8 @@ def pmc_traffic(kernel, tag=None):
             table = json.load(f)
         want = kernel.replace(' ', '').rstrip('>')
         for k, v in table.items():
+            if k.startswith('_'):
+                continue
             name, _, ktag = k.partition(' [')
             if (ktag.rstrip(']') or None) != tag:
                 continue
@@ -186,8 +212,8 @@ def aten_gpu_baseline(sd, scale, deg, c, h, w, frames, dev):
                 _aten_step(O, sd, a[0], a[1], a[2], scale, deg)
                 torch.cuda.synchronize()
                 return time.perf_counter() - t0
-            for _ in range(5):
-                run()
+            for _ in range(15):        # MIOpen's find runs inside the first calls of every conv shape
+                run()                  # (a fresh box measured 10 frames/s with 5 warm-up frames, 43-49 warm)
             for _ in range(frames):
                 tot += run()
     except Exception as e:       # context number only: never fail the bench for it
@@ -349,6 +375,57 @@ def config5_leg(dev, gen, frames):
                                           'algorithmic rate `achieved` may exceed `peak` in the Winograd form')
         else:
             out['roofline']['frac'] = ach / MFMA_F32_PEAK_TFLOPS
+    return out
+
+
+def parity_check(dev, c, h, w, s, deg):
+    """Outside every timed region: (a) FRNet.step with the procedural parity weights on the seeded inputs of
+    tests/golden/fullsize.npz -- a digest the REFERENCE produced (tests/golden/make_golden.py) -- through the
+    same kernels the bench times (the LDS-resident SRNet body at 134x320); (b) the bench path itself,
+    infer_sequence(pipeline=True), against the frame-by-frame step() chain on a 4-frame clip (uint8: at most one
+    level on <= 0.2 % of a frame -- the 8-pair batched flow pass picks the Winograd form for layers the
+    one-pair pass runs in the direct form, so the two are equal up to fp32 summation order, not bit for bit)."""
+    import numpy as np
+    from procedural_weights import generator_state_dict
+    from tecogan_pytorch_amd.models.networks import FRNet
+    out = {}
+    try:
+        tagk = {('BD', 4, 134, 320): 'A', ('BI', 2, 268, 640): 'E'}.get((deg, s, h, w))
+        net = FRNet(c, c, 64, 10, deg, s)
+        net.load_state_dict(generator_state_dict(scale=s, degradation=deg), strict=True)
+        net = net.to(dev).eval()
+
+        def rs(seed, shape):
+            return torch.from_numpy(np.random.RandomState(seed).uniform(0.0, 1.0, shape).astype(np.float32)).to(dev)
+        with torch.no_grad():
+            if tagk is not None:
+                g = np.load(os.path.join(ROOT, 'tests', 'golden', 'fullsize.npz'))
+                o = net.step(rs(100, (1, c, h, w)), rs(101, (1, c, h, w)), rs(102, (1, c, s * h, s * w)))
+                flat = o.double().cpu().reshape(-1)
+                idx = torch.from_numpy(g[f'full_{tagk}_sample_idx'])
+                e_s = float(np.abs(flat[idx].float().numpy() - g[f'full_{tagk}_samples']).max())
+                e_m = abs(flat.mean().item() - float(g[f'full_{tagk}_mean']))
+                out['step_vs_reference_digest'] = {'max_abs_err_257_samples': e_s, 'mean_err': e_m,
+                                                   'ok': bool(e_s <= 3e-4 and e_m <= 1e-5)}
+            clip = torch.rand(4, c, h, w, generator=torch.Generator().manual_seed(5)).to(dev)
+            u8 = net.infer_sequence(clip, dev, pipeline=True, return_device_tensor=True)
+            hr = torch.zeros(1, c, s * h, s * w, device=dev)
+            prev = torch.zeros(1, c, h, w, device=dev)
+            worst, differ = 0, 0.0
+            for t in range(clip.shape[0]):
+                hr = net.step(clip[t:t + 1], prev, hr)
+                prev = clip[t:t + 1]
+                q = (hr[0] * 255.0).round().clamp(0, 255).to(torch.uint8).permute(1, 2, 0)
+                d = (q.int() - u8[t].int()).abs()
+                worst = max(worst, int(d.max()))
+                differ = max(differ, float((d > 0).float().mean()))
+            torch.cuda.synchronize()
+            net.check_faults()
+            out['pipelined_clip_vs_step_chain'] = {'max_uint8_levels': worst, 'max_fraction_differing': differ,
+                                                   'ok': bool(worst <= 1 and differ <= 2e-3)}
+        out['ok'] = all(v['ok'] for v in out.values() if isinstance(v, dict))
+    except Exception as e:       # reported, never fatal: the parity tests proper are tests/ -m gpu
+        out = {'ok': False, 'error': repr(e)[:300]}
     return out
 
 
@@ -697,6 +774,10 @@ def main():
                                    'not a baseline for vs_baseline',
         }
         result.update(sec)
+        if not args.no_parity_check:
+            pc = parity_check(dev, c, h, w, s, deg)
+            result['parity_check'] = 'ok' if pc.get('ok') else 'FAILED'
+            result['parity_check_detail'] = pc
         if train_leg is not None:
             result['train_ddp'] = train_leg
         if cfg5 is not None:
@@ -717,6 +798,14 @@ def main():
                 'avg_launch_us': 1e3 * dom_mf['ms_per_frame'] / dom_mf['launches'],
                 'algorithmic_gflop_per_launch': dom_mf['gflop'] / dom_mf['launches'],
             }
+            result['roofline']['traffic_stale'] = pmc_traffic_stale()
+            if dom_mf['kernel'] == 'conv3x3_wino_resident_kernel':
+                nlay = 1 + 2 * 10
+                result['roofline']['layers_per_launch'] = nlay
+                result['roofline']['avg_layer_us'] = 1e3 * dom_mf['ms_per_frame'] / nlay
+                result['roofline']['note'] = ('ONE persistent launch per frame: SRNet conv_in + 20 residual-block convs on '
+                                              'LDS-resident 8x24-pixel blocks (tg_conv3x3_wino_res.hip); per-layer launches of '
+                                              'the same arithmetic: TG_WINO_RES=0')
             if dom_mf['kernel'].startswith('conv3x3_wino'):
                 # `achieved` counts the ALGORITHMIC FLOPs of the 3x3 convolution (2*9*cin*cout per
                 # pixel, the contract's definition); the Winograd F(2x2,3x3) form executes 16 of

@@ -29,6 +29,9 @@
 
 #include "tg_common.h"
 
+#ifndef TG_CHAIN_FENCES
+#define TG_CHAIN_FENCES 0   // 1: release / acquire fences around the flag of the chained launch (measurement build)
+#endif
 #ifndef TG_WINO_LAB
 #define TG_WINO_LAB 0   // 1: ablation switches of tools/wino_abl.sh (TG_WINO_ABL) compiled in
 #endif
@@ -432,12 +435,31 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_chain_kernel(WinoChainArg
         }
         if (fault) __hip_atomic_fetch_add(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
+#if TG_CHAIN_FENCES
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // measured variant, see the note below
+#endif
     }
     __syncthreads();
   }
   wino_tile<COHX>(a, tx, ty, 0, n);
   __builtin_amdgcn_s_waitcnt(0);              // this wave's stores have been acknowledged
   __syncthreads();
+  // Memory-model note.  The formally portable hand-over is
+  //   producer: data stores; fence(release, agent); relaxed flag store
+  //   consumer: relaxed flag poll; fence(acquire, agent); data loads
+  // On gfx950 the release fence is `buffer_wbl2 sc1; s_waitcnt vmcnt(0)` and the acquire fence `buffer_inv sc1`
+  // (MI355X_MICROARCH.md): with agent-scope (sc1, write-through) data stores that were waited for there is
+  // nothing left to write back, and with sc1 data loads there is no L1 line to invalidate -- the fences
+  // add nothing but their cost.  Built with -DTG_CHAIN_FENCES=1 the launch measured +X % (tools/chain_fence_lab.sh;
+  // DESIGN.md section 10c has the number), so the shipped form keeps sc1 stores + acknowledged waitcnt +
+  // relaxed agent-scope flag, and the property is held by tests/test_hip_soak.py (200 launches per production
+  // shape on fresh data under a concurrent memory stream, bit-compared with per-layer launches).
+#if TG_CHAIN_FENCES
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#endif
   if (threadIdx.x == 0)
     __hip_atomic_store(reinterpret_cast<unsigned*>(c.flags) + (size_t)layer * c.ntile + tile, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -14,11 +14,15 @@
 
 Tolerances are stated per assertion (fp32 everywhere; the differences are
 summation order, compounded through the recurrence)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import tecogan_oracle as O
 from procedural_weights import generator_state_dict, discriminator_state_dict, smooth_clip
@@ -98,6 +102,43 @@ def test_vid4_length_clip_vs_oracle_both_pipeline_modes():
             assert dp <= 1e-3, (name, t, dp)
 
 
+@pytest.mark.parametrize('deg,s,h,w,frames', [('BD', 4, 134, 320, 10), ('BI', 2, 268, 640, 6)])
+def test_bench_path_fullsize_clip_vs_oracle(deg, s, h, w, frames):
+    """The EXACT path bench.py times -- FRNet.infer_sequence(pipeline=True) at BASELINE's full sizes: the
+    8-pair batched FNet plan on the side stream, the LDS-resident SRNet body (4x: one 134x320 frame) / the
+    chained Winograd launch (2x: 268x640), the fused HR stage with uint8 output -- against the oracle's
+    infer_sequence on a clip with real motion: uint8 <= 1 level on <= 0.5 % of a frame and
+    |dPSNR-Y| <= 1e-3 dB against a common pseudo ground truth on EVERY frame (north_star's bound); the
+    serial path within one level on <= 0.2 % of a frame of the pipelined one."""
+    from tecogan_pytorch_amd.models.networks import FRNet
+    net = FRNet(3, 3, 64, 10, deg, s)
+    sd = generator_state_dict(scale=s, degradation=deg)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    clip = smooth_clip(frames, 3, h, w, seed=31, shift=1.3)
+    got = net.infer_sequence(clip, 'cuda', pipeline=True)
+    assert got.shape == (frames, s * h, s * w, 3) and got.dtype == np.uint8
+    serial = net.infer_sequence(clip, 'cuda', pipeline=False)
+    # (not bit-identical at this size: the 8-pair batched flow pass selects the Winograd form for layers the
+    # one-pair pass runs in the direct form -- same values up to fp32 summation order)
+    ds = np.abs(got.astype(np.int16) - serial.astype(np.int16))
+    assert ds.max() <= 1 and (ds > 0).reshape(frames, -1).mean(1).max() <= 2e-3, (ds.max(), (ds > 0).mean())
+    net.check_faults()
+    dev0 = torch.device('cuda', 0)
+    plan = net._get_plan(1, h, w, dev0)
+    assert plan.chain_state() == (0, True), plan.chain_state()      # the one-launch body ran and never faulted
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = O.infer_sequence(sd, clip, s, deg)
+    gt = O.float32_to_uint8(O.upsample(clip, s, deg).numpy()).transpose(0, 2, 3, 1)   # pseudo GT
+    d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1, d.max()
+    per_frame = (d > 0).reshape(frames, -1).mean(1)
+    assert per_frame.max() <= 5e-3, (per_frame.max(), int(per_frame.argmax()))
+    for t in range(frames):
+        dp = abs(_psnr_y(gt[t], got[t]) - _psnr_y(gt[t], ref[t]))
+        assert dp <= 1e-3, (t, dp)
+
+
 # ---------------------------------------------------- full-size training step
 WATCH_G = ['fnet.encoder1.0.weight', 'fnet.decoder1.2.bias', 'fnet.flow.2.weight',
            'srnet.conv_in.0.weight', 'srnet.resblocks.4.conv.2.weight', 'srnet.conv_up.2.weight',
@@ -125,6 +166,9 @@ def _train_opt(crop, tempo, thr):
                   'gan_crit': {'type': 'GAN', 'weight': 0.01, 'reduction': 'mean'}},
         'logger': {'decay': 0.99},
     }
+
+
+TOL_G, TOL_D = 1e-2, 1e-2      # relative L2 of a watched gradient against the oracle autograd; measured (round 4, gpurun_out/train_grad_rel_l2_crop*.json): G <= 4.7e-3 (crop 256), D <= 8.4e-3 (crop 128)
 
 
 def _rel_l2(a, b):
@@ -166,12 +210,20 @@ def test_fullsize_tecogan_train_step_vs_oracle(crop, tag):
         post_update = k in ('l_gan_G', 'p_fake_G')
         rtol, atol = (1e-2, 5e-4) if post_update else (5e-4, 2e-5)
         assert abs(log[k] - v) <= rtol * abs(v) + atol, (tag, k, log[k], v)
+    eG = {k: _rel_l2(gG[k], rG[k]) for k in WATCH_G}
+    eD = {k: _rel_l2(gD[k], rD[k]) for k in WATCH_D}
+    try:      # the measured values, for the record (DESIGN.md section 5 quotes them; bounds = ~2x the worst seen)
+        import json
+        out = os.path.join(ROOT_DIR, 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'train_grad_rel_l2_crop%d.json' % crop), 'w') as f:
+            json.dump({'gradG': eG, 'gradD': eD}, f, indent=1)
+    except OSError:
+        pass
     for k in WATCH_G:
-        e = _rel_l2(gG[k], rG[k])
-        assert e <= 2e-2, (tag, 'gradG', k, e)
+        assert eG[k] <= TOL_G, (tag, 'gradG', k, eG[k])
     for k in WATCH_D:
-        e = _rel_l2(gD[k], rD[k])
-        assert e <= 1e-2, (tag, 'gradD', k, e)
+        assert eD[k] <= TOL_D, (tag, 'gradD', k, eD[k])
     # BatchNorm running statistics after the iteration's three D passes.  The third pass runs
     # AFTER D's Adam step (every weight moved by lr * sign(g); weights whose summed gradient is
     # ~0 flip sign under fp32 re-association), so 0.1 x its batch statistics carry that

@@ -1,0 +1,114 @@
+"""Soak tests of every launch whose workgroups wait for each other INSIDE the launch:
+  * the LDS-resident SRNet body (tg_conv3x3_wino_resident: ring granules between neighbour blocks),
+  * the chained Winograd launch (tg_conv3x3_wino_chain: per-tile flags) at its two production shapes --
+    4 clips of 134x320 in lockstep and one 268x640 frame,
+  * the persistent row chain of the training frames (tg_conv3x3_chain, 16x16x4 form at 2 x 32 x 32),
+200 launches each on FRESH inputs, compared with one launch per layer (bit for bit where the arithmetic is
+the same kernel code, 2e-5 relative for the row chain against the direct kernel) WHILE a second stream
+streams 256 MB copies through L2 / HBM: a stale halo, a lost flag or a torn granule shows as an O(1)
+mismatch, a missed wake-up as a fault count."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ITERS = 200
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import tecogan_pytorch_amd.ops as ops_
+    from tecogan_pytorch_amd import _lib
+    _lib.lib()
+    return ops_
+
+
+class Thrash:
+    """Keeps a side stream busy with 256 MB device-to-device copies (rotating through 1 GB)."""
+
+    def __init__(self):
+        self.s = torch.cuda.Stream()
+        self.bufs = [torch.empty(64 * 1024 * 1024, device='cuda') for _ in range(4)]
+        self.k = 0
+
+    def kick(self, n=2):
+        with torch.cuda.stream(self.s):
+            for _ in range(n):
+                self.bufs[(self.k + 1) % 4].copy_(self.bufs[self.k % 4])
+                self.k += 1
+
+
+def _body_layers(ops, n, h, w, nb, seed, wino=True):
+    g = torch.Generator().manual_seed(seed)
+    lr, s2d = torch.rand(n, 3, h, w, generator=g).cuda(), torch.rand(n, 48, h, w, generator=g).cuda()
+    ws = [(torch.randn(64, 51, 3, 3, generator=g) * 0.04).cuda()] + \
+         [(torch.randn(64, 64, 3, 3, generator=g) * 0.03).cuda() for _ in range(2 * nb)]
+    bs = [(torch.randn(64, generator=g) * 0.1).cuda() for _ in range(2 * nb + 1)]
+    us = [ops.pack_conv3x3_wino(x) for x in ws] if wino else None
+
+    def make(A, B):
+        first = dict(x=lr, x2=s2d, bias=bs[0], cin=51, act=1, y=A)
+        layers = [first]
+        for b in range(nb):
+            layers.append(dict(x=A, bias=bs[1 + 2 * b], cin=64, act=1, y=B))
+            layers.append(dict(x=B, bias=bs[2 + 2 * b], cin=64, act=0, res=A, y=A))
+        for i, d in enumerate(layers):
+            d['w'] = ws[i]
+            if wino:
+                d['u'] = us[i]
+        return layers
+    return lr, s2d, make
+
+
+@pytest.mark.parametrize('kind,n,h,w', [('resident', 1, 134, 320), ('wino_chain', 4, 134, 320), ('wino_chain', 1, 268, 640)])
+def test_soak_winograd_body_launches_under_memory_pressure(ops, kind, n, h, w):
+    if kind == 'resident' and not ops.WinoResident.supported(64, h, w):
+        pytest.skip('frame does not fit one block per CU on this device')
+    nb = 10
+    lr, s2d, make = _body_layers(ops, n, h, w, nb, seed=41)
+    A1, B1, A2, B2 = (torch.empty(n, 64, h, w, device='cuda') for _ in range(4))
+    seq = make(A1, B1)
+    one = ops.WinoResident(make(A2, B2), 64, h, w) if kind == 'resident' else ops.WinoChain(make(A2, B2), n, 64, h, w)
+    th = Thrash()
+    for it in range(ITERS):
+        lr.uniform_(-1, 1); s2d.uniform_(-1, 1)
+        th.kick()
+        for d in seq:
+            ops.conv3x3_wino(d['x'], d['u'], d['bias'], d['cin'], 64, d['act'], x2=d.get('x2'), res=d.get('res'), out=d['y'])
+        th.kick()
+        one.run()
+        torch.cuda.current_stream().synchronize()
+        assert torch.equal(A1, A2), (kind, it, int((A1 != A2).sum()), (A1 - A2).abs().max().item())
+    torch.cuda.synchronize()
+    assert one.bailouts() == 0
+
+
+def test_soak_row_chain_training_frames_under_memory_pressure(ops):
+    n, h, w, nb = 2, 32, 32, 10
+    lr, s2d, make = _body_layers(ops, n, h, w, nb, seed=43, wino=False)
+    A1, B1, A2, B2 = (torch.empty(n, 64, h, w, device='cuda') for _ in range(4))
+    seq = make(A1, B1)
+    pks = [ops.pack_conv3x3(d['w'], ocb=64) for d in seq]
+    chain = ops.RowChain(make(A2, B2), n, h, w)
+    assert chain.parts == 4                       # the 16x16x4 form: four workgroups per tile row
+    th = Thrash()
+    ref = None
+    for it in range(ITERS):
+        fresh = it % 2 == 0                       # every input twice: the second launch must repeat the first bit for bit
+        if fresh:
+            lr.uniform_(-1, 1); s2d.uniform_(-1, 1)
+            th.kick()
+            for i, d in enumerate(seq):
+                ops.conv3x3(d['x'], pks[i][0], d['bias'], d['w'].shape[1], 64, 64, d['act'], x2=d.get('x2'),
+                            res=d.get('res'), out=d['y'], ksplit=1)
+        th.kick()
+        chain.run()
+        torch.cuda.current_stream().synchronize()
+        e = ((A2.double() - A1.double()).norm() / A1.double().norm()).item()
+        assert e <= 2e-5, (it, e)
+        if fresh:
+            ref = A2.clone()
+        else:
+            assert torch.equal(A2, ref), it
+    torch.cuda.synchronize()
+    assert chain.faults() == 0

@@ -14,9 +14,9 @@ echo "== bench (default flags)"; timeout 900 python bench.py > $OUT/${TAG}_bench
 echo "== bench 2xBI (configs[4]) as its own run"; timeout 600 python bench.py --lr-size 3x268x640 --scale 2 --degradation BI --no-train-leg --cpu-frames 0 --aten-frames 0 --clips 5 > $OUT/${TAG}_bench_config5_2xBI.json 2>/dev/null; cut -c1-300 $OUT/${TAG}_bench_config5_2xBI.json
 echo "== rocprofv3 kernel stats: pipelined / single stream / training"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o kt -- python $REPO/bench.py --steps 30 --warmup 5 --clips 3 --no-roofline --no-secondary --no-train-leg --cpu-frames 0 --aten-frames 0 > $OUT/prof_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o kt -- python $REPO/bench.py --steps 30 --warmup 5 --clips 3 --no-roofline --no-secondary --no-parity-check --no-train-leg --cpu-frames 0 --aten-frames 0 > $OUT/prof_$TAG.log 2>&1
 cp $OUT/prof_$TAG/kt_kernel_stats.csv $OUT/${TAG}_kernel_stats_rocprofv3.csv; rm -rf $OUT/prof_$TAG
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof1s_$TAG -o kt -- python $REPO/bench.py --steps 30 --warmup 5 --clips 3 --no-roofline --no-pipeline --no-secondary --no-train-leg --cpu-frames 0 --aten-frames 0 > $OUT/prof1s_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof1s_$TAG -o kt -- python $REPO/bench.py --steps 30 --warmup 5 --clips 3 --no-roofline --no-pipeline --no-secondary --no-parity-check --no-train-leg --cpu-frames 0 --aten-frames 0 > $OUT/prof1s_$TAG.log 2>&1
 cp $OUT/prof1s_$TAG/kt_kernel_stats.csv $OUT/${TAG}_kernel_stats_single_stream_rocprofv3.csv; rm -rf $OUT/prof1s_$TAG
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/proft_$TAG -o kt -- python $REPO/tools/bench_train.py --crop 256 --steps 4 --warmup 2 --force-d > $OUT/proft_$TAG.log 2>&1
 cp $OUT/proft_$TAG/kt_kernel_stats.csv $OUT/${TAG}_kernel_stats_train_rocprofv3.csv; rm -rf $OUT/proft_$TAG

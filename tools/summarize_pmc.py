@@ -43,6 +43,12 @@ for (k, g), d in agg.items():
         n = len(d['FETCH_SIZE'])
         t[0] += (sum(d['FETCH_SIZE']) / n + sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE'])) * 1024 * n
         t[1] += n
-json.dump({k: v[0] / v[1] for k, v in traffic.items()},
-          open(os.path.join(outdir, 'pmc_traffic.json'), 'w'), indent=1)
+table = {k: v[0] / v[1] for k, v in traffic.items()}
+# stamp: sha1 of the kernel sources these counters were collected on (bench.py prints traffic_stale on mismatch)
+sys.path.insert(0, ROOT)
+import hashlib
+csrc = os.path.join(ROOT, 'tecogan-pytorch_amd', 'csrc')
+table['_sources'] = {f: hashlib.sha1(open(os.path.join(csrc, f), 'rb').read()).hexdigest()[:16]
+                     for f in sorted(os.listdir(csrc)) if f.endswith(('.hip', '.h'))}
+json.dump(table, open(os.path.join(outdir, 'pmc_traffic.json'), 'w'), indent=1)
 print('wrote', out, 'and profiles/pmc_traffic.json')
