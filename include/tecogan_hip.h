@@ -552,6 +552,16 @@ int tg_bce_logits(const float* x, int64_t n, float target, float scale, float* s
 int tg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int step,
                  tg_stream_t stream);
+/* The same step behind a device-side guard: a no-op (weights and both moments untouched) when
+ * *skip_if_nonzero != 0.  The training step points it at the FAULT SLOT of the network's flat gradient
+ * buffer: tg_fault_to_slot adds 1 to that float when the pinned fault counter of the chained launches
+ * (tg_srnet_body_fwd / _bwd) is non-zero, BEFORE the data-parallel all-reduce of the buffer -- so a fault
+ * on any rank drops the update on every rank, instead of applying gradients built on stale tiles
+ * (the reference has no counterpart: its layers are separate launches). */
+int tg_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int step,
+                         const float* skip_if_nonzero, tg_stream_t stream);
+int tg_fault_to_slot(const int32_t* fault_counter, float* slot, tg_stream_t stream);
 int tg_axpy(float* y, const float* x, float a, int64_t n, tg_stream_t stream);
 /* y[i] = x[i] / d (y may alias x): the mean of an all-reduced gradient bucket, with the IEEE division
  * DDP's `bucket / world_size` performs (base_model.py:130-136), exact for any world size. */

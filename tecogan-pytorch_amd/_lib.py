@@ -109,6 +109,8 @@ SIGNATURES = {
     'tg_pixel_loss': (I, [P, P, I64, I, F, P, F, P, P]),
     'tg_bce_logits': (I, [P, I64, F, F, P, F, P, P]),
     'tg_adam_step': (I, [P, P, P, P, I64, F, F, F, F, F, I, P]),
+    'tg_adam_step_guarded': (I, [P, P, P, P, I64, F, F, F, F, F, I, P, P]),
+    'tg_fault_to_slot': (I, [P, P, P]),
     'tg_axpy': (I, [P, P, F, I64, P]),
     'tg_div_scalar': (I, [P, P, F, I64, P]),
     'tg_bn_lrelu_train_fwd': (I, [P, P, P, P, P, F, F, F, P, P, P, I, I, I, P]),

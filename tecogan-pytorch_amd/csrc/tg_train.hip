@@ -447,7 +447,11 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v, long long n, float lr,
-                            float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2) {
+                            float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
+                            const float* __restrict__ skip) {
+  // fail-safe of the chained launches: a fault recorded during this step (possibly on another rank: the
+  // slot travels with the gradient bucket) turns the update into a no-op -- weights and moments untouched
+  if (skip && *skip != 0.f) return;
   TG_GRID_STRIDE(i, n) {
     float gi = g[i];
     if (wd != 0.f) gi += wd * p[i];
@@ -911,8 +915,29 @@ extern "C" int tg_adam_step(float* p, const float* g, float* m, float* v, int64_
   float bc1 = 1.f - powf(beta1, (float)step);
   float sbc2 = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, g, m, v, (long long)n, lr,
-                     beta1, beta2, eps, weight_decay, bc1, sbc2);
+                     beta1, beta2, eps, weight_decay, bc1, sbc2, (const float*)nullptr);
   return check_launch("adam_step");
+}
+
+extern "C" int tg_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, int step,
+                                    const float* skip_if_nonzero, tg_stream_t stream) {
+  TG_REQUIRE(p && g && m && v && n > 0 && step >= 1, TG_E_ARG, "adam_step_guarded: bad argument");
+  float bc1 = 1.f - powf(beta1, (float)step);
+  float sbc2 = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, g, m, v, (long long)n, lr,
+                     beta1, beta2, eps, weight_decay, bc1, sbc2, skip_if_nonzero);
+  return check_launch("adam_step_guarded");
+}
+
+__global__ void fault_to_slot_kernel(const int32_t* __restrict__ err, float* __restrict__ slot) {
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) *slot += 1.0f;
+}
+
+extern "C" int tg_fault_to_slot(const int32_t* fault_counter, float* slot, tg_stream_t stream) {
+  TG_REQUIRE(fault_counter && slot, TG_E_ARG, "fault_to_slot: null pointer");
+  hipLaunchKernelGGL(fault_to_slot_kernel, dim3(1), dim3(1), 0, ST, fault_counter, slot);
+  return check_launch("fault_to_slot");
 }
 
 extern "C" int tg_div_scalar(float* y, const float* x, float d, int64_t n, tg_stream_t stream) {

@@ -41,10 +41,20 @@ class TrainSource:
         per = len(self.dataset) if not self.dist else -(-len(self.dataset) // self.world)
         return per // self.batch
 
+    def replay(self, epochs):
+        """A resumed run: draw (and discard) the sample geometry of `epochs` whole epochs, so that the
+        Python / numpy random streams the reference's __getitem__ consumes stand where an uninterrupted
+        run would have them (the sampler order itself is a function of (seed, epoch) alone).  Exact for a
+        resume in a NEW process seeded like the original one (main.setup) -- the random state is not
+        part of the checkpoint."""
+        for e in range(epochs):
+            for _ in self.epoch(e, first_batch=1 << 60):
+                pass
+
     def epoch(self, epoch=0, first_batch=0):
-        """Batches of one epoch; `first_batch` > 0 skips that many (a resumed run: the geometry of
-        the skipped samples is still drawn, so the random streams stay aligned with an
-        uninterrupted epoch)."""
+        """Batches of one epoch; `first_batch` > 0 skips that many: their sample geometry is still drawn
+        (only the device gather is skipped), so the random streams stay aligned with an uninterrupted
+        epoch.  Earlier EPOCHS of a resumed run are replayed with `replay()` (main --resume does)."""
         n = len(self.dataset)
         g = torch.Generator()
         g.manual_seed(self.seed + epoch)

@@ -25,9 +25,10 @@ class DeviceClipStore:
     @classmethod
     def from_frames(cls, frames, device='cuda', channels=3):
         """frames: iterable of (key, uint8 array-like / bytes of h*w*channels) with LMDB key names,
-        or a (keys, getter) pair for sources that can be walked twice (from_lmdb).  The device
-        buffer is sized from the key names (they carry the frame size) and filled through one
-        pinned staging buffer -- no second host copy of the data set."""
+        or a (keys, getter) pair for sources that can be walked twice (from_lmdb: no second host copy of
+        the data set).  A plain iterable is materialised first (its keys size the device buffer before
+        the first byte can be staged).  The device buffer is filled through one pinned staging buffer
+        whose alignment gaps are zeroed."""
         self = cls(device)
         if isinstance(frames, tuple) and len(frames) == 2 and callable(frames[1]):
             keys, get = frames
@@ -63,9 +64,8 @@ class DeviceClipStore:
                 flush()
                 base = o
             stage_np[o - base:o - base + arr.size] = arr
-            fill = o - base + (arr.size + 15) // 16 * 16
-            if fill > stage.numel():
-                fill = stage.numel()
+            fill = min(o - base + (arr.size + 15) // 16 * 16, stage.numel())
+            stage_np[o - base + arr.size:fill] = 0             # the alignment gap: no stale bytes of an earlier flush
         flush()
         return self
 

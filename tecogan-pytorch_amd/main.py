@@ -210,6 +210,8 @@ def main(argv=None):
         # a resumed run continues in the epoch (and at the batch) iteration `resume` had reached:
         # the sampler order of an epoch is a function of (seed, epoch) alone
         ep0, skip = divmod(args.resume, per_epoch)
+        if ep0 > 0:
+            src.replay(ep0)      # the geometry draws of the finished epochs (random streams aligned with an uninterrupted run)
 
         def epochs():
             ep, left, sk = ep0, n_iter, skip

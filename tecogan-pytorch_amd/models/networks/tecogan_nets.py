@@ -180,8 +180,8 @@ class SRNet(nn.Module):
         lr_curr, hr_prev_tran = lr_curr.contiguous(), hr_prev_tran.contiguous()
         if tape is not None:
             n_, _, h_, w_ = lr_curr.shape
-            if self.chain_body and len(self.resblocks) >= 1 and TG._ChainState.usable(
-                    n_, self.conv_in['0'].cout, self.conv_in['0'].cin, h_, w_):
+            if self.chain_body and TG._ChainState.usable(
+                    n_, self.conv_in['0'].cout, self.conv_in['0'].cin, h_, w_, len(self.resblocks)):
                 # conv_in + the residual blocks as ONE launch (and one for their reverse sweep)
                 out = TG.srnet_body(tape, self, lr_curr, hr_prev_tran)
             else:

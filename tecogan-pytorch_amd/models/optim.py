@@ -24,6 +24,7 @@ class Adam:
         self.state = {}
         self.steps = 0
         self.flat_param = self.flat_grad = self.flat_m = self.flat_v = None
+        self.fault_slot = None
         if flatten and self.params and all(p.is_cuda and p.dtype == torch.float32 for p in self.params):
             self._flatten()
 
@@ -33,10 +34,15 @@ class Adam:
             offs.append(tot)
             tot += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         dev = self.params[0].device
-        self.flat_param = torch.zeros(tot, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(tot, dtype=torch.float32, device=dev)
-        self.flat_m = torch.zeros(tot, dtype=torch.float32, device=dev)
-        self.flat_v = torch.zeros(tot, dtype=torch.float32, device=dev)
+        # one more aligned block behind the last tensor: its first float is the FAULT SLOT of the chained
+        # launches' fail-safe -- it travels with the gradient all-reduce, and a non-zero value turns this
+        # network's step into a no-op on every rank (models/train_graph.py: stamp_fault)
+        self._ntot = tot
+        self.flat_param = torch.zeros(tot + self.ALIGN, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(tot + self.ALIGN, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(tot + self.ALIGN, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(tot + self.ALIGN, dtype=torch.float32, device=dev)
+        self.fault_slot = self.flat_grad[tot:tot + 1]
         with torch.no_grad():
             for p, o in zip(self.params, offs):
                 k = p.numel()
@@ -71,8 +77,9 @@ class Adam:
         g = self.param_groups[0]
         self.steps += 1
         if self._is_flat() and all(p.requires_grad for p in self.params):
-            ops.adam_step(self.flat_param, self.flat_grad, self.flat_m, self.flat_v, g['lr'],
-                          g['betas'], g['eps'], g['weight_decay'], self.steps)
+            n = self._ntot
+            ops.adam_step(self.flat_param[:n], self.flat_grad[:n], self.flat_m[:n], self.flat_v[:n], g['lr'],
+                          g['betas'], g['eps'], g['weight_decay'], self.steps, skip=self.fault_slot)
             for p in self.params:
                 ops.bump_version(p)
             return

@@ -341,7 +341,9 @@ class _ChainState:
     @classmethod
     def buffers(cls, nlayer, n, h, w, device):
         from .. import _lib as L
-        key = (n, h, w, str(device))
+        # one flag buffer per (shape, device, stream): two chained launches of one shape in flight at once
+        # (a second model, a side stream, another device) must not overwrite each other's epochs
+        key = (n, h, w, str(device), ops._stream())
         fl = cls.flags.get(key)
         need = L.lib().tg_conv3x3_chain_flag_ints(24, n, h, w)
         if fl is None or fl.numel() < need:
@@ -355,33 +357,53 @@ class _ChainState:
     def parts(cls, n, h, w):
         """workgroups per tile the launcher uses for this shape (0: not supported): 4 needs the
         16 x 16 x 4 weight layout (ops.pack_conv3x3_m16), 1 / 2 the 64-channel-block layout."""
-        key = (n, h, w)
+        key = (n, h, w, torch.cuda.current_device() if torch.cuda.is_available() else -1)
         r = cls.supported.get(key)
         if r is None:
             from .. import _lib as L
             r = cls.supported[key] = int(L.lib().tg_conv3x3_chain_supported(n, h, w, 64))
         return r
 
+    MAX_LAYERS = 24      # RC_MAXL of tg_conv3x3_chain.hip: tg_srnet_body_fwd / _bwd walk 1 + 2 nb (+ 1) layers
+
     @classmethod
-    def usable(cls, n, nf, cin0, h, w):
-        if cls.disabled or nf > 64 or cin0 > 64:
+    def usable(cls, n, nf, cin0, h, w, nb):
+        """nb: residual blocks of the body (a free yml parameter in the reference, tecogan_nets.py:108-116):
+        beyond 11 the body does not fit one chained launch and runs one launch per layer."""
+        if cls.disabled or nf > 64 or cin0 > 64 or nb < 1 or 2 * nb + 2 > cls.MAX_LAYERS:
             return False
         return cls.parts(n, h, w) > 0
 
 
-def chain_check():
-    """Call after a host synchronisation (the training step's scalar read): raises if a chained
-    launch recorded a fault since the last check -- the step's results are then invalid -- and
-    switches every later step to one launch per layer."""
+def stamp_fault(optim):
+    """Before a network's gradient exchange / optimiser step: add 1 to the FAULT SLOT of its flat gradient
+    buffer if a chained launch of this process has recorded a fault (a one-thread kernel reads the pinned
+    counter).  The slot is all-reduced with the gradients and guards the Adam step on the device
+    (tg_adam_step_guarded): gradients built on stale tiles are then applied on NO rank."""
     err = _ChainState.err
-    if err is not None and int(err[0]) != 0:
+    if err is not None and optim is not None and getattr(optim, 'fault_slot', None) is not None and optim._is_flat():
+        ops.fault_to_slot(err, optim.fault_slot)
+
+
+def chain_check(slot_value=0.0):
+    """Call after a host synchronisation (the training step's scalar read): raises if a chained launch
+    recorded a fault since the last check, here (pinned counter) or on any rank (`slot_value`: the fault slot
+    of the generator's gradient buffer after its all-reduce, read with the step's scalars).  The iteration's
+    generator update was dropped on every rank by the device-side guard; every later step runs one launch
+    per layer."""
+    err = _ChainState.err
+    local = err is not None and int(err[0]) != 0
+    if local or slot_value != 0.0:
         from .. import _lib as L
-        lost = int(err[0])
-        err.zero_()
+        lost = int(err[0]) if local else 0
+        if err is not None:
+            err.zero_()
         _ChainState.disabled = True
-        raise L.TecoganHipError(f'chained SRNet launch (training): {lost} workgroup(s) timed out waiting for a '
-                                'neighbour tile; the results of this step are INVALID.  Later steps run one '
-                                'launch per layer.')
+        raise L.TecoganHipError(
+            'chained SRNet launch (training): %s timed out waiting for a neighbour tile; the results of this '
+            'step are INVALID and its optimiser step was DROPPED on every rank (weights and Adam moments '
+            'untouched).  Later steps run one launch per layer.'
+            % (f'{lost} workgroup(s) of this rank' if local else 'workgroups of another rank'))
 
 
 def srnet_body(tape, srnet, lr, tran):
@@ -399,8 +421,8 @@ def srnet_body(tape, srnet, lr, tran):
     fw = (L.PackedLayer * nl)()
     layout = 16 if _ChainState.parts(n, h, w) == 4 else 64
     # all 2 x (1 + 2nb) packs (forward, data gradient) of the body by two launches, cached on the network
-    # until a parameter changes (every layer is updated by the same optimiser step: first and last are checked)
-    ver = (_ver(layers[0].weight), _ver(layers[-1].weight), layout, c_lr)
+    # until a parameter changes
+    ver = (tuple(_ver(m.weight) for m in layers), layout, c_lr)      # every layer: a partial load / freeze must re-pack too
 
     def build():
         ws = [m.weight.detach() for m in layers]

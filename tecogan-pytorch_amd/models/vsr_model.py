@@ -47,7 +47,7 @@ class VSRModel(BaseModel):
         out = self.net_G(self.lr_data)
         tape = self.net_G.tape
         self.hr_data = out['hr_data']
-        losses = torch.zeros(2, dtype=torch.float32, device=self.device)
+        losses = torch.zeros(3, dtype=torch.float32, device=self.device)     # [pixel, warp, fault slot]
         pix_w = self.opt['train']['pixel_crit'].get('weight', 1.0)
         tape.add_grad(out['hr_data'], self._crit(self.pix_crit, out['hr_data'],
                                                  self.gt_data.contiguous(), pix_w, losses[0:1]))
@@ -57,10 +57,13 @@ class VSRModel(BaseModel):
             tape.add_grad(lr_warp, self._crit(self.warp_crit, lr_warp, out['lr_curr'], warp_w,
                                               losses[1:2]))
         tape.backward()
+        TG.stamp_fault(self.optim_G)                 # a chained-launch fault (any rank) turns the step into a no-op
         self.allreduce_grads(self.net_G, 'G')
         self.optim_G.step()
+        if getattr(self.optim_G, 'fault_slot', None) is not None:
+            losses[2:3].copy_(self.optim_G.fault_slot)
         vals = losses.tolist()                       # the iteration's only host sync
-        TG.chain_check()        # fail-safe of the chained launches (a host read of a pinned counter)
+        TG.chain_check(vals[2])  # fail-safe of the chained launches: raises on EVERY rank, the update was dropped
         self.log_dict = OrderedDict(l_pix_G=vals[0])
         if self.warp_crit is not None:
             self.log_dict['l_warp_G'] = vals[1]

@@ -110,7 +110,7 @@ class VSRGANModel(VSRModel):
         (fake_pred, _), _ = self.net_D(hr_data, d_in)        # no input grad: == hr_data.detach()
 
         n_clip = real_pred.numel()
-        scal = torch.zeros(14, dtype=torch.float32, device=self.device)   # every scalar of the step
+        scal = torch.zeros(15, dtype=torch.float32, device=self.device)   # every scalar of the step (+ the fault slot)
         st_real, st_fake, st_g, losses = scal[0:3], scal[3:6], scal[6:9], scal[9:14]
         red = self.gan_crit[1]
         gsc = (1.0 / n_clip) if red == 'mean' else 1.0
@@ -132,6 +132,7 @@ class VSRGANModel(VSRModel):
             tape_D.backward()
             # D's gradient all-reduce runs on RCCL's stream while the D-independent generator
             # losses below are evaluated on the compute stream
+            TG.stamp_fault(self.optim_D)
             bucket_D = self.start_grad_exchange(self.net_D)
         tape_D.nodes, tape_D.grads = [], {}
 
@@ -182,12 +183,15 @@ class VSRGANModel(VSRModel):
         tape_G.add_grad(fake_pred_G, ops.bce_logits(fake_pred_G, 1.0, st_g, 1.0 / n_clip,
                                                     grad_scale=gan_w * gsc))
         tape_G.backward()
+        TG.stamp_fault(self.optim_G)                 # a chained-launch fault (any rank) turns the step into a no-op
         self.allreduce_grads(self.net_G, 'G')
         self.optim_G.step()
+        if getattr(self.optim_G, 'fault_slot', None) is not None:
+            scal[14:15].copy_(self.optim_G.fault_slot)
 
         # === logging: one host read of all scalars ===
         sc_ = scal.tolist()
-        TG.chain_check()        # fail-safe of the chained launches (a host read of a pinned counter)
+        TG.chain_check(sc_[14])  # fail-safe of the chained launches: raises on EVERY rank, G's update was dropped
         sr, sf, sg, ls = sc_[0:3], sc_[3:6], sc_[6:9], sc_[9:14]
         self.log_dict = OrderedDict()
         self.log_dict['l_gan_D'] = (sr[0] + sf[0]) if upd_D else 0.0

@@ -722,10 +722,23 @@ def bce_logits(x, target, stats3, scale, grad_scale=None):
     return dx
 
 
-def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step):
+def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, skip=None):
+    """torch.optim.Adam step in place; `skip`: a device float -- non-zero turns the step into a no-op
+    (the fault slot of the flat gradient buffer, see tg_adam_step_guarded)."""
+    if skip is not None:
+        L.check(L.lib().tg_adam_step_guarded(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                             float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                             float(weight_decay), int(step), skip.data_ptr(), _stream()),
+                'tg_adam_step_guarded')
+        return
     L.check(L.lib().tg_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                                  float(lr), float(betas[0]), float(betas[1]), float(eps),
                                  float(weight_decay), int(step), _stream()), 'tg_adam_step')
+
+
+def fault_to_slot(err_pinned, slot):
+    """slot += 1 if the pinned int32 fault counter is non-zero (one thread; device-side read of host memory)."""
+    L.check(L.lib().tg_fault_to_slot(err_pinned.data_ptr(), slot.data_ptr(), _stream()), 'tg_fault_to_slot')
 
 
 def axpy_(y, x, a=1.0):

@@ -4,6 +4,8 @@ against the CPU oracle.  Tolerances: losses 2e-4 relative; gradient digests
 (L2 norm / sum / three samples per tensor) 1e-2 relative to the gradient
 norm -- BPTT through 7 frames x 45 layers in fp32 with atomics in the warp /
 up-sample transposes; parameter digests a few Adam sign flips (2*lr each)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -174,3 +176,90 @@ def test_resume_from_weights_and_optimizer_state(tmp_path):
         d = (pa[k] - pc[k]).abs().max().item()
         assert d <= 2.5e-4, (k, d)          # a few Adam sign flips of 1e-4 at most
     assert abs(a.log_dict['l_pix_G'] - c.log_dict['l_pix_G']) <= 1e-5
+
+
+# ---------------------------------------------------- fail-safe of the chained launches in training
+def test_guarded_adam_step_and_fault_slot():
+    """tg_adam_step_guarded: a non-zero guard leaves weights and both moments untouched, a zero guard is the
+    plain step bit for bit; tg_fault_to_slot adds 1 to the slot iff the (pinned) fault counter is non-zero."""
+    import tecogan_pytorch_amd.ops as ops
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(5000, generator=g).cuda()
+    gr = torch.randn(5000, generator=g).cuda()
+    args = (1e-3, (0.9, 0.999), 1e-8, 0.0, 1)
+    ref = [p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)]
+    ops.adam_step(ref[0], gr, ref[1], ref[2], *args)
+    for guard, moved in ((0.0, True), (1.0, False), (3.0, False)):
+        q = [p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)]
+        ops.adam_step(q[0], gr, q[1], q[2], *args, skip=torch.tensor([guard], device='cuda'))
+        if moved:
+            assert all(torch.equal(a, b) for a, b in zip(q, ref))
+        else:
+            assert torch.equal(q[0], p0) and not q[1].any() and not q[2].any()
+    err = torch.zeros(16, dtype=torch.int32).pin_memory()
+    slot = torch.zeros(1, device='cuda')
+    ops.fault_to_slot(err, slot); torch.cuda.synchronize()
+    assert slot.item() == 0.0
+    err[0] = 7
+    ops.fault_to_slot(err, slot); ops.fault_to_slot(err, slot); torch.cuda.synchronize()
+    assert slot.item() == 2.0
+
+
+def test_training_step_with_chain_fault_drops_the_update_and_raises():
+    """A chained-launch fault during a training iteration (injected: negative poll limit) must NOT reach the
+    weights: the generator's Adam step is a no-op on the device (fault slot of the gradient bucket), the
+    iteration raises after its host sync, and the next iteration runs one launch per layer from the
+    unchanged weights.  (the check used to run after the optimiser step.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from tests.test_hip_train import make_opt\n"
+        "from procedural_weights import smooth_clip\n"
+        "from tecogan_pytorch_amd.models import define_model, train_graph as TG\n"
+        "from tecogan_pytorch_amd import _lib\n"
+        "from procedural_weights import generator_state_dict\n"
+        "opt = make_opt('FRVSR'); opt['dataset']['train']['crop_size'] = 128     # 2 x 32 x 32 LR frames: the chained body's production shape\n"
+        "m = define_model(opt)\n"
+        "m.net_G.load_state_dict(generator_state_dict(scale=4, degradation='BD'), strict=True)\n"
+        "m.prepare_training_data({'gt': torch.stack([smooth_clip(4, 3, 136, 136, seed=11 + i, shift=1.0) for i in range(2)])})\n"
+        "m.train()                                   # a clean iteration (chained body in use)\n"
+        "assert not TG._ChainState.disabled and TG._ChainState.err is not None\n"
+        "before = {k: v.detach().clone() for k, v in m.net_G.state_dict().items()}\n"
+        "mom = [(a.clone(), b.clone()) for a, b in (m.optim_G.state[id(p)] for p in m.optim_G.params)]\n"
+        "TG._ChainState.poll_limit = -1               # every waiting workgroup gives up at once\n"
+        "try:\n"
+        "    m.train(); raise SystemExit('no error reported')\n"
+        "except _lib.TecoganHipError as e:\n"
+        "    assert 'DROPPED' in str(e) and 'timed out' in str(e), str(e)\n"
+        "after = m.net_G.state_dict()\n"
+        "assert all(torch.equal(before[k], after[k]) for k in before), 'weights moved although the step faulted'\n"
+        "assert all(torch.equal(a, c) and torch.equal(b, d) for (a, b), (c, d) in zip(mom, (m.optim_G.state[id(p)] for p in m.optim_G.params))), 'Adam moments moved'\n"
+        "assert TG._ChainState.disabled\n"
+        "TG._ChainState.poll_limit = 1 << 21\n"
+        "m.train()                                   # one launch per layer from the unchanged weights\n"
+        "assert any(not torch.equal(before[k], v) for k, v in m.net_G.state_dict().items())\n"
+        "print('DROP-OK')\n" % (root, os.path.join(root, 'tests', 'golden')))
+    r = subprocess.run([sys.executable, '-c', script], timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0 and 'DROP-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_deep_body_runs_without_the_chained_launch():
+    """nb is a free yml parameter in the reference (tecogan_nets.py:108-116): a 12-block body exceeds the
+    chained launch's 24 layers and must take the per-layer path instead of raising."""
+    from tecogan_pytorch_amd.models import train_graph as TG
+    from tecogan_pytorch_amd.models.networks import FRNet
+    assert TG._ChainState.usable(2, 64, 51, 32, 32, 11) or TG._ChainState.disabled
+    assert not TG._ChainState.usable(2, 64, 51, 32, 32, 12)
+    torch.manual_seed(0)
+    net = FRNet(3, 3, 64, 12, 'BD', 4).cuda().train()
+    lr = torch.rand(2, 3, 3, 32, 32, device='cuda')
+    out = net(lr)
+    tape = net.tape
+    tape.add_grad(out['hr_data'], torch.ones_like(out['hr_data']))
+    tape.backward()
+    torch.cuda.synchronize()
+    TG.chain_check()
+    g = net.srnet.resblocks[11].conv['2'].weight.grad
+    assert out['hr_data'].shape == (2, 3, 3, 128, 128) and g is not None and torch.isfinite(g).all() and g.abs().sum() > 0

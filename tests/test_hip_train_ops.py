@@ -588,7 +588,7 @@ def test_srnet_body_chain_fault_is_reported_and_falls_back(ops):
         "from tecogan_pytorch_amd import _lib\n"
         "net = _srnet(2)\n"
         "lr, tran = dev(rs(1, (2, 3, 32, 32), 0, 1)), dev(rs(2, (2, 48, 32, 32), 0, 1))\n"
-        "assert TG._ChainState.usable(2, 64, 51, 32, 32)\n"
+        "assert TG._ChainState.usable(2, 64, 51, 32, 32, 2)\n"
         "ref = TG.srnet_body(None, net, lr, tran).clone(); torch.cuda.synchronize(); TG.chain_check()\n"
         "TG._ChainState.poll_limit = -1\n"
         "bad = TG.srnet_body(None, net, lr, tran); torch.cuda.synchronize()\n"
@@ -596,7 +596,7 @@ def test_srnet_body_chain_fault_is_reported_and_falls_back(ops):
         "    TG.chain_check(); raise SystemExit('no error reported')\n"
         "except _lib.TecoganHipError as e:\n"
         "    assert 'timed out' in str(e)\n"
-        "assert not TG._ChainState.usable(2, 64, 51, 32, 32)\n"
+        "assert not TG._ChainState.usable(2, 64, 51, 32, 32, 2)\n"
         "out = net(lr, tran, tape=TG.Tape()); torch.cuda.synchronize(); TG.chain_check()\n"
         "print('BODY-FAILSAFE-OK')\n" % root)
     r = subprocess.run([sys.executable, '-c', script], timeout=600, capture_output=True, text=True)
