@@ -135,9 +135,15 @@ __device__ __forceinline__ void bilinear_src(int dst, int scale, int in_size,
 }
 
 // fp32 torch.linspace(-1, 1, n)[i] (ATen CPU: two fused multiply-adds)
+// Branch- and select-free form (round 4: v_cndmask_b32 costs ~23 cycles per wave instruction on gfx950,
+// tools/valu_lab.hip): with j = min(i, n-1-i) the second half is -fmaf(step, j, -1) -- round-to-nearest is
+// sign symmetric, so that is fmaf(-step, j, 1) bit for bit (but for the sign of an exact zero, which the
+// callers add 1 to) -- and the sign bit comes from the integer n/2 - 1 - i.
 __device__ __forceinline__ float linspace_m1p1(int i, int n, float step) {
-  return (i < n / 2) ? __builtin_fmaf(step, (float)i, -1.0f)
-                     : __builtin_fmaf(-step, (float)(n - 1 - i), 1.0f);
+  const int mirror = n - 1 - i;
+  const int j = i < mirror ? i : mirror;                                   // v_min_i32
+  const unsigned flip = (unsigned)(n / 2 - 1 - i) & 0x80000000u;           // i >= n/2
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, __builtin_fmaf(step, (float)j, -1.0f)) ^ flip);
 }
 
 // Sampling position of backward_warp along one axis (net_utils.py:62-78 +
@@ -147,8 +153,8 @@ __device__ __forceinline__ float warp_coord(int i, int n, float flow) {
   float half = (float)(n - 1) / 2.0f;
   float g = linspace_m1p1(i, n, step) + flow / half;
   float p = (g + 1.0f) * half;
-  p = p < 0.f ? 0.f : p;  // clip_coordinates; also maps NaN->0 like fmax
-  p = p > (float)(n - 1) ? (float)(n - 1) : p;
+  p = __builtin_fmaxf(p, 0.f);                       // clip_coordinates (v_max / v_min: no conditional moves)
+  p = __builtin_fminf(p, (float)(n - 1));
   return p;
 }
 

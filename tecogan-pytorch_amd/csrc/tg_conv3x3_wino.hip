@@ -327,7 +327,10 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
       float v0 = ((sr[i][0] + sr[i][1]) + sr[i][2]) + bz;
       float v1 = ((sr[i][1] - sr[i][2]) - sr[i][3]) + bz;
       if (a.act == TG_ACT_TANH24) { v0 = apply_act(v0, a.act); v1 = apply_act(v1, a.act); }
-      else { v0 = v0 >= 0.f ? v0 : v0 * slope; v1 = v1 >= 0.f ? v1 : v1 * slope; }
+      else {      // max(x, 0) + slope * min(x, 0): the piecewise-linear activations without v_cndmask (see tg_conv3x3_wino_res.hip)
+        v0 = __builtin_fmaf(slope, __builtin_fminf(v0, 0.f), __builtin_fmaxf(v0, 0.f));
+        v1 = __builtin_fmaf(slope, __builtin_fminf(v1, 0.f), __builtin_fmaxf(v1, 0.f));
+      }
       const size_t o = (size_t)oc * hw + (size_t)oy * a.w + ox;
       const bool two = ox + 1 < a.w;
       if (a.vec_ok) {

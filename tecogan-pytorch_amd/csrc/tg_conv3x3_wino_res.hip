@@ -285,8 +285,10 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
         for (int i = 0; i < 2; ++i) {
           float v0 = ((sr[i][0] + sr[i][1]) + sr[i][2]) + bz[r];
           float v1 = ((sr[i][1] - sr[i][2]) - sr[i][3]) + bz[r];
-          v0 = v0 >= 0.f ? v0 : v0 * slope;
-          v1 = v1 >= 0.f ? v1 : v1 * slope;
+          // x >= 0 ? x : x * slope without a conditional move (v_cndmask_b32: ~23 cycles per wave instruction
+          // on gfx950, tools/valu_lab.hip): max(x, 0) + slope * min(x, 0) -- same value for every finite x
+          v0 = __builtin_fmaf(slope, __builtin_fminf(v0, 0.f), __builtin_fmaxf(v0, 0.f));
+          v1 = __builtin_fmaf(slope, __builtin_fminf(v1, 0.f), __builtin_fmaxf(v1, 0.f));
           if constexpr (RES) {                // the residual input: what the destination buffer still holds
             v0 += dst[wb + r * WR_CS + i * WR_RS];
             v1 += dst[wb + r * WR_CS + i * WR_RS + 1];

@@ -19,8 +19,9 @@ namespace tg {
 
 // row / column of the reflect-padded (bottom/right) flow -> source index.
 // F.pad(..., 'reflect') at tecogan_nets.py:241: padded index fh+k mirrors fh-2-k.
-__device__ __forceinline__ int reflect_src(int i, int f) { return i < f ? i : 2 * f - 2 - i; }
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// (min / max forms: integer v_min / v_max instead of compare + conditional move)
+__device__ __forceinline__ int reflect_src(int i, int f) { const int m = 2 * f - 2 - i; return i < m ? i : m; }   // i < f <=> i <= m
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return max(lo, min(v, hi)); }
 
 // bilinear tap gather with grid_sample's out-of-bounds-is-zero rule
 __device__ __forceinline__ float warp_sample(const float* __restrict__ img, int h, int w,
@@ -77,8 +78,8 @@ __device__ __forceinline__ float warp_coord_c(int i, int n, float flow, float st
                                               float rhalf) {
   float g = linspace_m1p1(i, n, step) + div_const(flow, half, rhalf);
   float p = (g + 1.0f) * half;
-  p = p < 0.f ? 0.f : p;
-  p = p > (float)(n - 1) ? (float)(n - 1) : p;
+  p = __builtin_fmaxf(p, 0.f);
+  p = __builtin_fminf(p, (float)(n - 1));
   return p;
 }
 
@@ -285,13 +286,25 @@ __global__ __launch_bounds__(128 * (R / RPT)) void flowup_warp_s2d_kernel(FusedA
         const int ix = (int)fx0, iy = (int)fy0;
         ixy[e][0] = ix; ixy[e][1] = iy;
         o0[e] = ((unsigned)iy * WW + ix) * 4u;
-        o1[e] = o0[e] + (iy + 1 <= HH - 1 ? (unsigned)WW * 4u : 0u);
+        o1[e] = o0[e] + (unsigned)(min(iy + 1, HH - 1) - iy) * ((unsigned)WW * 4u);   // next row, or the same one at the border (weight 0)
         w00[e] = wy0 * wx0; w01[e] = wy0 * wx1; w10[e] = wy1 * wx0; w11[e] = wy1 * wx1;
       }
       // pixel b's taps lie inside pixel a's 16-byte lanes when both sample the same source
       // row and b starts 0..2 elements to the right (the usual case for a smooth flow)
       const int d = ixy[1][0] - ixy[0][0];
       const bool shared = ixy[1][1] == ixy[0][1] && (unsigned)d <= 2u;
+      // Element d, d + 1 of the shared 16-byte lane by BIT masks, not by conditional moves: v_cndmask_b32
+      // costs ~23 cycles per wave instruction on gfx950 against ~5 for v_bfi_b32 (tools/valu_lab.hip), and
+      // the 12 three-way selects per channel pair were half of this kernel's VALU time (round 4).
+      // m1 / m2 = all ones when d == 1 / d == 2 (d outside 0..2: the lane is not shared, vb is redone below)
+      unsigned m1 = 0u - ((unsigned)d & 1u), m2 = 0u - (((unsigned)d >> 1) & 1u);
+      asm volatile("" : "+v"(m1), "+v"(m2));          // opaque: the compiler turns known 0 / ~0 masks back into v_cndmask
+      auto pick = [&](float e0, float e1, float e2) {     // v_bfi_b32 d, m, a, b = (m & a) | (~m & b): one instruction per step
+        float r;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m1), "v"(e1), "v"(e0));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m2), "v"(e2), "v"(r));
+        return r;
+      };
       float va[C], vb[C];
 #pragma unroll
       for (int ch = 0; ch < C; ++ch) {
@@ -299,10 +312,10 @@ __global__ __launch_bounds__(128 * (R / RPT)) void flowup_warp_s2d_kernel(FusedA
         const f32x4 t4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (int)o0[0], (int)pl, 0));
         const f32x4 b4 = (TG_WARP_ABL & 2) ? t4 : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (int)o1[0], (int)pl, 0));
         va[ch] = ((t4[0] * w00[0] + t4[1] * w01[0]) + b4[0] * w10[0]) + b4[1] * w11[0];
-        const float t0 = d == 0 ? t4[0] : (d == 1 ? t4[1] : t4[2]);
-        const float t1 = d == 0 ? t4[1] : (d == 1 ? t4[2] : t4[3]);
-        const float b0 = d == 0 ? b4[0] : (d == 1 ? b4[1] : b4[2]);
-        const float b1 = d == 0 ? b4[1] : (d == 1 ? b4[2] : b4[3]);
+        const float t0 = pick(t4[0], t4[1], t4[2]);
+        const float t1 = pick(t4[1], t4[2], t4[3]);
+        const float b0 = pick(b4[0], b4[1], b4[2]);
+        const float b1 = pick(b4[1], b4[2], b4[3]);
         vb[ch] = ((t0 * w00[1] + t1 * w01[1]) + b0 * w10[1]) + b1 * w11[1];
       }
       if (!shared) {

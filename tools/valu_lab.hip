@@ -37,6 +37,10 @@ __global__ void k(float* out, int iters) {
       if (MODE == 2) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[i & 15]) : "v"(b));
       if (MODE == 3) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(w[i & 7]) : "v"(w[(i + 1) & 7]));
       if (MODE == 4) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i & 15]) : "v"(b));
+      if (MODE == 6) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(v[i & 15]) : "v"(b), "v"(a));
+      if (MODE == 7) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(v[i & 15]) : "v"(b), "v"(a));
+      if (MODE == 8) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[i & 15]) : "v"(b));
+      if (MODE == 9) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i & 15]) : "v"(b));
     }
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -78,18 +82,12 @@ void run(const char* name, float* out) {
 int main() {
   float* out;
   hipMalloc(&out, 256 * 768 * 4);
-  run<16, 0, 0, 0>("16 MFMA", out);
   run<0, 32, 0, 0>("32 v_add", out);
-  run<0, 32, 1, 0>("32 v_pk_add", out);
+  run<0, 32, 4, 0>("32 v_cndmask vcc (e32)", out);
+  run<0, 32, 6, 0>("32 v_and_or_b32", out);
+  run<0, 32, 7, 0>("32 v_bfi_b32", out);
+  run<0, 32, 8, 0>("32 v_mul_f32", out);
+  run<0, 32, 9, 0>("32 v_mov_b32", out);
   run<0, 32, 2, 0>("32 v_fma", out);
-  run<0, 32, 3, 0>("32 v_pk_fma", out);
-  run<0, 32, 4, 0>("32 v_cndmask", out);
-  run<16, 32, 0, 0>("16 MFMA + 32 v_add", out);
-  run<16, 64, 0, 0>("16 MFMA + 64 v_add", out);
-  run<16, 32, 1, 0>("16 MFMA + 32 v_pk_add", out);
-  run<16, 16, 1, 0>("16 MFMA + 16 v_pk_add", out);
-  run<0, 0, 0, 8>("8 ds_read_b64 (each waited)", out);
-  run<16, 0, 0, 8>("16 MFMA + 8 ds_read_b64", out);
-  run<16, 32, 0, 8>("16 MFMA + 32 v_add + 8 ds_read", out);
   return 0;
 }
