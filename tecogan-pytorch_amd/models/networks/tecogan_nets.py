@@ -657,12 +657,12 @@ class DiscriminatorBlocks(nn.Module):
         for i, (ci, co) in enumerate([(64, 64), (64, 64), (64, 128), (128, 256)], 1):
             setattr(self, f'block{i}', _block([(0, _Conv4(ci, co)), (1, _BN(co))]))
 
-    def forward(self, x, tape, need_dx):
+    def forward(self, x, tape, need_dx, groups=1):
         feats = []
         for i in range(1, 5):
             blk = getattr(self, f'block{i}')
             x = TG.conv4x4s2(tape, blk['0'], x, need_dx=True)   # conv_in below it has parameters
-            x = TG.bn_lrelu(tape, blk['1'], x, need_dx=True)
+            x = TG.bn_lrelu(tape, blk['1'], x, need_dx=True, groups=groups)
             feats.append(x)
         return x, feats
 
@@ -687,9 +687,55 @@ class SpatioTemporalDiscriminator(nn.Module):
     def forward(self, data, args_dict):
         return self.forward_sequence(data, args_dict)
 
+    def forward_pair(self, data_a, data_b, args_dict):
+        """The two critic passes of the D update -- real, then fake (vsrgan_model.py:137-153; neither needs a
+        gradient to its input) -- as ONE pass over the stacked clip batch [a | b]: every convolution, its data
+        and weight gradients and the dense layer run once on 2 n_clip clips (12-clip batches of 8x8 .. 64x64
+        maps leave most of the GPU idle), BatchNorm keeps SEPARATE batch statistics per half and updates the
+        running statistics a-then-b as the reference's two passes do, and under data parallelism each layer
+        needs one statistics exchange instead of two.  Returns ((logits (2 n_clip, 1), feats), ret_dict):
+        rows [:n_clip] belong to data_a."""
+        tape = args_dict.get('tape')
+        lr_data = args_dict['lr_data']
+        n_clip = lr_data.size(0) * (lr_data.size(1) // 3)
+        hr_h, hr_w = data_a.shape[3:]
+        x = torch.empty(2 * n_clip, 9 * lr_data.size(2), hr_h, hr_w, dtype=torch.float32, device=data_a.device)
+        # (both halves are assembled straight into the pair batch; the flow triplets are built once)
+        _, ret = self._assemble(data_a, args_dict, None, False, out=x[:n_clip])
+        d2 = dict(args_dict)
+        d2.update(ret)
+        self._assemble(data_b, d2, None, False, out=x[n_clip:])
+        out = TG.conv3x3(tape, self.conv_in['0'], x, TG.LRELU, need_dx=False)
+        out, feats = self.discriminator_block(out, tape, False, groups=2)
+        flat = out.reshape(out.size(0), -1)
+        if tape is not None:
+            def flat_bwd():
+                g = tape.pop_grad(flat)
+                if g is not None:
+                    tape.add_grad(out, g.view_as(out))
+            tape.record(flat_bwd)
+        logits = TG.linear1(tape, self.dense, flat, need_dx=True)
+        return (logits, feats), ret
+
     def forward_sequence(self, data, args_dict):
         tape = args_dict.get('tape')
         need_in = bool(args_dict.get('need_input_grad', False))
+        x, ret = self._assemble(data, args_dict, tape, need_in)
+        out = TG.conv3x3(tape, self.conv_in['0'], x, TG.LRELU, need_dx=need_in)
+        out, feats = self.discriminator_block(out, tape, need_in)
+        flat = out.reshape(out.size(0), -1)
+        if tape is not None:
+            def flat_bwd():        # recorded before the linear node => runs right after it
+                g = tape.pop_grad(flat)
+                if g is not None:
+                    tape.add_grad(out, g.view_as(out))
+            tape.record(flat_bwd)
+        logits = TG.linear1(tape, self.dense, flat, need_dx=True)
+        return (logits, feats), ret
+
+    def _assemble(self, data, args_dict, tape, need_in, out=None):
+        """The critic's input of one pass: flow triplets, warped frames, channel assembly
+        (tecogan_nets.py:384-463) -> (x (n_clip, 27, H, W), {'hr_flow_merge': ...})."""
         lr_data, bi_data, hr_flow = args_dict['lr_data'], args_dict['bi_data'], args_dict['hr_flow']
         n, t, c, lr_h, lr_w = lr_data.size()
         hr_h, hr_w = data.shape[3:]
@@ -746,7 +792,7 @@ class SpatioTemporalDiscriminator(nn.Module):
             tape.record(frames_bwd)
         warped = TG.backward_warp(tape if track else None, frames, hr_flow_merge,
                                   need_dimg=True, need_dflow=False)
-        x = ops.d_assemble_fwd(data, warped, bi_data, t, n_pad, c_size)
+        x = ops.d_assemble_fwd(data, warped, bi_data, t, n_pad, c_size, out=out)
 
         if track:
             def assemble_bwd():
@@ -756,18 +802,7 @@ class SpatioTemporalDiscriminator(nn.Module):
                 held['g_data'], g_warped = ops.d_assemble_bwd(g, n, t, t_data, c, n_pad, c_size)
                 tape.add_grad(warped, g_warped)
             tape.record(assemble_bwd)
-
-        out = TG.conv3x3(tape, self.conv_in['0'], x, TG.LRELU, need_dx=need_in)
-        out, feats = self.discriminator_block(out, tape, need_in)
-        flat = out.reshape(out.size(0), -1)
-        if tape is not None:
-            def flat_bwd():        # recorded before the linear node => runs right after it
-                g = tape.pop_grad(flat)
-                if g is not None:
-                    tape.add_grad(out, g.view_as(out))
-            tape.record(flat_bwd)
-        logits = TG.linear1(tape, self.dense, flat, need_dx=True)
-        return (logits, feats), {'hr_flow_merge': hr_flow_merge}
+        return x, {'hr_flow_merge': hr_flow_merge}
 
 
 class SpatialDiscriminator(nn.Module):

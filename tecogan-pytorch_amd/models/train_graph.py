@@ -764,11 +764,50 @@ def _distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def bn_lrelu(tape, bn, x, need_dx=True, sync=None):
+def bn_lrelu(tape, bn, x, need_dx=True, sync=None, groups=1):
     """BatchNorm2d (train mode) + LeakyReLU(0.2); bn holds weight/bias/running stats.
-    Under torch.distributed (or sync=True) the statistics are global (SyncBatchNorm)."""
+    Under torch.distributed (or sync=True) the statistics are global (SyncBatchNorm).
+    groups > 1: x stacks that many INDEPENDENT batches along n (the critic's real + fake pair pass):
+    batch statistics per group, the running statistics updated group after group -- exactly what the
+    reference's separate passes do -- and, data parallel, ONE collective per layer for all groups."""
     if sync is None:
         sync = _distributed()
+    n = x.shape[0]
+    if groups > 1:
+        assert n % groups == 0
+        per = n // groups
+        if sync:
+            y, stats = ops.sync_bn_lrelu_train_fwd_groups(x, groups, bn.weight, bn.bias, bn.running_mean,
+                                                          bn.running_var)
+        else:
+            y, stats = torch.empty_like(x), []
+            for g in range(groups):
+                _, mean, invstd = ops.bn_lrelu_train_fwd(x[g * per:(g + 1) * per], bn.weight, bn.bias,
+                                                         bn.running_mean, bn.running_var,
+                                                         out=y[g * per:(g + 1) * per])
+                stats.append((mean, invstd, None))
+        for _ in range(groups):
+            bn.count_pass() if hasattr(bn, 'count_pass') else bn.num_batches_tracked.add_(1)
+        if tape is not None:
+            def bwd_groups():
+                g_ = tape.pop_grad(y)
+                if g_ is None:
+                    return
+                train = bn.weight.requires_grad
+                gw = _grad_buf(bn.weight) if train else None
+                gb = _grad_buf(bn.bias) if train else None
+                if sync:
+                    dx = ops.sync_bn_lrelu_train_bwd_groups(x, y, g_, groups, bn.weight, stats, gw, gb, need_dx)
+                else:
+                    dx = torch.empty_like(x) if need_dx else None
+                    for g in range(groups):
+                        sl = slice(g * per, (g + 1) * per)
+                        ops.bn_lrelu_train_bwd(x[sl], y[sl], g_[sl], bn.weight, stats[g][0], stats[g][1], gw, gb,
+                                               need_dx, dx_out=dx[sl] if need_dx else None)
+                if need_dx:
+                    tape.add_grad(x, dx)
+            tape.record(bwd_groups)
+        return y
     if sync:
         y, mean, invstd, count = ops.sync_bn_lrelu_train_fwd(x, bn.weight, bn.bias, bn.running_mean,
                                                              bn.running_var)

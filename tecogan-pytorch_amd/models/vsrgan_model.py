@@ -32,6 +32,9 @@ class VSRGANModel(VSRModel):
     def set_criterions(self):
         """vsrgan_model.py:50-72."""
         tr = self.opt['train']
+        # the critic's real and fake pass of the D update as one stacked pass (SpatioTemporalDiscriminator.forward_pair);
+        # `train.discriminator.pair_pass: false` selects the reference's two separate passes
+        self.pair_pass = bool(tr.get('discriminator', {}).get('pair_pass', True))
         self.pix_crit = define_criterion(tr.get('pixel_crit'))
         self.warp_crit = define_criterion(tr.get('warping_crit'))
         self.feat_crit = define_criterion(tr.get('feature_crit'))
@@ -105,17 +108,29 @@ class VSRGANModel(VSRModel):
         d_in.update(out)
         tape_D = TG.Tape()
         d_in['tape'] = tape_D
-        (real_pred, real_feats), d_out = self.net_D(gt_data, d_in)
-        d_in.update(d_out)
-        (fake_pred, _), _ = self.net_D(hr_data, d_in)        # no input grad: == hr_data.detach()
+        pair = getattr(self.net_D, 'forward_pair', None) if self.pair_pass else None
+        if pair is not None:
+            # real and fake pass as ONE pass over the stacked batch (per-half BatchNorm statistics)
+            (pair_pred, pair_feats), d_out = pair(gt_data, hr_data, d_in)
+            d_in.update(d_out)
+            n_clip = pair_pred.shape[0] // 2
+            real_pred, fake_pred = pair_pred[:n_clip], pair_pred[n_clip:]
+            real_feats = [f[:n_clip] for f in pair_feats]
+        else:
+            (real_pred, real_feats), d_out = self.net_D(gt_data, d_in)
+            d_in.update(d_out)
+            (fake_pred, _), _ = self.net_D(hr_data, d_in)        # no input grad: == hr_data.detach()
+            n_clip = real_pred.numel()
 
-        n_clip = real_pred.numel()
         scal = torch.zeros(15, dtype=torch.float32, device=self.device)   # every scalar of the step (+ the fault slot)
         st_real, st_fake, st_g, losses = scal[0:3], scal[3:6], scal[6:9], scal[9:14]
         red = self.gan_crit[1]
         gsc = (1.0 / n_clip) if red == 'mean' else 1.0
-        g_real = ops.bce_logits(real_pred, 1.0, st_real, 1.0 / n_clip, grad_scale=gsc)
-        g_fake = ops.bce_logits(fake_pred, 0.0, st_fake, 1.0 / n_clip, grad_scale=gsc)
+        g_pair = torch.empty_like(pair_pred) if pair is not None else None
+        g_real = ops.bce_logits(real_pred, 1.0, st_real, 1.0 / n_clip, grad_scale=gsc,
+                                dx_out=None if g_pair is None else g_pair[:n_clip])
+        g_fake = ops.bce_logits(fake_pred, 0.0, st_fake, 1.0 / n_clip, grad_scale=gsc,
+                                dx_out=None if g_pair is None else g_pair[n_clip:])
 
         update_policy = opt_tr['discriminator']['update_policy']
         if update_policy == 'adaptive':
@@ -127,8 +142,11 @@ class VSRGANModel(VSRModel):
         bucket_D = None
         if upd_D:
             self.cnt_upd_D += 1.0
-            tape_D.add_grad(real_pred, g_real)
-            tape_D.add_grad(fake_pred, g_fake)
+            if g_pair is not None:
+                tape_D.add_grad(pair_pred, g_pair)
+            else:
+                tape_D.add_grad(real_pred, g_real)
+                tape_D.add_grad(fake_pred, g_fake)
             tape_D.backward()
             # D's gradient all-reduce runs on RCCL's stream while the D-independent generator
             # losses below are evaluated on the compute stream

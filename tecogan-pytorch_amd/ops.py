@@ -713,9 +713,9 @@ def cosine_loss(a, b, loss_accum, loss_scale, grad_scale=None, eps=1e-8):
     return da
 
 
-def bce_logits(x, target, stats3, scale, grad_scale=None):
+def bce_logits(x, target, stats3, scale, grad_scale=None, dx_out=None):
     _chk(x, 'x')
-    dx = torch.empty_like(x) if grad_scale is not None else None
+    dx = (dx_out if dx_out is not None else torch.empty_like(x)) if grad_scale is not None else None
     L.check(L.lib().tg_bce_logits(x.data_ptr(), x.numel(), float(target), float(scale),
                                   _ptr(stats3), float(grad_scale or 0.0), _ptr(dx), _stream()),
             'tg_bce_logits')
@@ -755,10 +755,10 @@ def div_scalar_(y, d, x=None):
     return y
 
 
-def bn_lrelu_train_fwd(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, slope=0.2):
+def bn_lrelu_train_fwd(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, slope=0.2, out=None):
     _chk(x, 'x')
     n, c, h, w = x.shape
-    y = torch.empty_like(x)
+    y = out if out is not None else torch.empty_like(x)
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     invstd = torch.empty(c, dtype=torch.float32, device=x.device)
     L.check(L.lib().tg_bn_lrelu_train_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
@@ -770,9 +770,9 @@ def bn_lrelu_train_fwd(x, gamma, beta, running_mean, running_var, momentum=0.1, 
 
 
 def bn_lrelu_train_bwd(x, y, dy, gamma, mean, invstd, dgamma=None, dbeta=None, need_dx=True,
-                       slope=0.2):
+                       slope=0.2, dx_out=None):
     n, c, h, w = x.shape
-    dx = torch.empty_like(x) if need_dx else None
+    dx = (dx_out if dx_out is not None else torch.empty_like(x)) if need_dx else None
     scratch = torch.empty(2 * c, dtype=torch.float32, device=x.device)
     L.check(L.lib().tg_bn_lrelu_train_bwd(x.data_ptr(), y.data_ptr(), dy.data_ptr(), gamma.data_ptr(),
                                           mean.data_ptr(), invstd.data_ptr(), float(slope), _ptr(dx),
@@ -874,6 +874,68 @@ def sync_bn_lrelu_train_bwd(x, y, dy, gamma, mean, invstd, count, dgamma=None, d
     return dx
 
 
+def sync_bn_lrelu_train_fwd_groups(x, groups, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5,
+                                   slope=0.2):
+    """SyncBatchNorm + LeakyReLU of `groups` INDEPENDENT batches stacked along n (the critic's real and fake
+    pass run as one pair batch, vsrgan_model.py:137-153): statistics per group, ONE all-gather of
+    groups x 2c floats per layer instead of one per pass, running statistics updated group after group (the
+    order of the reference's separate passes).  Returns y and per-group (mean, invstd, count)."""
+    from .utils import dist_utils
+    _chk(x, 'x')
+    n, c, h, w = x.shape
+    per = n // groups
+    lib = L.lib()
+    local = torch.empty(groups * 2 * c, dtype=torch.float32, device=x.device)
+    for g in range(groups):
+        L.check(lib.tg_bn_local_stats(x[g * per:(g + 1) * per].data_ptr(), local[g * 2 * c:].data_ptr(), per, c, h * w,
+                                      _stream()), 'tg_bn_local_stats')
+    gathered = dist_utils.all_gather_flat(local)                     # (world, groups * 2c)
+    world = gathered.shape[0]
+    count = float(per * h * w * world)
+    y = torch.empty_like(x)
+    stats = []
+    for g in range(groups):
+        part = gathered[:, g * 2 * c:(g + 1) * 2 * c].contiguous()
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        L.check(lib.tg_bn_merge_stats(part.data_ptr(), world, float(per * h * w), float(eps), float(momentum),
+                                      mean.data_ptr(), invstd.data_ptr(), _ptr(running_mean), _ptr(running_var), c,
+                                      _stream()), 'tg_bn_merge_stats')
+        L.check(lib.tg_bn_lrelu_apply(x[g * per:(g + 1) * per].data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                      gamma.data_ptr(), beta.data_ptr(), float(slope), y[g * per:(g + 1) * per].data_ptr(),
+                                      per, c, h * w, _stream()), 'tg_bn_lrelu_apply')
+        stats.append((mean, invstd, count))
+    return y, stats
+
+
+def sync_bn_lrelu_train_bwd_groups(x, y, dy, groups, gamma, stats, dgamma=None, dbeta=None, need_dx=True, slope=0.2):
+    """Backward of sync_bn_lrelu_train_fwd_groups: ONE all-reduce of the groups x 2c sums per layer."""
+    from .utils import dist_utils
+    n, c, h, w = x.shape
+    per = n // groups
+    lib = L.lib()
+    sums = torch.empty(groups * 2 * c, dtype=torch.float32, device=x.device)
+    for g in range(groups):
+        sl = slice(g * per, (g + 1) * per)
+        L.check(lib.tg_bn_lrelu_bwd_reduce(x[sl].data_ptr(), y[sl].data_ptr(), dy[sl].data_ptr(), stats[g][0].data_ptr(),
+                                           stats[g][1].data_ptr(), float(slope), sums[g * 2 * c:].data_ptr(), per, c,
+                                           h * w, _stream()), 'tg_bn_lrelu_bwd_reduce')
+        if dgamma is not None:
+            axpy_(dgamma, sums[g * 2 * c + c:(g + 1) * 2 * c], 1.0)
+            axpy_(dbeta, sums[g * 2 * c:g * 2 * c + c], 1.0)
+    dist_utils.all_reduce_sum_(sums)
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        for g in range(groups):
+            sl = slice(g * per, (g + 1) * per)
+            L.check(lib.tg_bn_lrelu_bwd_apply(x[sl].data_ptr(), y[sl].data_ptr(), dy[sl].data_ptr(), stats[g][0].data_ptr(),
+                                              stats[g][1].data_ptr(), gamma.data_ptr(), sums[g * 2 * c:].data_ptr(),
+                                              float(slope), 1.0 / stats[g][2], dx[sl].data_ptr(), per, c, h * w,
+                                              _stream()), 'tg_bn_lrelu_bwd_apply')
+    return dx
+
+
 # ---- data movement of the training step (tg_assemble.hip) ---------------------------------
 def time_gather(x, idx):
     """x (n, t, ...) -> (n, len(idx), ...) with out[:, k] = x[:, idx[k]] (one launch)."""
@@ -904,12 +966,12 @@ def pingpong_grad(g, te):
     return out
 
 
-def d_assemble_fwd(data, warped, cond, t, pad, crop):
+def d_assemble_fwd(data, warped, cond, t, pad, crop, out=None):
     """Discriminator input (n*t/3, 9c, h, w) from data (n, T, c, h, w), warped (n*t, c, h, w),
-    cond (n, T', c, h, w)."""
+    cond (n, T', c, h, w); `out`: a contiguous (n*t/3, 9c, h, w) destination (half of a pair batch)."""
     _chk(data, 'data'); _chk(warped, 'warped'); _chk(cond, 'cond')
     n, t_data, c, h, w = data.shape
-    x = torch.empty(n * t // 3, 9 * c, h, w, dtype=torch.float32, device=data.device)
+    x = out if out is not None else torch.empty(n * t // 3, 9 * c, h, w, dtype=torch.float32, device=data.device)
     L.check(L.lib().tg_d_assemble_fwd(data.data_ptr(), t_data, warped.data_ptr(), cond.data_ptr(),
                                       cond.shape[1], x.data_ptr(), n, t, c, h, w, pad, crop, _stream()),
             'tg_d_assemble_fwd')
