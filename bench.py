@@ -817,6 +817,12 @@ def main():
                 result['roofline']['mfma_executed_frac'] = ach * 16.0 / 36.0 / MFMA_F32_PEAK_TFLOPS
                 # against the form's own ceiling (every MFMA issue slot busy = 157.3 x 36/16 algorithmic)
                 result['roofline']['frac_vs_winograd_ceiling'] = ach / (MFMA_F32_PEAK_TFLOPS * 2.25)
+                # `frac` is the share of the fp32-MFMA peak the kernel actually occupies (executed FLOPs): the
+                # algorithmic rate of a Winograd kernel may exceed the peak, and no line should print > 1
+                result['roofline']['frac_algorithmic'] = ach / MFMA_F32_PEAK_TFLOPS
+                result['roofline']['frac'] = result['roofline']['mfma_executed_frac']
+                result['roofline']['frac_is'] = ('executed MFMA FLOPs (16/36 of the algorithmic ones) / peak; `achieved` is the '
+                                                 'ALGORITHMIC rate of the 3x3 convolutions (SURVEY 8d) and may exceed `peak` in this form')
             warp = [r for r in rows if r['kernel'].startswith('flowup_warp')]
             if warp:
                 wk = warp[0]

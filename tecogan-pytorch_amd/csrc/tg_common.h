@@ -10,9 +10,9 @@
 #include "../../include/tecogan_hip.h"
 
 // Tuning / ablation switches read from the environment exist only in lab builds
-// (tools/build_lab_libs.sh, -DTG_LAB=1).  The shipped library reads exactly two variables,
-// both documented in INTEGRATION.md: TG_CONV_WINO and TG_WINO_CHAIN (kernel-form selection for
-// A/B runs; every setting produces reference-parity results).
+// (tools/build_lab_libs.sh, -DTG_LAB=1).  The shipped library reads exactly three variables,
+// all documented in INTEGRATION.md: TG_CONV_WINO, TG_WINO_CHAIN and TG_WINO_RES (kernel-form selection
+// for A/B runs; every setting produces reference-parity results).
 #ifndef TG_LAB
 #define TG_LAB 0
 #endif
