@@ -548,6 +548,10 @@ int tg_pixel_loss(const float* x, const float* y, int64_t n, int mode, float los
  * dx = grad_scale * (sigmoid(x) - target). */
 int tg_bce_logits(const float* x, int64_t n, float target, float scale, float* stats3,
                   float grad_scale, float* dx, tg_stream_t stream);
+/* LSGANLoss (optim/losses.py:17-28): MSE against the constant 1 / 0 target; same statistics layout
+ * (stats3[0] += scale*sum((x-t)^2), [1], [2] as above), dx = grad_scale * 2 (x - target). */
+int tg_lsgan_loss(const float* x, int64_t n, float target, float scale, float* stats3,
+                  float grad_scale, float* dx, tg_stream_t stream);
 /* torch.optim.Adam step (vsrgan_model.py:76-87), in place, `step` = 1-based count */
 int tg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int step,

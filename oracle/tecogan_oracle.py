@@ -660,9 +660,15 @@ def vsrgan_train_step(sd_G, sd_D, adam_G, adam_D, state, lr_data, gt_data, scale
                       spatial_size, tempo_extent, lr_G=5e-5, lr_D=5e-5, pix_w=1.0, warp_w=1.0,
                       pp_w=0.5, gan_w=0.01, crop_border_ratio=0.75, update_threshold=0.4,
                       reduction='mean', sd_F=None, feat_w=0.2, feature_layers=(8, 17, 26, 35),
-                      fm=None):
-    """sd_F: VGG19 weights -> perceptual loss (:226-241).  fm = dict(kind, weight, layer_norm,
-    reduction) -> feature-matching loss (:255-271)."""
+                      fm=None, gan_type='GAN', feat_type='CosineSimilarity', feat_reduction='mean'):
+    """sd_F: VGG19 weights -> perceptual loss (:226-241), criterion feat_type (CosineSimilarity as in the
+    shipped ymls, or L1 / MSE / CB: optim/__init__.py:5-35 accepts any).  fm = dict(kind, weight,
+    layer_norm, reduction) -> feature-matching loss (:255-271).  gan_type 'GAN' (VanillaGANLoss,
+    losses.py:6-14) or 'LSGAN' (losses.py:17-28: MSE against the constant 1 / 0 target)."""
+    def gan(x, status):
+        if gan_type == 'LSGAN':
+            return pointwise_criterion('MSE', x, torch.full_like(x, float(int(status))), reduction)
+        return bce_with_logits(x, status, reduction)
     n, t, c, lr_h, lr_w = lr_data.shape
     gt_h, gt_w = gt_data.shape[3:]
     bi = upsample(lr_data.reshape(n * t, c, lr_h, lr_w), scale, degradation).view(
@@ -685,7 +691,7 @@ def vsrgan_train_step(sd_G, sd_D, adam_G, adam_D, state, lr_data, gt_data, scale
     gD = {}
     if upd_D:
         state['cnt_upd_D'] = state.get('cnt_upd_D', 0) + 1.0
-        loss_D = bce_with_logits(real, True, reduction) + bce_with_logits(fake, False, reduction)
+        loss_D = gan(real, True) + gan(fake, False)
         loss_D.backward()
         gD = {k: v.grad for k, v in PD.items() if torch.is_tensor(v) and v.requires_grad
               and v.grad is not None}
@@ -712,7 +718,10 @@ def vsrgan_train_step(sd_G, sd_D, adam_G, adam_D, state, lr_data, gt_data, scale
         hr_f = vgg19_features(sd_F, hr.reshape(-1, c, gt_h, gt_w), feature_layers)
         with torch.no_grad():
             gt_f = vgg19_features(sd_F, gt_data.reshape(-1, c, gt_h, gt_w), feature_layers)
-        l_feat = feat_w * sum(cosine_similarity_loss(a, b) for a, b in zip(hr_f, gt_f))
+        if feat_type == 'CosineSimilarity':
+            l_feat = feat_w * sum(cosine_similarity_loss(a, b) for a, b in zip(hr_f, gt_f))
+        else:
+            l_feat = feat_w * sum(pointwise_criterion(feat_type, a, b, feat_reduction) for a, b in zip(hr_f, gt_f))
         extra = extra + l_feat
         log['l_feat_G'] = l_feat.item()
     fake_g, fake_feats, _ = discriminator_forward(PDf, hr, hr_flow_merge=merge, **kw)  # :257/:275
@@ -723,7 +732,7 @@ def vsrgan_train_step(sd_G, sd_D, adam_G, adam_D, state, lr_data, gt_data, scale
             for i, (ff, rf) in enumerate(zip(fake_feats, real_feats)))
         extra = extra + l_fm
         log['l_fm_G'] = l_fm.item()
-    l_gan = gan_w * bce_with_logits(fake_g, True, reduction)
+    l_gan = gan_w * gan(fake_g, True)
     (l_pix + l_warp + l_pp + l_gan + extra).backward()
     gG = {k: v.grad for k, v in PG.items() if torch.is_tensor(v) and v.requires_grad
           and v.grad is not None}

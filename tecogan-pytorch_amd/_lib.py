@@ -108,6 +108,7 @@ SIGNATURES = {
     'tg_cosine_loss': (I, [P, P, I, I, I64, F, F, P, F, P, P]),
     'tg_pixel_loss': (I, [P, P, I64, I, F, P, F, P, P]),
     'tg_bce_logits': (I, [P, I64, F, F, P, F, P, P]),
+    'tg_lsgan_loss': (I, [P, I64, F, F, P, F, P, P]),
     'tg_adam_step': (I, [P, P, P, P, I64, F, F, F, F, F, I, P]),
     'tg_adam_step_guarded': (I, [P, P, P, P, I64, F, F, F, F, F, I, P, P]),
     'tg_fault_to_slot': (I, [P, P, P]),

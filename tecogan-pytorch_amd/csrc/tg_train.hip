@@ -423,6 +423,8 @@ __global__ __launch_bounds__(256) void pixel_loss_kernel(const float* __restrict
 
 // BCE-with-logits against a constant target t; also mean(x) and mean(log(sigmoid(x)+1e-8))
 // stats[0] += scale*sum(loss), stats[1] += scale*sum(x), stats[2] += scale*sum(log(sig+1e-8))
+// LS = true: LSGANLoss (optim/losses.py:17-28), (x - t)^2 with dx = 2 (x - t); the logged statistics are the same
+template <bool LS>
 __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict__ x, long long n,
                                                          float target, float scale,
                                                          float* __restrict__ stats, float gscale,
@@ -432,10 +434,11 @@ __global__ __launch_bounds__(256) void bce_logits_kernel(const float* __restrict
   TG_GRID_STRIDE(i, n) {
     float v = x[i];
     float sig = 1.f / (1.f + expf(-v));
-    s0 += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+    if (LS) s0 += (v - target) * (v - target);
+    else s0 += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
     s1 += v;
     s2 += logf(sig + 1e-8f);
-    if (dx) dx[i] = gscale * (sig - target);
+    if (dx) dx[i] = LS ? gscale * (2.f * (v - target)) : gscale * (sig - target);
   }
   float r0 = block_sum(s0, sm), r1 = block_sum(s1, sm), r2 = block_sum(s2, sm);
   if (threadIdx.x == 0 && stats) {
@@ -903,9 +906,17 @@ extern "C" int tg_pixel_loss(const float* x, const float* y, int64_t n, int mode
 extern "C" int tg_bce_logits(const float* x, int64_t n, float target, float scale, float* stats3,
                              float grad_scale, float* dx, tg_stream_t stream) {
   TG_REQUIRE(x && n > 0 && (stats3 || dx), TG_E_ARG, "bce_logits: bad argument");
-  hipLaunchKernelGGL(bce_logits_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ST, x, (long long)n,
+  hipLaunchKernelGGL(bce_logits_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, ST, x, (long long)n,
                      target, scale, stats3, grad_scale, dx);
   return check_launch("bce_logits");
+}
+
+extern "C" int tg_lsgan_loss(const float* x, int64_t n, float target, float scale, float* stats3,
+                             float grad_scale, float* dx, tg_stream_t stream) {
+  TG_REQUIRE(x && n > 0 && (stats3 || dx), TG_E_ARG, "lsgan_loss: bad argument");
+  hipLaunchKernelGGL(bce_logits_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, ST, x, (long long)n,
+                     target, scale, stats3, grad_scale, dx);
+  return check_launch("lsgan_loss");
 }
 
 extern "C" int tg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,

@@ -139,13 +139,10 @@ def define_criterion(criterion_opt):
     if criterion_opt is None:
         return None
     kind = criterion_opt['type']
-    if kind in ('CB', 'L1', 'MSE', 'GAN'):
+    if kind in ('CB', 'L1', 'MSE', 'GAN', 'LSGAN'):
         return (kind, criterion_opt.get('reduction', 'mean'))
     if kind == 'CosineSimilarity':
         return (kind, 'mean')                      # losses.py:53-62 takes no reduction
-    if kind == 'LSGAN':
-        raise NotImplementedError('LSGAN criterion: no shipped configuration selects it; '
-                                  'not built on the HIP path')
     raise ValueError(f'Unrecognized criterion: {criterion_opt["type"]}')
 
 

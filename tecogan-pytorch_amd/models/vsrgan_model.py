@@ -39,9 +39,8 @@ class VSRGANModel(VSRModel):
         self.warp_crit = define_criterion(tr.get('warping_crit'))
         self.feat_crit = define_criterion(tr.get('feature_crit'))
         if self.feat_crit is not None:
-            if self.feat_crit[0] != 'CosineSimilarity':
-                raise NotImplementedError(f'feature_crit type {self.feat_crit[0]}: the shipped '
-                                          'configurations use CosineSimilarity')
+            if self.feat_crit[0] not in ('CosineSimilarity', 'L1', 'MSE', 'CB'):
+                raise ValueError(f'feature_crit type {self.feat_crit[0]} is not a feature criterion')
             fc = tr['feature_crit']
             self.net_F = VGGFeatureExtractor(fc.get('feature_layers', [8, 17, 26, 35])).to(self.device)
             self._load_vgg(fc)
@@ -125,12 +124,13 @@ class VSRGANModel(VSRModel):
         scal = torch.zeros(15, dtype=torch.float32, device=self.device)   # every scalar of the step (+ the fault slot)
         st_real, st_fake, st_g, losses = scal[0:3], scal[3:6], scal[6:9], scal[9:14]
         red = self.gan_crit[1]
+        lsgan = self.gan_crit[0] == 'LSGAN'        # LSGANLoss (losses.py:17-28) instead of VanillaGANLoss
         gsc = (1.0 / n_clip) if red == 'mean' else 1.0
         g_pair = torch.empty_like(pair_pred) if pair is not None else None
         g_real = ops.bce_logits(real_pred, 1.0, st_real, 1.0 / n_clip, grad_scale=gsc,
-                                dx_out=None if g_pair is None else g_pair[:n_clip])
+                                dx_out=None if g_pair is None else g_pair[:n_clip], lsgan=lsgan)
         g_fake = ops.bce_logits(fake_pred, 0.0, st_fake, 1.0 / n_clip, grad_scale=gsc,
-                                dx_out=None if g_pair is None else g_pair[n_clip:])
+                                dx_out=None if g_pair is None else g_pair[n_clip:], lsgan=lsgan)
 
         update_policy = opt_tr['discriminator']['update_policy']
         if update_policy == 'adaptive':
@@ -170,8 +170,11 @@ class VSRGANModel(VSRModel):
             gt_feats = self.net_F(gt_data.reshape(-1, c, gt_h, gt_w).contiguous())   # detached
             w_ = opt_tr['feature_crit'].get('weight', 1)
             for hf, gf in zip(hr_feats, gt_feats):
-                sc = w_ / (hf.shape[0] * hf.shape[2] * hf.shape[3])         # 1 - mean(cos)
-                tape_G.add_grad(hf, ops.cosine_loss(hf, gf, losses[3:4], sc, grad_scale=sc))
+                if self.feat_crit[0] == 'CosineSimilarity':
+                    sc = w_ / (hf.shape[0] * hf.shape[2] * hf.shape[3])     # 1 - mean(cos)
+                    tape_G.add_grad(hf, ops.cosine_loss(hf, gf, losses[3:4], sc, grad_scale=sc))
+                else:      # any element-wise criterion define_criterion accepts (optim/__init__.py:5-35)
+                    tape_G.add_grad(hf, pointwise_loss(self.feat_crit, hf, gf, w_, losses[3:4]))
             del gt_feats
         if self.pp_crit is not None:
             te = opt_tr['tempo_extent']
@@ -199,7 +202,7 @@ class VSRGANModel(VSRModel):
                                                    losses[4:5]))
         gan_w = opt_tr['gan_crit'].get('weight', 1)
         tape_G.add_grad(fake_pred_G, ops.bce_logits(fake_pred_G, 1.0, st_g, 1.0 / n_clip,
-                                                    grad_scale=gan_w * gsc))
+                                                    grad_scale=gan_w * gsc, lsgan=lsgan))
         tape_G.backward()
         TG.stamp_fault(self.optim_G)                 # a chained-launch fault (any rank) turns the step into a no-op
         self.allreduce_grads(self.net_G, 'G')

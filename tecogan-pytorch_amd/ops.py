@@ -713,12 +713,13 @@ def cosine_loss(a, b, loss_accum, loss_scale, grad_scale=None, eps=1e-8):
     return da
 
 
-def bce_logits(x, target, stats3, scale, grad_scale=None, dx_out=None):
+def bce_logits(x, target, stats3, scale, grad_scale=None, dx_out=None, lsgan=False):
+    """VanillaGANLoss (BCE with logits) or, lsgan=True, LSGANLoss (MSE) against a constant target."""
     _chk(x, 'x')
     dx = (dx_out if dx_out is not None else torch.empty_like(x)) if grad_scale is not None else None
-    L.check(L.lib().tg_bce_logits(x.data_ptr(), x.numel(), float(target), float(scale),
-                                  _ptr(stats3), float(grad_scale or 0.0), _ptr(dx), _stream()),
-            'tg_bce_logits')
+    fn = L.lib().tg_lsgan_loss if lsgan else L.lib().tg_bce_logits
+    L.check(fn(x.data_ptr(), x.numel(), float(target), float(scale), _ptr(stats3), float(grad_scale or 0.0),
+               _ptr(dx), _stream()), 'tg_lsgan_loss' if lsgan else 'tg_bce_logits')
     return dx
 
 
