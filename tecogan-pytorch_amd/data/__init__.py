@@ -4,38 +4,51 @@ import torch
 
 from .device_clip_store import DeviceClipStore
 from .lmdb_io import LMDBReader, LMDBWriter, make_key, parse_lmdb_key
+from .paired_lmdb_dataset import PairedLMDBDataset
 from .unpaired_lmdb_dataset import ClipPlan, UnpairedLMDBDataset
 
 
 class TrainSource:
-    """What codes/data/__init__.py:create_dataloader(opt, 'train', ...) provides for BD
-    training: an iterable of {'gt': (n, t, 3, S + 2b, S + 2b) fp32} batches, here already on
-    the device.  Epoch order = DataLoader(shuffle=True, drop_last=True), or under
+    """What codes/data/__init__.py:create_dataloader(opt, 'train', ...) provides: an iterable of
+    {'gt': (n, t, 3, S + 2b, S + 2b) fp32} batches for BD training, {'gt': (n, t, 3, S, S), 'lr': (n, t, 3, S/s,
+    S/s)} for BI (paired sets), here already on the device.  Epoch order = DataLoader(shuffle=True, drop_last=True), or under
     torch.distributed the DistributedSampler rule (permutation seeded with seed + epoch, padded
     to a multiple of the world size, every world-th index starting at rank)."""
 
     def __init__(self, opt):
         data_opt = opt['dataset']['train']
-        if opt['dataset']['degradation']['type'] != 'BD':
-            raise NotImplementedError('LMDB front end: BD (unpaired GT) training sets; BI batches '
-                                      'carry their own LR frames (paired_lmdb_dataset.py)')
-        sigma = opt['dataset']['degradation'].get('sigma', 1.5)
-        self.dataset = UnpairedLMDBDataset(
-            data_opt, crop_size=data_opt['crop_size'] + 2 * int(sigma * 3.0),      # :33-34
-            tempo_extent=opt['train']['tempo_extent'],
-            moving_first_frame=opt['train'].get('moving_first_frame', False),
-            moving_factor=opt['train'].get('moving_factor', 1.0))
         self.batch = data_opt['batch_size_per_gpu']
         self.rank, self.world = opt.get('rank', 0), opt.get('world_size', 1)
         self.dist = bool(opt.get('dist', False))
         self.seed = opt.get('manual_seed', 0)
-        reader = LMDBReader(data_opt['seq_dir'])
-        # every frame any sample can touch: the keys of the selected sequences
-        seqs = {parse_lmdb_key(k)[0] for k in self.dataset.keys}
+        deg = opt['dataset']['degradation']['type']
+        dev = opt.get('device', 'cuda')
+        common = dict(tempo_extent=opt['train']['tempo_extent'],
+                      moving_first_frame=opt['train'].get('moving_first_frame', False),
+                      moving_factor=opt['train'].get('moving_factor', 1.0))
+        self.paired = deg == 'BI'
+        if deg == 'BI':          # paired GT / LR sets (paired_lmdb_dataset.py; data/__init__.py:22-29)
+            self.dataset = PairedLMDBDataset(data_opt, scale=opt['scale'], **common)
+            seqs = {parse_lmdb_key(g)[0] for g, _ in self.dataset.gt_lr_keys}
+            self.store = self._load(data_opt['gt_seq_dir'], seqs, dev)
+            self.store_lr = self._load(data_opt['lr_seq_dir'], seqs, dev)
+        elif deg == 'BD':        # unpaired GT, the crop enlarged by the blur border (:31-42)
+            sigma = opt['dataset']['degradation'].get('sigma', 1.5)
+            self.dataset = UnpairedLMDBDataset(data_opt, crop_size=data_opt['crop_size'] + 2 * int(sigma * 3.0), **common)
+            seqs = {parse_lmdb_key(k)[0] for k in self.dataset.keys}
+            self.store = self._load(data_opt['seq_dir'], seqs, dev)
+        else:
+            raise ValueError(f'Unrecognized degradation type: {deg}')
+
+    @staticmethod
+    def _load(seq_dir, seqs, device):
+        """every frame any sample can touch -- the keys of the selected sequences -- into HBM"""
+        reader = LMDBReader(seq_dir)
         frames = [k.decode('ascii') for k in reader.keys()]
         frames = [k for k in frames if k.count('_') >= 2 and parse_lmdb_key(k)[0] in seqs]
-        self.store = DeviceClipStore.from_lmdb(reader, frames, opt.get('device', 'cuda'))
+        store = DeviceClipStore.from_lmdb(reader, frames, device)
         reader.close()
+        return store
 
     def __len__(self):
         per = len(self.dataset) if not self.dist else -(-len(self.dataset) // self.world)
@@ -65,7 +78,11 @@ class TrainSource:
         for b in range(len(order) // self.batch):
             plans = [self.dataset.draw_plan(i) for i in order[b * self.batch:(b + 1) * self.batch]]
             if b >= first_batch:
-                yield {'gt': self.store.gather(plans)}
+                if self.paired:
+                    yield {'gt': self.store.gather([p[0] for p in plans]),
+                           'lr': self.store_lr.gather([p[1] for p in plans])}
+                else:
+                    yield {'gt': self.store.gather(plans)}
 
     def __iter__(self):
         return self.epoch(0)

@@ -29,3 +29,15 @@ CONFIGS = {            # tag -> (moving_first_frame, moving_factor, python seed,
     'mixed': (True, 0.6, 31, 32),
 }
 N_ITEMS = 12
+
+# paired (BI) sets: LR frames of half the size under the matching keys (make_golden_data_paired.py)
+PAIRED_SCALE, PAIRED_GT_CROP = 2, 16
+
+
+def all_lr_frames():
+    out = {}
+    for name, n, h, w in SEQS:
+        for i in range(n):
+            key = f'{name}_{n}x{h // PAIRED_SCALE}x{w // PAIRED_SCALE}_{i:04d}'
+            out[key] = frame(key, h // PAIRED_SCALE, w // PAIRED_SCALE)
+    return out

@@ -126,3 +126,49 @@ def test_manual_seed_reproduces_augmentation(tmp_path):
                 for p in (ds.draw_plan(i % len(ds)) for i in range(16))]
     a, b, c = draw(2021), draw(2021), draw(2022)
     assert a == b and a != c
+
+
+# ------------------------------------------------------------------ paired (BI) sets, round 4
+def _make_paired_envs(tmp_path):
+    from tecogan_pytorch_amd.data import LMDBWriter as W
+    dirs = []
+    for name, frames in (('gt', F.all_frames()), ('lr', F.all_lr_frames())):
+        d = os.path.join(str(tmp_path), name)
+        os.makedirs(d)
+        W(d).write({k: v.tobytes() for k, v in frames.items()})
+        with open(os.path.join(d, 'meta_info.pkl'), 'wb') as f:
+            pickle.dump({'name': 'fixture', 'color': 'RGB', 'keys': list(frames.keys())}, f)
+        dirs.append(d)
+    return dirs
+
+
+@pytest.mark.parametrize('tag', list(F.CONFIGS))
+def test_paired_dataset_samples_equal_the_reference(tmp_path, golden, tag):
+    """PairedLMDBDataset (codes/data/paired_lmdb_dataset.py:12-166, BI training): GT and LR windows of a
+    sample cut from two LMDBs with the reference's random draws -- identical to the reference's __getitem__
+    under the same seeds (tests/golden/make_golden_data_paired.py), incl. the moving-first-frame motion on
+    the LR grid and the reflect temporal padding."""
+    from tecogan_pytorch_amd.data import PairedLMDBDataset
+    gt_dir, lr_dir = _make_paired_envs(tmp_path)
+    moving, factor, pseed, nseed = F.CONFIGS[tag]
+    ds = PairedLMDBDataset({'gt_seq_dir': gt_dir, 'lr_seq_dir': lr_dir, 'filter_file': None, 'data_type': 'rgb',
+                            'gt_crop_size': F.PAIRED_GT_CROP},
+                           scale=F.PAIRED_SCALE, tempo_extent=F.TEMPO, moving_first_frame=moving, moving_factor=factor)
+    g = golden('data_aug_paired')
+    assert len(ds) == sum(n for _, n, _, _ in F.SEQS)
+    random.seed(pseed)
+    np.random.seed(nseed)
+    lc = F.PAIRED_GT_CROP // F.PAIRED_SCALE
+    for it, rg, rl in zip(g[tag + '_items'], g[tag + '_gt_u8'], g[tag + '_lr_u8']):
+        s = ds[int(it)]
+        assert tuple(s['gt'].shape) == (F.TEMPO, 3, F.PAIRED_GT_CROP, F.PAIRED_GT_CROP) and tuple(s['lr'].shape) == (F.TEMPO, 3, lc, lc)
+        assert np.array_equal(s['gt'].numpy(), rg.astype(np.float32) / np.float32(255.0)), (tag, int(it))
+        assert np.array_equal(s['lr'].numpy(), rl.astype(np.float32) / np.float32(255.0)), (tag, int(it))
+
+
+def test_paired_dataset_refuses_mismatched_sets(tmp_path):
+    from tecogan_pytorch_amd.data import PairedLMDBDataset
+    gt_dir, lr_dir = _make_paired_envs(tmp_path)
+    opt = {'gt_seq_dir': gt_dir, 'lr_seq_dir': lr_dir, 'filter_file': None, 'data_type': 'rgb', 'gt_crop_size': 16}
+    with pytest.raises(ValueError):            # the sets are 2x apart
+        PairedLMDBDataset(opt, scale=4, tempo_extent=3)

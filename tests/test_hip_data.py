@@ -112,3 +112,45 @@ def test_train_source_feeds_the_training_step(tmp_path):
         halves.append(order[rank:n:2])
         assert len(s) == (n // 2) // 2
     assert set(halves[0]).isdisjoint(halves[1]) and len(halves[0]) + len(halves[1]) == 8
+
+
+# ------------------------------------------------------------------ paired (BI) sets, round 4
+def test_paired_train_source_equals_reference_samples_and_feeds_bi_training(tmp_path, golden):
+    """TrainSource for `degradation: BI` (codes/data/__init__.py:22-29): GT and LR clips gathered on the device
+    from the two HBM-resident sets are bit-identical to the reference's PairedLMDBDataset samples (golden), and a
+    batch goes straight into prepare_training_data + train() of the 2x BI model."""
+    from tests.test_data_cpu import _make_paired_envs
+    from tecogan_pytorch_amd.data import PairedLMDBDataset
+    gt_dir, lr_dir = _make_paired_envs(tmp_path)
+    g = golden('data_aug_paired')
+    for tag in F.CONFIGS:
+        moving, factor, pseed, nseed = F.CONFIGS[tag]
+        ds = PairedLMDBDataset({'gt_seq_dir': gt_dir, 'lr_seq_dir': lr_dir, 'filter_file': None, 'data_type': 'rgb',
+                                'gt_crop_size': F.PAIRED_GT_CROP},
+                               scale=F.PAIRED_SCALE, tempo_extent=F.TEMPO, moving_first_frame=moving, moving_factor=factor)
+        gt_store = DeviceClipStore.from_frames(F.all_frames().items())
+        lr_store = DeviceClipStore.from_frames(F.all_lr_frames().items())
+        random.seed(pseed)
+        np.random.seed(nseed)
+        plans = [ds.draw_plan(int(it)) for it in g[tag + '_items']]
+        gt = gt_store.gather([p[0] for p in plans]).cpu().numpy()
+        lr = lr_store.gather([p[1] for p in plans]).cpu().numpy()
+        assert np.array_equal(gt, g[tag + '_gt_u8'].astype(np.float32) / np.float32(255.0)), tag
+        assert np.array_equal(lr, g[tag + '_lr_u8'].astype(np.float32) / np.float32(255.0)), tag
+    # the whole front end into a BI training step (2x, crop 16 -> LR 8)
+    from tests.test_hip_train import make_opt
+    from tecogan_pytorch_amd.models import define_model
+    opt = make_opt('FRVSR')
+    opt['scale'] = 2
+    opt['dataset']['degradation'] = {'type': 'BI'}
+    opt['dataset']['train'].update({'gt_seq_dir': gt_dir, 'lr_seq_dir': lr_dir, 'filter_file': None, 'data_type': 'rgb',
+                                    'gt_crop_size': 16, 'batch_size_per_gpu': 2, 'name': 'REDS'})
+    opt['train']['tempo_extent'] = 4
+    src = TrainSource(opt)
+    b = next(iter(src.epoch(0)))
+    assert tuple(b['gt'].shape) == (2, 4, 3, 16, 16) and tuple(b['lr'].shape) == (2, 4, 3, 8, 8) and b['lr'].is_cuda
+    m = define_model(opt)
+    m.prepare_training_data(b)
+    assert tuple(m.lr_data.shape) == (2, 4, 3, 8, 8) and tuple(m.gt_data.shape) == (2, 4, 3, 16, 16)
+    m.train()
+    assert np.isfinite(m.log_dict['l_pix_G'])
