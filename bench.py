@@ -481,6 +481,8 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
             m.exchange_timing.clear()
         if dist_on:
             _barrier(dist, local_rank)
+        from tecogan_pytorch_amd.utils import dist_utils as DU
+        c0 = dict(DU.COMM_COUNTS)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         nupd = 0
@@ -489,6 +491,7 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
             nupd += 1 if m.log_dict.get('l_gan_D', 0) != 0 else 0
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        m.comm_per_step = {k: (DU.COMM_COUNTS[k] - c0[k]) / steps for k in c0}
         if dist_on:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -506,6 +509,13 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
                                 'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version())
                                 if dist.get_backend() == 'nccl' else None,
                                 'transport': os.environ.get('TECOGAN_COMM', 'torch.distributed')}
+        cps = getattr(m, 'comm_per_step', {})
+        out['rccl_comm_count'] = {
+            'all_reduce_per_step': cps.get('all_reduce'), 'all_gather_per_step': cps.get('all_gather'),
+            'payload_bytes_per_step': cps.get('bytes'),
+            'what': '2 flat gradient buckets (G, D) + 1 fused adaptive-D scalar pair + SyncBatchNorm: 4 layers x '
+                    '(1 statistics all-gather forward + 1 sum all-reduce backward) for the D update (real and fake pass '
+                    'run as ONE pair pass since round 4: 8 instead of 16) and the same for the generator\'s pass through D'}
         et = getattr(m, 'exchange_timing', None)
         if et:
             torch.cuda.synchronize()
@@ -578,6 +588,7 @@ def main():
             # time-sharing the CUs their fail-safe can trip (measured at 2 ranks: ~400 workgroups timed
             # out, the plan fell back -- INTEGRATION.md).  The rehearsal walks the per-layer paths instead.
             os.environ['TG_WINO_CHAIN'] = '0'
+            os.environ['TG_WINO_RES'] = '0'
             from tecogan_pytorch_amd.models.networks.tecogan_nets import SRNet
             SRNet.chain_body = False
         else:

@@ -124,11 +124,18 @@ def _staged(t):
     return t.is_cuda and dist.get_backend() == 'gloo'
 
 
+# collectives issued by this process (bench.py --gpus N reports them per training step: "rccl_comm_count")
+COMM_COUNTS = {'all_reduce': 0, 'all_gather': 0, 'bytes': 0}
+
+
 def all_reduce_sum_(t, async_op=False):
     """In-place SUM of `t` over ranks.  Returns an object with .wait() (already complete
     unless async_op on an RCCL group: then wait() orders the CURRENT stream after the
     collective without blocking the host)."""
     rank, world = get_dist_info()
+    if world > 1:
+        COMM_COUNTS['all_reduce'] += 1
+        COMM_COUNTS['bytes'] += t.numel() * t.element_size()
     if _use_c_abi(t):
         from .. import _lib as L
         L.check(L.lib().tg_allreduce_sum_f32(_c_comm(), t.data_ptr(), t.numel(),
@@ -152,6 +159,9 @@ def all_gather_flat(t):
     """(world, t.numel()) tensor holding every rank's `t`, rank order."""
     rank, world = get_dist_info()
     flat = t.reshape(-1)
+    if world > 1:
+        COMM_COUNTS['all_gather'] += 1
+        COMM_COUNTS['bytes'] += flat.numel() * flat.element_size()
     if _use_c_abi(t):
         from .. import _lib as L
         out = torch.empty(max(world, 1) * flat.numel(), dtype=t.dtype, device=t.device)
