@@ -32,6 +32,9 @@
 #ifndef WR_POLL_SLEEP
 #define WR_POLL_SLEEP 2   // s_sleep units (64 cycles) between two polls of the ring
 #endif
+#ifndef WR_PRIO_I
+#define WR_PRIO_I 0     // s_setprio of the interior waves
+#endif
 #ifndef WR_PRIO_B
 #define WR_PRIO_B 0     // s_setprio of the boundary waves (the interior waves stay at 0)
 #endif
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
   const int ty = T / WR_TW, tx = T - ty * WR_TW;
   const bool interior = g == 2;               // wave-uniform
   if (WR_PRIO_B > 0 && !interior) __builtin_amdgcn_s_setprio(WR_PRIO_B);
+  if (WR_PRIO_I > 0 && interior) __builtin_amdgcn_s_setprio(WR_PRIO_I);
   const int kk = l >> 4;                      // K index inside a K step (B operand) / output-channel quad (D)
   const int rb = kk * WR_CS + (2 * ty) * WR_RS + 2 * tx;        // window origin in the resident block (floats)
   const int oc_base = 16 * q + 4 * kk;
