@@ -661,6 +661,14 @@ def main():
             net.infer_sequence(clip, dev, pipeline=False, return_device_tensor=True)
             torch.cuda.synchronize()
             sec['fps_clip_single_stream'] = args.steps / (time.perf_counter() - t1)
+            # one stream, flows batched: the 8-pair FNet passes enqueued on the SAME stream ahead of their frames
+            # (no concurrency of any kind; the per-frame-FNet figure above keeps the reference's loop shape)
+            net.infer_sequence(wclip, dev, pipeline='one_stream', return_device_tensor=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            net.infer_sequence(clip, dev, pipeline='one_stream', return_device_tensor=True)
+            torch.cuda.synchronize()
+            sec['fps_clip_one_stream_batched_flow'] = args.steps / (time.perf_counter() - t1)
             # with host I/O, as the reference's loop has it (tecogan_nets.py:273-279 moves every
             # frame H2D and the uint8 result D2H): LR clip in pinned host memory, uploaded batch by
             # batch, uint8 HR frames downloaded to pinned memory on a copy stream while the next

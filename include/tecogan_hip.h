@@ -511,6 +511,14 @@ int tg_backward_warp_bwd(const float* x, const float* flow, const float* dy, flo
  * accumulation pass: the frame a warp reads usually has a gradient of its own loss term already). */
 int tg_backward_warp_bwd_acc(const float* x, const float* flow, const float* dy, float* dimg_acc, float* dflow,
                              int n, int c, int h, int w, tg_stream_t stream);
+/* The training unroll's pair backward_warp (net_utils.py:50-82) -> space_to_depth (net_utils.py:36-47;
+ * tecogan_nets.py:208-212) as ONE launch each way: y (n, scale^2 c, h/scale, w/scale) =
+ * space_to_depth(backward_warp(x, flow), scale), bit-identical to the two separate calls; backward takes the
+ * gradient in that layout (dy_s2d), accumulate != 0 adds the image gradient to dimg instead of overwriting it. */
+int tg_backward_warp_s2d_fwd(const float* x, const float* flow, float* y, int n, int c, int h, int w, int scale,
+                             tg_stream_t stream);
+int tg_backward_warp_s2d_bwd(const float* x, const float* flow, const float* dy_s2d, float* dimg, int accumulate,
+                             float* dflow, int n, int c, int h, int w, int scale, tg_stream_t stream);
 /* inverse of tg_space_to_depth: x (n, s*s*c, h, w) -> y (n, c, s*h, s*w) */
 int tg_depth_to_space(const float* x, float* y, int n, int c, int h, int w, int scale,
                       tg_stream_t stream);

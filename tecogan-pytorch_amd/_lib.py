@@ -100,6 +100,8 @@ SIGNATURES = {
     'tg_upsample_bwd': (I, [P, P, I, I, I, I, I, F, P]),
     'tg_backward_warp_bwd': (I, [P, P, P, P, P, I, I, I, I, P]),
     'tg_backward_warp_bwd_acc': (I, [P, P, P, P, P, I, I, I, I, P]),
+    'tg_backward_warp_s2d_fwd': (I, [P, P, P, I, I, I, I, I, P]),
+    'tg_backward_warp_s2d_bwd': (I, [P, P, P, P, I, P, I, I, I, I, I, P]),
     'tg_depth_to_space': (I, [P, P, I, I, I, I, I, P]),
     'tg_depth_to_space_act_bwd_supported': (I, [P, P, P, I, I]),
     'tg_depth_to_space_act_bwd': (I, [P, P, I, P, I, I, I, I, I, P]),

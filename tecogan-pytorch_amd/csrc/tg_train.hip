@@ -228,7 +228,7 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restr
 // backward of backward_warp: dflow (n,2,h,w) and (optionally) dimg scatter.  dimg pre-zeroed.
 __global__ __launch_bounds__(256) void backward_warp_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ flow, const float* __restrict__ dy,
-    float* __restrict__ dimg, float* __restrict__ dflow, int n, int c, int h, int w) {
+    float* __restrict__ dimg, float* __restrict__ dflow, int n, int c, int h, int w, int s2d) {
   const int px_ = blockIdx.x * 64 + (threadIdx.x & 63);
   const int py_ = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.z;
@@ -251,9 +251,13 @@ __global__ __launch_bounds__(256) void backward_warp_bwd_kernel(
   int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
   bool okx1 = x1 <= w - 1, oky1 = y1 <= h - 1;
   float gsx = 0.f, gsy = 0.f;
+  // s2d > 1: dy is the gradient of space_to_depth(warp(x), s2d) (plane (sy s + sx) c + ch, h / s x w / s)
+  const int oy_ = py_ / s2d, ox_ = px_ / s2d, ph_ = (py_ - oy_ * s2d) * s2d + (px_ - ox_ * s2d);
+  const long long ohw = hw / (s2d * s2d);
+  const float* dyo = dy + ((long long)b * c * s2d * s2d + (long long)ph_ * c) * ohw + (long long)oy_ * (w / s2d) + ox_;
   for (int ch = 0; ch < c; ++ch) {
     const long long plane = ((long long)b * c + ch) * hw;
-    const float g = dy[plane + pix];
+    const float g = dyo[ch * ohw];
     const float* img = x + plane;
     float v00 = img[y0 * w + x0];
     float v01 = okx1 ? img[y0 * w + x1] : 0.f;
@@ -802,15 +806,16 @@ extern "C" int tg_upsample_bwd(const float* dy, float* dx, int nc, int h, int w,
 }
 
 static int warp_bwd_impl(const float* x, const float* flow, const float* dy, float* dimg,
-                         float* dflow, int n, int c, int h, int w, tg_stream_t stream, bool zero_img) {
+                         float* dflow, int n, int c, int h, int w, tg_stream_t stream, bool zero_img, int s2d = 1) {
   TG_REQUIRE(x && flow && dy && (dimg || dflow), TG_E_ARG, "backward_warp_bwd: null pointer");
-  TG_REQUIRE(n > 0 && c > 0 && h >= 2 && w >= 2, TG_E_SHAPE, "backward_warp_bwd: shape");
+  TG_REQUIRE(n > 0 && c > 0 && h >= 2 && w >= 2 && s2d >= 1 && h % s2d == 0 && w % s2d == 0, TG_E_SHAPE,
+             "backward_warp_bwd: shape");
   if (dimg && zero_img) {
     hipError_t e = hipMemsetAsync(dimg, 0, (size_t)n * c * h * w * sizeof(float), ST);
     TG_REQUIRE(e == hipSuccess, TG_E_HIP, "backward_warp_bwd: memset: %s", hipGetErrorString(e));
   }
   dim3 g(cdiv(w, 64), cdiv(h, 4), n), t(256);
-  hipLaunchKernelGGL(backward_warp_bwd_kernel, g, t, 0, ST, x, flow, dy, dimg, dflow, n, c, h, w);
+  hipLaunchKernelGGL(backward_warp_bwd_kernel, g, t, 0, ST, x, flow, dy, dimg, dflow, n, c, h, w, s2d);
   return check_launch("backward_warp_bwd");
 }
 
@@ -825,6 +830,15 @@ extern "C" int tg_backward_warp_bwd_acc(const float* x, const float* flow, const
                                         float* dflow, int n, int c, int h, int w, tg_stream_t stream) {
   TG_REQUIRE(dimg_acc, TG_E_ARG, "backward_warp_bwd_acc: null pointer");
   return warp_bwd_impl(x, flow, dy, dimg_acc, dflow, n, c, h, w, stream, false);
+}
+
+// dy_s2d: the gradient of space_to_depth(backward_warp(x, flow), scale), (n, scale^2 c, h / scale, w / scale);
+// accumulate != 0: the image gradient is ADDED to dimg (tg_backward_warp_bwd_acc), else dimg is overwritten
+extern "C" int tg_backward_warp_s2d_bwd(const float* x, const float* flow, const float* dy_s2d, float* dimg,
+                                        int accumulate, float* dflow, int n, int c, int h, int w, int scale,
+                                        tg_stream_t stream) {
+  TG_REQUIRE(!accumulate || dimg, TG_E_ARG, "backward_warp_s2d_bwd: accumulate without dimg");
+  return warp_bwd_impl(x, flow, dy_s2d, dimg, dflow, n, c, h, w, stream, !accumulate, scale);
 }
 
 extern "C" int tg_depth_to_space(const float* x, float* y, int n, int c, int h, int w, int scale,

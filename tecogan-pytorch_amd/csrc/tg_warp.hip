@@ -374,7 +374,7 @@ __global__ __launch_bounds__(128 * (R / RPT)) void flowup_warp_s2d_kernel(FusedA
 __global__ __launch_bounds__(256) void backward_warp_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ flow,
                                                             float* __restrict__ y, int n, int c,
-                                                            int h, int w) {
+                                                            int h, int w, int s2d) {
   const int px_ = blockIdx.x * 64 + (threadIdx.x & 63);
   const int py_ = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.z;
@@ -383,9 +383,14 @@ __global__ __launch_bounds__(256) void backward_warp_kernel(const float* __restr
   const float* fl = flow + (long long)b * 2 * hw + (long long)py_ * w + px_;
   float sx = warp_coord(px_, w, fl[0]);
   float sy = warp_coord(py_, h, fl[hw]);
+  // s2d > 1: the result leaves in space_to_depth(., s2d) layout (net_utils.py:36-47: plane (sy s + sx) c + ch of
+  // the h / s x w / s image) -- the training unroll's warp -> space_to_depth pair as one launch
+  const int oy = py_ / s2d, ox = px_ / s2d, ph = (py_ - oy * s2d) * s2d + (px_ - ox * s2d);
+  const long long ohw = hw / (s2d * s2d);
+  float* yo = y + ((long long)b * c * s2d * s2d + (long long)ph * c) * ohw + (long long)oy * (w / s2d) + ox;
   for (int ch = 0; ch < c; ++ch) {
     const float* img = x + ((long long)b * c + ch) * hw;
-    y[((long long)b * c + ch) * hw + (long long)py_ * w + px_] = warp_sample(img, h, w, sx, sy);
+    yo[ch * ohw] = warp_sample(img, h, w, sx, sy);
   }
 }
 
@@ -468,6 +473,57 @@ __global__ void upsample_kernel(const float* __restrict__ x, float* __restrict__
       v = ly0 * top + ly1 * bot;
     }
     y[i] = mul * v;
+  }
+}
+
+// Bilinear x2 (the three decoder stages of FNet, tecogan_nets.py:49-61; F.interpolate(scale_factor=2, mode='bilinear',
+// align_corners=False)): one thread = 2 input columns x 1 input row -> a 2 x 4 output patch from 12 loads, two
+// 16-byte stores.  Same weights (bilinear_src) and the same expression as upsample_kernel: bit-identical, without
+// its per-element 64-bit index divisions and 4-byte stores (57 -> ~25 us on the 8 x 64 x 68 x 160 stage).
+__global__ __launch_bounds__(256) void upsample_bilinear2x_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  int nc, int h, int w, float mul) {
+  const int hw2 = w >> 1, ow = 2 * w;
+  const int total = nc * h * hw2;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int m = idx % hw2; const int t = idx / hw2;
+    const int i = t % h, p = t / h;
+    const float* src = x + (size_t)p * h * w;
+    const int r[3] = {max(i - 1, 0), i, min(i + 1, h - 1)};
+    const int c[4] = {max(2 * m - 1, 0), 2 * m, 2 * m + 1, min(2 * m + 2, w - 1)};
+    float v[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v[a][b] = src[r[a] * w + c[b]];
+    float lx0[4], lx1[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { int d0, d1; bilinear_src(4 * m + o, 2, w, d0, d1, lx0[o], lx1[o]); }
+    float* dst = y + ((size_t)p * 2 * h + 2 * i) * ow + 4 * m;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      int d0, d1; float ly0, ly1;
+      bilinear_src(2 * i + e, 2, h, d0, d1, ly0, ly1);
+      float tv[4], bv[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        tv[b] = e == 0 ? v[0][b] : v[1][b];                        // row y0
+        bv[b] = e == 0 ? (i ? v[1][b] : v[2][b]) : v[2][b];        // row y1 (row 0: y0 = 0, y1 = min(1, h - 1))
+      }
+      float o4[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        // columns (x0, x1) of output column 4 m + o inside c[]: (0, 1 | 2 at m = 0), (1, 2), (1, 2), (2, 3)
+        const int ka = o == 0 ? 0 : (o == 3 ? 2 : 1);
+        const float ta = tv[ka], ba = bv[ka];
+        const float tb = o == 0 ? (m ? tv[1] : tv[2]) : (o == 3 ? tv[3] : tv[2]);
+        const float bb = o == 0 ? (m ? bv[1] : bv[2]) : (o == 3 ? bv[3] : bv[2]);
+        float top = lx0[o] * ta + lx1[o] * tb;
+        float bot = lx0[o] * ba + lx1[o] * bb;
+        float vv = ly0 * top + ly1 * bot;
+        o4[o] = mul * vv;
+      }
+      *reinterpret_cast<float4*>(dst + (size_t)e * ow) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
   }
 }
 
@@ -610,8 +666,18 @@ extern "C" int tg_backward_warp_fwd(const float* x, const float* flow, float* y,
   TG_REQUIRE(n > 0 && c > 0 && h >= 2 && w >= 2, TG_E_SHAPE, "backward_warp: n=%d c=%d h=%d w=%d",
              n, c, h, w);
   dim3 g(cdiv(w, 64), cdiv(h, 4), n), t(256);
-  hipLaunchKernelGGL(backward_warp_kernel, g, t, 0, (hipStream_t)stream, x, flow, y, n, c, h, w);
+  hipLaunchKernelGGL(backward_warp_kernel, g, t, 0, (hipStream_t)stream, x, flow, y, n, c, h, w, 1);
   return check_launch("backward_warp");
+}
+
+extern "C" int tg_backward_warp_s2d_fwd(const float* x, const float* flow, float* y, int n, int c, int h, int w,
+                                        int scale, tg_stream_t stream) {
+  TG_REQUIRE(x && flow && y, TG_E_ARG, "backward_warp_s2d: null pointer");
+  TG_REQUIRE(n > 0 && c > 0 && h >= 2 && w >= 2 && scale >= 1 && h % scale == 0 && w % scale == 0, TG_E_SHAPE,
+             "backward_warp_s2d: n=%d c=%d h=%d w=%d scale=%d", n, c, h, w, scale);
+  dim3 g(cdiv(w, 64), cdiv(h, 4), n), t(256);
+  hipLaunchKernelGGL(backward_warp_kernel, g, t, 0, (hipStream_t)stream, x, flow, y, n, c, h, w, scale);
+  return check_launch("backward_warp_s2d");
 }
 
 extern "C" int tg_space_to_depth(const float* x, float* y, int64_t y_nstride, int n, int c, int h,
@@ -637,6 +703,21 @@ extern "C" int tg_space_to_depth(const float* x, float* y, int64_t y_nstride, in
   return check_launch("space_to_depth");
 }
 
+// 16-byte form of maxpool2_kernel (w % 4 == 0, 16-byte aligned planes): two outputs per thread from two float4 loads
+__global__ __launch_bounds__(256) void maxpool2_vec_kernel(const float* __restrict__ x, float* __restrict__ y, int nc,
+                                                           int h, int w) {
+  const int oh = h / 2, ow2 = w / 4;
+  const int total = nc * oh * ow2;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int m = idx % ow2; const int t = idx / ow2;
+    const int oy = t % oh, p = t / oh;
+    const float* s = x + ((size_t)p * h + 2 * oy) * w + 4 * m;
+    const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + w);
+    *reinterpret_cast<float2*>(y + ((size_t)p * oh + oy) * (w / 2) + 2 * m) =
+        make_float2(fmaxf(fmaxf(a.x, a.y), fmaxf(b.x, b.y)), fmaxf(fmaxf(a.z, a.w), fmaxf(b.z, b.w)));
+  }
+}
+
 extern "C" int tg_upsample_fwd(const float* x, float* y, int nc, int h, int w, int scale,
                                int up_mode, float mul, tg_stream_t stream) {
   TG_REQUIRE(x && y, TG_E_ARG, "upsample: null pointer");
@@ -645,6 +726,13 @@ extern "C" int tg_upsample_fwd(const float* x, float* y, int nc, int h, int w, i
   TG_REQUIRE(up_mode == TG_UP_BICUBIC || up_mode == TG_UP_BILINEAR, TG_E_ARG, "upsample: mode=%d",
              up_mode);
   long long total = (long long)nc * h * scale * w * scale;
+  if (up_mode == TG_UP_BILINEAR && scale == 2 && (w & 1) == 0 && total < (1ll << 31) &&
+      (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+    const long long th = (long long)nc * h * (w / 2);
+    hipLaunchKernelGGL(upsample_bilinear2x_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, nc, h, w, mul);
+    return check_launch("upsample");
+  }
   hipLaunchKernelGGL(upsample_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, x, y,
                      nc, h, w, scale, up_mode, mul);
   return check_launch("upsample");
@@ -655,6 +743,11 @@ extern "C" int tg_maxpool2_fwd(const float* x, float* y, int nc, int h, int w,
   TG_REQUIRE(x && y, TG_E_ARG, "maxpool2: null pointer");
   TG_REQUIRE(nc > 0 && h >= 2 && w >= 2, TG_E_SHAPE, "maxpool2: nc=%d h=%d w=%d", nc, h, w);
   long long total = (long long)nc * (h / 2) * (w / 2);
+  if ((w & 3) == 0 && total < (1ll << 31) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+    hipLaunchKernelGGL(maxpool2_vec_kernel, dim3((unsigned)((total / 2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, nc, h, w);
+    return check_launch("maxpool2");
+  }
   hipLaunchKernelGGL(maxpool2_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, x, y,
                      nc, h, w);
   return check_launch("maxpool2");

@@ -372,6 +372,9 @@ class FRNet(nn.Module):
         TG_FNET_BATCH (default 8) frame pairs are estimated by one batched FNet pass on a
         second HIP stream while warp+SRNet runs frame by frame on the first (two flow
         slots, ordered by events); the serial part of the recurrence is SRNet alone.
+        pipeline='one_stream': the same batched flow passes, enqueued on the CALLER's stream ahead of
+        their frames (nothing runs concurrently; what a single-stream deployment does).
+        pipeline=False: the reference's loop shape, one FNet pass per frame inside step().
 
         Host I/O (the reference moves every frame H2D and back D2H inside its loop, :273-279):
         a host clip is uploaded batch by batch and the uint8 frames of a finished batch are
@@ -386,7 +389,7 @@ class FRNet(nn.Module):
         s = self.scale
         dev = _norm_device(device if device is not None else lr_data.device)
         host_in = not lr_data.is_cuda
-        stream_io = pipeline and tot_frm >= 2 and not return_device_tensor
+        stream_io = bool(pipeline) and tot_frm >= 2 and not return_device_tensor
         if host_in and stream_io:
             lr_ext = torch.empty(tot_frm + 1, k, c, h, w, dtype=torch.float32, device=dev)
             lr_ext[0].zero_()                               # frame -1 = zeros (tecogan_nets.py:266)
@@ -412,7 +415,7 @@ class FRNet(nn.Module):
                 plan = self._get_plan(k, h, w, dev)
                 lib = L.lib()
                 main = torch.cuda.current_stream(dev)
-                side = self._side_stream(dev)
+                side = main if pipeline == 'one_stream' else self._side_stream(dev)
                 side.wait_stream(main)                      # inputs / weights are ready
                 nbatch = (tot_frm + nb_ - 1) // nb_
                 ev_f, ev_s = self._events(nbatch)
@@ -541,9 +544,8 @@ class FRNet(nn.Module):
                 # recorded BEFORE frame i's nodes => runs right after frames t-1 .. i have been swept:
                 # their weight gradients start on the side stream under the sweep of frames i-1 .. 0
                 tape.record(tape.flush_deferred_async)
-            warped = TG.backward_warp(tape, hr_prev, flow_fm[i - 1],
-                                      dflow_out=functools.partial(flow_grad_slice, i - 1))
-            tran = TG.space_to_depth(tape, warped, s)
+            tran = TG.backward_warp(tape, hr_prev, flow_fm[i - 1],          # warp -> space_to_depth, one launch
+                                    dflow_out=functools.partial(flow_grad_slice, i - 1), s2d=s)
             hr_prev = self.srnet(lr_fm[i], tran, tape=tape, bi=bi_fm[i])
             frames.append(hr_prev)
         hr_data = ops.stack_time(frames)

@@ -694,11 +694,12 @@ def upsample(tape, x, scale, up_mode, mul=1.0):
     return y
 
 
-def backward_warp(tape, x, flow, need_dimg=True, need_dflow=True, dflow_out=None):
+def backward_warp(tape, x, flow, need_dimg=True, need_dflow=True, dflow_out=None, s2d=1):
     """`dflow_out`: a callable returning the buffer the flow gradient is written into (a slice of
     a larger gradient tensor the caller owns, allocated when backward reaches it) instead of
-    the gradient being deposited on the tape."""
-    y = ops.backward_warp(x, flow)
+    the gradient being deposited on the tape.  `s2d` > 1: the result is space_to_depth(warp, s2d) -- the
+    unroll's warp -> space_to_depth pair (tecogan_nets.py:208-212) as one launch each way."""
+    y = ops.backward_warp(x, flow) if s2d == 1 else ops.backward_warp_s2d(x, flow, s2d)
     if tape is not None and (need_dimg or need_dflow):
         def bwd():
             g = tape.pop_grad(y)
@@ -710,11 +711,11 @@ def backward_warp(tape, x, flow, need_dimg=True, need_dflow=True, dflow_out=None
                 # tensor, no accumulation pass
                 tape.unmasked.add(id(x))
                 _, dflow = ops.backward_warp_bwd(x, flow, g, True, need_dflow,
-                                                 dflow_out() if dflow_out is not None else None, dimg_acc=cur)
+                                                 dflow_out() if dflow_out is not None else None, dimg_acc=cur, s2d=s2d)
                 dimg = None
             else:
                 dimg, dflow = ops.backward_warp_bwd(x, flow, g, need_dimg, need_dflow,
-                                                    dflow_out() if dflow_out is not None else None)
+                                                    dflow_out() if dflow_out is not None else None, s2d=s2d)
             if need_dimg and dimg is not None:
                 tape.add_grad(x, dimg)
             if need_dflow and dflow_out is None:

@@ -317,6 +317,19 @@ def backward_warp(x, flow):
     return out
 
 
+def backward_warp_s2d(x, flow, scale):
+    """space_to_depth(backward_warp(x, flow), scale) in one launch (tg_backward_warp_s2d_fwd)."""
+    _chk(x, 'x')
+    _chk(flow, 'flow')
+    n, c, h, w = x.shape
+    if flow.shape != (n, 2, h, w) or h % scale or w % scale:
+        raise L.TecoganHipError(f'backward_warp_s2d: flow {tuple(flow.shape)} vs x {tuple(x.shape)}, scale {scale}')
+    out = torch.empty(n, scale * scale * c, h // scale, w // scale, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_backward_warp_s2d_fwd(x.data_ptr(), flow.data_ptr(), out.data_ptr(), n, c, h, w, scale,
+                                             _stream()), 'tg_backward_warp_s2d_fwd')
+    return out
+
+
 def space_to_depth(x, scale):
     _chk(x, 'x')
     n, c, h, w = x.shape
@@ -616,12 +629,27 @@ def upsample_bwd(dy, scale, up_mode, mul=1.0):
     return dx
 
 
-def backward_warp_bwd(x, flow, dy, need_img=True, need_flow=True, dflow_out=None, dimg_acc=None):
+def backward_warp_bwd(x, flow, dy, need_img=True, need_flow=True, dflow_out=None, dimg_acc=None, s2d=1):
     """`dflow_out`: write the flow gradient into this (contiguous, flow-shaped) buffer instead
     of a new tensor (a slice of the frame-major gradient of the training unroll).  `dimg_acc`: ADD the
-    image gradient to this tensor (the gradient x already has) instead of returning a new one."""
+    image gradient to this tensor (the gradient x already has) instead of returning a new one.
+    `s2d` > 1: dy is the gradient of backward_warp_s2d's output (space_to_depth layout)."""
     _chk(x, 'x'); _chk(flow, 'flow'); _chk(dy, 'dy')
     n, c, h, w = x.shape
+    if s2d > 1:
+        assert dy.shape == (n, s2d * s2d * c, h // s2d, w // s2d), (dy.shape, x.shape, s2d)
+        if dimg_acc is not None:
+            _chk(dimg_acc, 'dimg_acc')
+            dimg = dimg_acc
+        else:
+            dimg = torch.empty_like(x) if need_img else None
+        dflow = None
+        if need_flow:
+            dflow = _chk(dflow_out, 'dflow_out') if dflow_out is not None else torch.empty_like(flow)
+        L.check(L.lib().tg_backward_warp_s2d_bwd(x.data_ptr(), flow.data_ptr(), dy.data_ptr(), _ptr(dimg),
+                                                 1 if dimg_acc is not None else 0, _ptr(dflow), n, c, h, w, s2d,
+                                                 _stream()), 'tg_backward_warp_s2d_bwd')
+        return dimg, dflow
     if dimg_acc is not None:
         _chk(dimg_acc, 'dimg_acc')
         assert dimg_acc.shape == x.shape

@@ -106,6 +106,20 @@ def test_maxpool_floor_mode(ops):
     assert out.shape == ref.shape and torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.parametrize('shape', [(2, 5, 9, 12), (1, 3, 2, 4), (3, 4, 17, 40), (2, 3, 6, 16)])
+def test_maxpool_vector_form_and_bilinear2x_vector_form(ops, shape):
+    """w % 4 == 0: the 16-byte MaxPool2d(2, 2) kernel (exact: bit-identical to the CPU result, odd heights in
+    floor mode); even w: the 2 x 4-patch bilinear x2 kernel against F.interpolate(align_corners=False)
+    (tecogan_nets.py:49-61), incl. the clamped first / last rows and columns."""
+    x = rs(6, shape, -1, 1)
+    out = ops.maxpool2(dev(x))
+    ref = torch.nn.functional.max_pool2d(x, 2, 2)
+    assert out.shape == ref.shape and torch.equal(out.cpu(), ref)
+    up = ops.upsample(dev(x), 2, ops.UP_BILINEAR, 3.0)
+    ref = 3.0 * torch.nn.functional.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    assert up.shape == ref.shape and err(up, ref.numpy()) <= 4e-6
+
+
 CONV_CASES = [
     # n, cin, cout, h, w, act, split(c1), residual
     (1, 64, 64, 22, 40, 1, None, False),
@@ -837,6 +851,11 @@ def test_pipelined_clip_inference_is_deterministic_and_matches_single_stream():
         assert np.array_equal(first, b)
     d = np.abs(a.astype(np.int16) - first.astype(np.int16))
     assert d.max() <= 1 and (d > 0).mean() <= 2e-3, (d.max(), (d > 0).mean())
+    # the same launch list on ONE stream (pipeline='one_stream'): identical kernels, identical bits --
+    # from a host clip (streamed uploads / downloads on the copy stream) and from a device clip
+    assert np.array_equal(net.infer_sequence(clip, 'cuda', pipeline='one_stream'), first)
+    one = net.infer_sequence(clip.cuda(), 'cuda', pipeline='one_stream', return_device_tensor=True)
+    assert np.array_equal(one.cpu().numpy(), first)
 
 
 # --------------------------------------------------- BASELINE full-size checks

@@ -263,3 +263,32 @@ def test_deep_body_runs_without_the_chained_launch():
     TG.chain_check()
     g = net.srnet.resblocks[11].conv['2'].weight.grad
     assert out['hr_data'].shape == (2, 3, 3, 128, 128) and g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+
+
+@pytest.mark.parametrize('scale,shape', [(4, (2, 3, 32, 48)), (2, (1, 3, 12, 20)), (4, (3, 2, 8, 8))])
+def test_backward_warp_s2d_equals_warp_then_space_to_depth(scale, shape):
+    """tg_backward_warp_s2d_fwd / _bwd (the unroll's warp -> space_to_depth pair as one launch each way,
+    tecogan_nets.py:208-212) against the separate entry points: forward bit-identical; backward the flow
+    gradient bit-identical, the image gradient (an atomic scatter in both forms) to summation order --
+    overwrite and accumulate modes."""
+    from tecogan_pytorch_amd import ops
+    g = torch.Generator().manual_seed(7)
+    n, c, h, w = shape
+    x = torch.rand(n, c, h, w, generator=g).cuda()
+    flow = ((torch.rand(n, 2, h, w, generator=g) - 0.5) * 9.0).cuda()      # incl. positions clipped at the border
+    y = ops.backward_warp_s2d(x, flow, scale)
+    ref = ops.space_to_depth(ops.backward_warp(x, flow), scale)
+    assert torch.equal(y, ref)
+    dy = torch.randn(y.shape, generator=g).cuda()
+    dimg, dflow = ops.backward_warp_bwd(x, flow, dy, s2d=scale)
+    rimg, rflow = ops.backward_warp_bwd(x, flow, ops.depth_to_space(dy, scale))
+    assert torch.equal(dflow, rflow)
+    assert torch.allclose(dimg, rimg, rtol=1e-5, atol=1e-6)
+    base = torch.rand(n, c, h, w, generator=g).cuda()
+    acc = base.clone()
+    out = torch.empty_like(flow)
+    ops.backward_warp_bwd(x, flow, dy, dflow_out=out, dimg_acc=acc, s2d=scale)
+    assert torch.equal(out, rflow)
+    assert torch.allclose(acc, base + rimg, rtol=1e-5, atol=1e-6)
+    only_flow = ops.backward_warp_bwd(x, flow, dy, need_img=False, s2d=scale)
+    assert only_flow[0] is None and torch.equal(only_flow[1], rflow)
