@@ -11,6 +11,8 @@ for storage and for pure data movement (slicing / stacking / zero fill) only.
 Gradients of intermediate tensors are keyed by tensor identity; parameter
 gradients accumulate into `param.grad` (allocated and zeroed by the caller).
 """
+import os
+
 import torch
 
 from .. import ops
@@ -617,6 +619,7 @@ def convt3x3s2(tape, layer, x, act=RELU):
 #   2*oy - 1 + ky = 2*(oy + ty - 1) + py
 # ---------------------------------------------------------------------------
 _K4 = {0: (1, 0), 1: (0, 1), 2: (1, 1), 3: (0, 2)}   # ky -> (py, ty)
+DIRECT_CONV4 = os.environ.get('TG_CONV4_DIRECT', '1') != '0'   # 0: the embedded form everywhere (lab / tests)
 
 
 def _conv4_embed(w4):
@@ -627,17 +630,28 @@ def _conv4_embed(w4):
 
 
 def conv4x4s2(tape, holder, x, need_dx=True):
-    """holder.weight: (co, ci, 4, 4).  Returns (n, co, h/2, w/2)."""
+    """holder.weight: (co, ci, 4, 4).  Returns (n, co, h/2, w/2).
+    Forward and data gradient run on the direct K = 16 ci kernel (tg_conv4x4s2_fwd / _dgrad, round 4) where it
+    applies (ci, co multiples of 64, w a multiple of 64); smaller maps and the weight gradient use the embedding
+    into a phase-masked 3x3 conv on space_to_depth(x, 2) -- the copy is then made in backward, only when the
+    weights take a gradient."""
     w = holder.weight
     co, ci = w.shape[:2]
-    s = ops.space_to_depth(x, 2)
-    pk = _CACHE.get(holder, ('c4f',), _ver(w), lambda: ops.pack_conv3x3(_conv4_embed(w.detach())))
-    # phase coordinate 1 owns tap rows {0, 1}, coordinate 0 rows {1, 2}: 4 of 9 taps per channel
+    n, _, h_, w_ = x.shape
+    direct = DIRECT_CONV4 and ops.conv4x4s2_supported(n, ci, co, h_, w_)
     sparse = ci % 8 == 0 and co > 32
-    if sparse:
-        y = ops.conv3x3_phased(s, pk[0], 4 * ci, co, pk[3], 1, ci, ops.TAPS_12, ops.TAPS_01)
+    if direct:
+        pk4 = _CACHE.get(holder, ('c4x',), _ver(w), lambda: ops.pack_conv4x4s2(w.detach().contiguous()))
+        y = ops.conv4x4s2(x, pk4[0], co)
+        s_held = [None]
     else:
-        y = ops.conv3x3(s, pk[0], None, 4 * ci, co, pk[3])
+        s_held = [ops.space_to_depth(x, 2)]
+        pk = _CACHE.get(holder, ('c4f',), _ver(w), lambda: ops.pack_conv3x3(_conv4_embed(w.detach())))
+        # phase coordinate 1 owns tap rows {0, 1}, coordinate 0 rows {1, 2}: 4 of 9 taps per channel
+        if sparse:
+            y = ops.conv3x3_phased(s_held[0], pk[0], 4 * ci, co, pk[3], 1, ci, ops.TAPS_12, ops.TAPS_01)
+        else:
+            y = ops.conv3x3(s_held[0], pk[0], None, 4 * ci, co, pk[3])
     if tape is None:
         return y
 
@@ -649,16 +663,24 @@ def conv4x4s2(tape, holder, x, need_dx=True):
             def post(ge):
                 _, inv = _embed_index('conv4', co, ci, ge.device)
                 ops.index_gather(ge, inv, out=_grad_buf(w), accumulate=True)
+            s = s_held[0] if s_held[0] is not None else ops.space_to_depth(x, 2)
             tape.defer_wgrad(('c4', id(holder)), g, s, None, 0, post, phased=(ci, ops.TAPS_12, ops.TAPS_01))
         if need_dx:
+            a = tape.act_outputs.get(id(x))
+            fuse = a is not None and tape.grad(x) is None
+            if direct:
+                # x = act(conv(.)): the epilogue applies act'(x) (one pass over the tensor instead of three)
+                fuse = fuse and a in (ops.ACT_RELU, ops.ACT_LRELU02)
+                gx = ops.conv4x4s2_dgrad(g, pk4[1], ci, act_y=x if fuse else None, act=a if fuse else ops.ACT_NONE)
+                tape.add_grad(x, gx, act_applied=fuse)
+                return
             pkd = _CACHE.get(holder, ('c4d',), _ver(w),
                              lambda: ops.pack_conv3x3_dgrad(_conv4_embed(w.detach())))
             if ci % 64 == 0:    # rot180 taps: coordinate 1 owns rows {1, 2}, coordinate 0 rows {0, 1}
                 ds = ops.conv3x3_phased(g, pkd[0], co, 4 * ci, pkd[3], 2, ci, ops.TAPS_01, ops.TAPS_12)
             else:
                 ds = ops.conv3x3(g, pkd[0], None, co, 4 * ci, pkd[3], ksplit=1)
-            a = tape.act_outputs.get(id(x))
-            if a is not None and tape.grad(x) is None:
+            if fuse:
                 # x = act(conv(.)): the depth-to-space pass applies act'(x) on the way out (one pass over
                 # the HR tensor instead of three)
                 gx, fused = ops.depth_to_space(ds, 2, act_y=x, act=a)

@@ -692,6 +692,46 @@ def depth_to_space(x, scale, act_y=None, act=ACT_NONE):
     return y
 
 
+def conv4x4s2_supported(n, ci, co, h, w):
+    return bool(L.lib().tg_conv4x4s2_supported(n, ci, co, h, w))
+
+
+def pack_conv4x4s2(w):
+    """OIHW (co, ci, 4, 4) -> (forward pack, data-gradient pack) of tg_conv4x4s2_fwd / _dgrad."""
+    _chk(w, 'w')
+    co, ci = w.shape[:2]
+    lib = L.lib()
+    nfl = lib.tg_conv4x4s2_packed_floats(ci, co)
+    pf = torch.empty(nfl, dtype=torch.float32, device=w.device)
+    pd = torch.empty(nfl, dtype=torch.float32, device=w.device)
+    L.check(lib.tg_conv4x4s2_pack(w.data_ptr(), pf.data_ptr(), pd.data_ptr(), ci, co, _stream()), 'tg_conv4x4s2_pack')
+    return pf, pd
+
+
+def conv4x4s2(x, w_fwd, co, out=None):
+    """nn.Conv2d(ci, co, 4, 2, 1, bias=False)(x) (tecogan_nets.py:322-340) on the direct kernel."""
+    _chk(x, 'x')
+    n, ci, h, w = x.shape
+    y = out if out is not None else torch.empty(n, co, h // 2, w // 2, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_conv4x4s2_fwd(x.data_ptr(), w_fwd.data_ptr(), y.data_ptr(), n, ci, co, h, w, _stream()),
+            'tg_conv4x4s2_fwd')
+    return y
+
+
+def conv4x4s2_dgrad(g, w_dgrad, ci, act_y=None, act=ACT_NONE):
+    """Gradient of conv4x4s2's input from the gradient g of its output; act_y / act: multiplied by act'(act_y)
+    on the way out (act_y = the conv's input when that is an activation output)."""
+    _chk(g, 'g')
+    n, co, oh, ow = g.shape
+    dx = torch.empty(n, ci, 2 * oh, 2 * ow, dtype=torch.float32, device=g.device)
+    if act_y is not None:
+        _chk(act_y, 'act_y')
+        assert act_y.shape == dx.shape
+    L.check(L.lib().tg_conv4x4s2_dgrad(g.data_ptr(), w_dgrad.data_ptr(), _ptr(act_y), act, dx.data_ptr(), n, ci, co,
+                                       2 * oh, 2 * ow, _stream()), 'tg_conv4x4s2_dgrad')
+    return dx
+
+
 def charbonnier(x, y, loss_accum, loss_scale, grad_scale=None, eps=1e-6):
     """loss_accum[0] += loss_scale * sum sqrt((x-y)^2+eps); returns d loss / dx (scaled) or None."""
     _chk(x, 'x'); _chk(y, 'y')

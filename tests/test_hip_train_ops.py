@@ -811,3 +811,33 @@ def test_body_bias_gradients_ride_on_the_layered_launch(ops):
         assert torch.equal(a, b)
     for L_ in range(1, nl):
         assert relerr(db1[L_ - 1], db2[L_]) <= 1e-5, L_
+
+
+@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 8, 64), (1, 64, 128, 6, 128), (3, 128, 64, 10, 64), (1, 64, 64, 2, 192)])
+def test_conv4x4s2_direct_kernels_vs_torch(n, ci, co, h, w):
+    """tg_conv4x4s2_fwd / _dgrad (Conv2d(ci, co, 4, 2, 1, bias=False) of the discriminator blocks,
+    tecogan_nets.py:322-340, taken directly) against torch's CPU conv2d and its autograd input gradient
+    (fp64 reference; tolerance 2e-5 relative to the output scale: K = 16 ci fp32 products in another order),
+    incl. heights that do not fill the 4-row tiles, both tile forms (64 / 32 output columns) and the
+    epilogue's act'(.) factor."""
+    from tecogan_pytorch_amd import ops
+    g_ = torch.Generator().manual_seed(11)
+    x = torch.randn(n, ci, h, w, generator=g_)
+    wt = torch.randn(co, ci, 4, 4, generator=g_) * 0.05
+    assert ops.conv4x4s2_supported(n, ci, co, h, w)
+    pf, pd = ops.pack_conv4x4s2(wt.cuda())
+    y = ops.conv4x4s2(x.cuda(), pf, co)
+    xd = x.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xd, wt.double(), None, 2, 1)
+    assert y.shape == ref.shape
+    assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    g = torch.randn(ref.shape, generator=g_)
+    ref.backward(g.double())
+    dx = ops.conv4x4s2_dgrad(g.cuda(), pd, ci)
+    assert (dx.cpu().double() - xd.grad).abs().max().item() <= 2e-5 * xd.grad.abs().max().item()
+    act_y = torch.randn(n, ci, h, w, generator=g_)
+    dxa = ops.conv4x4s2_dgrad(g.cuda(), pd, ci, act_y=act_y.cuda(), act=ops.ACT_LRELU02)
+    assert torch.equal(dxa.cpu(), torch.where(act_y > 0, dx.cpu(), dx.cpu() * 0.2))
+    dxr = ops.conv4x4s2_dgrad(g.cuda(), pd, ci, act_y=act_y.cuda(), act=ops.ACT_RELU)
+    assert torch.equal(dxr.cpu(), torch.where(act_y > 0, dx.cpu(), dx.cpu() * 0.0))
+    assert not ops.conv4x4s2_supported(n, ci, co, h, 32) and not ops.conv4x4s2_supported(n, 27, co, h, w)
