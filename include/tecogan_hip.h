@@ -115,15 +115,19 @@ int tg_conv3x3_fwd_phased(const float* x, int64_t x_nstride, const float* w_pack
  * out: act_y (n, ci, h, w) the activation OUTPUT that was this conv's input, act = TG_ACT_RELU | TG_ACT_LRELU02).
  * x, dx: (n, ci, h, w); y, g: (n, co, h/2, w/2), contiguous.  Weights: tg_conv4x4s2_pack from OIHW (co, ci, 4, 4)
  * into two buffers of tg_conv4x4s2_packed_floats(ci, co) floats (either may be NULL).
- * tg_conv4x4s2_supported: ci, co multiples of 64, h even, w a multiple of 64; other shapes keep the embedded form
- * (tg_conv3x3_fwd_phased on tg_space_to_depth(x, 2)).  The weight gradient stays on that form as well. */
+ * tg_conv4x4s2_supported: ci, co multiples of 64, h even, w a multiple of 64 -- or the small maps of the deeper
+ * blocks, w = 32 (h % 8 == 0) / w = 16 (h % 16 == 0): 32 pixels of the matrix tile are then 2 / 4 rows, the input
+ * channels are split over several workgroups and a second launch adds the partial sums in a fixed order; such calls
+ * need tg_conv4x4s2_workspace_floats(.., dgrad) floats of workspace (0: none, workspace may be NULL).  Other shapes
+ * keep the embedded form (tg_conv3x3_fwd_phased on tg_space_to_depth(x, 2)), and so does the weight gradient. */
 int tg_conv4x4s2_supported(int n, int ci, int co, int h, int w);
 size_t tg_conv4x4s2_packed_floats(int ci, int co);
 int tg_conv4x4s2_pack(const float* w, float* w_fwd, float* w_dgrad, int ci, int co, tg_stream_t stream);
-int tg_conv4x4s2_fwd(const float* x, const float* w_fwd, float* y, int n, int ci, int co, int h, int w,
+size_t tg_conv4x4s2_workspace_floats(int n, int ci, int co, int h, int w, int dgrad);
+int tg_conv4x4s2_fwd(const float* x, const float* w_fwd, float* y, float* workspace, int n, int ci, int co, int h, int w,
                      tg_stream_t stream);
-int tg_conv4x4s2_dgrad(const float* g, const float* w_dgrad, const float* act_y, int act, float* dx, int n, int ci,
-                       int co, int h, int w, tg_stream_t stream);
+int tg_conv4x4s2_dgrad(const float* g, const float* w_dgrad, const float* act_y, int act, float* dx, float* workspace,
+                       int n, int ci, int co, int h, int w, tg_stream_t stream);
 /* STRIDE-2 3x3 conv on small frames: y(oy, ox) = act(sum_k w[k] x(2 oy - 1 + ky, 2 ox - 1 + kx) + bias),
  * zero outside x (n, cin, 2 h_out, 2 w_out) -- the data gradient of ConvTranspose2d(k3, s2, p1, op1)
  * (tecogan_nets.py:119-126) taken directly (K = 9 cin) instead of through the 4 cin-channel phased

@@ -103,8 +103,9 @@ SIGNATURES = {
     'tg_conv4x4s2_supported': (I, [I, I, I, I, I]),
     'tg_conv4x4s2_packed_floats': (SZ, [I, I]),
     'tg_conv4x4s2_pack': (I, [P, P, P, I, I, P]),
-    'tg_conv4x4s2_fwd': (I, [P, P, P, I, I, I, I, I, P]),
-    'tg_conv4x4s2_dgrad': (I, [P, P, P, I, P, I, I, I, I, I, P]),
+    'tg_conv4x4s2_workspace_floats': (SZ, [I, I, I, I, I, I]),
+    'tg_conv4x4s2_fwd': (I, [P, P, P, P, I, I, I, I, I, P]),
+    'tg_conv4x4s2_dgrad': (I, [P, P, P, I, P, P, I, I, I, I, I, P]),
     'tg_backward_warp_s2d_fwd': (I, [P, P, P, I, I, I, I, I, P]),
     'tg_backward_warp_s2d_bwd': (I, [P, P, P, P, I, P, I, I, I, I, I, P]),
     'tg_depth_to_space': (I, [P, P, I, I, I, I, I, P]),

@@ -713,7 +713,10 @@ def conv4x4s2(x, w_fwd, co, out=None):
     _chk(x, 'x')
     n, ci, h, w = x.shape
     y = out if out is not None else torch.empty(n, co, h // 2, w // 2, dtype=torch.float32, device=x.device)
-    L.check(L.lib().tg_conv4x4s2_fwd(x.data_ptr(), w_fwd.data_ptr(), y.data_ptr(), n, ci, co, h, w, _stream()),
+    lib = L.lib()
+    nws = lib.tg_conv4x4s2_workspace_floats(n, ci, co, h, w, 0)      # partial sums of the small-map form
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+    L.check(lib.tg_conv4x4s2_fwd(x.data_ptr(), w_fwd.data_ptr(), y.data_ptr(), _ptr(ws), n, ci, co, h, w, _stream()),
             'tg_conv4x4s2_fwd')
     return y
 
@@ -727,8 +730,11 @@ def conv4x4s2_dgrad(g, w_dgrad, ci, act_y=None, act=ACT_NONE):
     if act_y is not None:
         _chk(act_y, 'act_y')
         assert act_y.shape == dx.shape
-    L.check(L.lib().tg_conv4x4s2_dgrad(g.data_ptr(), w_dgrad.data_ptr(), _ptr(act_y), act, dx.data_ptr(), n, ci, co,
-                                       2 * oh, 2 * ow, _stream()), 'tg_conv4x4s2_dgrad')
+    lib = L.lib()
+    nws = lib.tg_conv4x4s2_workspace_floats(n, ci, co, 2 * oh, 2 * ow, 1)
+    ws = torch.empty(nws, dtype=torch.float32, device=g.device) if nws else None
+    L.check(lib.tg_conv4x4s2_dgrad(g.data_ptr(), w_dgrad.data_ptr(), _ptr(act_y), act, dx.data_ptr(), _ptr(ws), n, ci, co,
+                                   2 * oh, 2 * ow, _stream()), 'tg_conv4x4s2_dgrad')
     return dx
 
 

@@ -813,13 +813,14 @@ def test_body_bias_gradients_ride_on_the_layered_launch(ops):
         assert relerr(db1[L_ - 1], db2[L_]) <= 1e-5, L_
 
 
-@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 8, 64), (1, 64, 128, 6, 128), (3, 128, 64, 10, 64), (1, 64, 64, 2, 192)])
+@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 8, 64), (1, 64, 128, 6, 128), (3, 128, 64, 10, 64), (1, 64, 64, 2, 192),
+                                         (3, 64, 128, 32, 32), (2, 128, 256, 16, 16), (24, 128, 256, 16, 16), (1, 64, 64, 8, 32)])
 def test_conv4x4s2_direct_kernels_vs_torch(n, ci, co, h, w):
     """tg_conv4x4s2_fwd / _dgrad (Conv2d(ci, co, 4, 2, 1, bias=False) of the discriminator blocks,
     tecogan_nets.py:322-340, taken directly) against torch's CPU conv2d and its autograd input gradient
     (fp64 reference; tolerance 2e-5 relative to the output scale: K = 16 ci fp32 products in another order),
-    incl. heights that do not fill the 4-row tiles, both tile forms (64 / 32 output columns) and the
-    epilogue's act'(.) factor."""
+    incl. heights that do not fill the 4-row tiles, both tile forms (64 / 32 output columns), the small-map forms
+    (w = 32 / 16: folded rows, input channels split over workgroups + the summing launch) and the act'(.) factor."""
     from tecogan_pytorch_amd import ops
     g_ = torch.Generator().manual_seed(11)
     x = torch.randn(n, ci, h, w, generator=g_)
@@ -840,4 +841,4 @@ def test_conv4x4s2_direct_kernels_vs_torch(n, ci, co, h, w):
     assert torch.equal(dxa.cpu(), torch.where(act_y > 0, dx.cpu(), dx.cpu() * 0.2))
     dxr = ops.conv4x4s2_dgrad(g.cuda(), pd, ci, act_y=act_y.cuda(), act=ops.ACT_RELU)
     assert torch.equal(dxr.cpu(), torch.where(act_y > 0, dx.cpu(), dx.cpu() * 0.0))
-    assert not ops.conv4x4s2_supported(n, ci, co, h, 32) and not ops.conv4x4s2_supported(n, 27, co, h, w)
+    assert not ops.conv4x4s2_supported(n, ci, co, 6, 32) and not ops.conv4x4s2_supported(n, 27, co, h, w)

@@ -51,7 +51,8 @@ for clips in (24, 12):
 
 print('direct kernels (tg_conv4x4s2_fwd / _dgrad):')
 for clips in (24, 12):
-    for name, ci, co, hw in (('block1', 64, 64, crop), ('block2', 64, 64, crop // 2), ('block3', 64, 128, crop // 4)):
+    for name, ci, co, hw in (('block1', 64, 64, crop), ('block2', 64, 64, crop // 2), ('block3', 64, 128, crop // 4),
+                             ('block4', 128, 256, crop // 8)):
         if not ops.conv4x4s2_supported(clips, ci, co, hw, hw):
             continue
         wt = torch.randn(co, ci, 4, 4, device='cuda') * 0.05
