@@ -28,7 +28,7 @@ for k, v in aten.most_common(25):
 g = collections.Counter(); gns = collections.Counter()
 for r in rows:
     k = r['Kernel_Name']
-    if 'conv3x3' in k or 'wgrad3x3' in k or 'convt3x3' in k:
+    if 'conv3x3' in k or 'wgrad3x3' in k or 'convt3x3' in k or 'conv4' in k:
         key = (k.split('(')[0][-60:], r.get('Grid_Size_X', r.get('Grid_Size', '?')), r.get('Workgroup_Size_X', ''))
         g[key] += 1; gns[key] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
 print('conv launches by (kernel, grid, block): count, avg us, total ms')
