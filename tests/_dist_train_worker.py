@@ -18,7 +18,7 @@ for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
 
 import torch  # noqa: E402
 
-CROP, T, SCALE, GLOBAL_N = 32, 4, 4, 2
+CROP, T, SCALE, GLOBAL_N = int(os.environ.get('TG_TEST_CROP', '32')), 4, 4, 2
 
 
 def make_opt():
@@ -74,7 +74,9 @@ def main():
         logs.append({'local': local, 'reduced': dict(m.log_dict)})
     final = {('G.' + k): v.detach().cpu().clone() for k, v in m.net_G.state_dict().items()}
     final.update({('D.' + k): v.detach().cpu().clone() for k, v in m.net_D.state_dict().items()})
-    torch.save({'after_init': after_init, 'final': final, 'logs': logs}, outfile)
+    from tecogan_pytorch_amd.models import train_graph as TG
+    torch.save({'after_init': after_init, 'final': final, 'logs': logs,
+                'chained_launches': int(TG._ChainState.epoch), 'chain_disabled': bool(TG._ChainState.disabled)}, outfile)
     if world > 1:
         torch.distributed.barrier()
         dist_utils.destroy_c_comm()

@@ -96,6 +96,28 @@ def test_two_ranks_rccl_equal_single_process(tmp_path, comm):
     _check_two_ranks(res2, res1)
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs 2 GPUs (RCCL over xGMI)')
+def test_two_ranks_rccl_with_chained_body_launches(tmp_path):
+    """The first real DDP + chained-launch combination: at the REDS crop 128 (2 x 32 x 32 LR
+    frames, the 16 x 16 x 4 row-chain form) every rank's SRNet body runs as persistent chained launches forward
+    and backward while RCCL exchanges gradients / SyncBN statistics between the steps.  Replicas must stay
+    bit-identical, no launch may have tripped its fail-safe, and the result must match the single-process run
+    (chained as well) on the whole batch."""
+    env = {'TG_TEST_CROP': '128'}
+    res1 = _run(1, 'none', tmp_path, 'c1', env)[0]
+    res2 = _run(2, 'nccl', tmp_path, 'c2', env)
+    for r in [res1] + res2:
+        assert r['chained_launches'] > 0 and not r['chain_disabled'], (r['chained_launches'], r['chain_disabled'])
+    _check_two_ranks(res2, res1)
+
+
+def test_worker_at_crop128_runs_the_chained_body_launches(tmp_path):
+    """One-GPU half of the test above (the two-GPU half is skipped on a one-GPU box): the worker at the REDS crop
+    really goes through the chained launches, and none trips its fail-safe."""
+    r = _run(1, 'none', tmp_path, 'c1', {'TG_TEST_CROP': '128'})[0]
+    assert r['chained_launches'] >= 2 * 2 * 7 and not r['chain_disabled'], (r['chained_launches'], r['chain_disabled'])
+
+
 def test_c_abi_communicator_world1():
     """tg_comm_* / tg_allreduce_sum_f32 / tg_allgather_f32 through RCCL with one rank: binds
     librccl at run time, creates a communicator from a unique id, reduces in place."""
