@@ -309,10 +309,13 @@ class FRNet(nn.Module):
     def _weights_key(self):
         return tuple(ops.param_version(p) for p in self.parameters())
 
-    def _get_plan(self, n, h, w, device, fnet_only=False):
-        """Plans are cached per (batch, size, device, kind); a weight update drops them all."""
+    def _get_plan(self, n, h, w, device, fnet_only=False, wk=None):
+        """Plans are cached per (batch, size, device, kind); a weight update drops them all.
+        wk: the caller's _weights_key() of THIS call (a walk over ~100 parameters, ~50 us: infer_sequence takes it once
+        per clip instead of once per flow pass)."""
         device = _norm_device(device)
-        wk = self._weights_key()
+        if wk is None:
+            wk = self._weights_key()
         if self._plan_key != wk:
             self._plan, self._plan_key = {}, wk
         key = (n, h, w, str(device), fnet_only)
@@ -371,7 +374,10 @@ class FRNet(nn.Module):
         pipeline=True: FNet depends only on the LR frames, so the flows of the next
         TG_FNET_BATCH (default 8) frame pairs are estimated by one batched FNet pass on a
         second HIP stream while warp+SRNet runs frame by frame on the first (two flow
-        slots, ordered by events); the serial part of the recurrence is SRNet alone.
+        slots, ordered by events); the serial part of the recurrence is SRNet alone.  Frame 0 warps the
+        zero state -- its warped frame is zero whatever the flow -- so it runs on a zero flow buffer, ahead
+        of the first flow pass, and its (unused) flow is not estimated: bit-identical, one FNet pass less
+        per clip on the critical path.
         pipeline='one_stream': the same batched flow passes, enqueued on the CALLER's stream ahead of
         their frames (nothing runs concurrently; what a single-stream deployment does).
         pipeline=False: the reference's loop shape, one FNet pass per frame inside step().
@@ -412,12 +418,19 @@ class FRNet(nn.Module):
                 # split-K) while the main stream runs warp + SRNet frame by frame on the
                 # previous batch -- the serial part of the recurrence is SRNet alone.
                 nb_ = max(1, min(max(1, int(os.environ.get('TG_FNET_BATCH', '8')) // k), tot_frm))
-                plan = self._get_plan(k, h, w, dev)
+                nb0 = max(1, min(nb_, max(1, int(os.environ.get('TG_FNET_FIRST_BATCH', '8')) // k)))   # lab knob
+                batches, i0_ = [], 0           # (first frame, frames); frame 0 needs no flow: the first batch has one more
+                while i0_ < tot_frm:
+                    cnt_ = min(nb0 + 1 if not batches else nb_, tot_frm - i0_)
+                    batches.append((i0_, cnt_))
+                    i0_ += cnt_
+                wk = self._weights_key()
+                plan = self._get_plan(k, h, w, dev, wk=wk)
                 lib = L.lib()
                 main = torch.cuda.current_stream(dev)
                 side = main if pipeline == 'one_stream' else self._side_stream(dev)
                 side.wait_stream(main)                      # inputs / weights are ready
-                nbatch = (tot_frm + nb_ - 1) // nb_
+                nbatch = len(batches)
                 ev_f, ev_s = self._events(nbatch)
                 copy = self._copy_stream(dev) if stream_io else None
                 ev_in = [torch.cuda.Event() for _ in range(nbatch)] if (stream_io and host_in) else None
@@ -425,35 +438,46 @@ class FRNet(nn.Module):
                     host_out = torch.empty(tot_frm, k, s * h, s * w, c, dtype=torch.uint8, pin_memory=True)
                     copy.wait_stream(main)                  # lr_ext / u8 allocations are visible
                 if ev_in is not None:                       # uploads run ahead on the copy stream
-                    for b_ in range(nbatch):
-                        i0 = b_ * nb_
-                        cnt = min(nb_, tot_frm - i0)
+                    for b_, (i0, cnt) in enumerate(batches):
                         with torch.cuda.stream(copy):
                             lr_ext[i0 + 1:i0 + 1 + cnt].copy_(lr_host[i0:i0 + cnt], non_blocking=True)
                             ev_in[b_].record(copy)
                 fsz = k * 2 * plan.fh * plan.fw * 4         # bytes of one frame's LR flows (k clips)
-                for b_ in range(nbatch):
-                    i0 = b_ * nb_
-                    cnt = min(nb_, tot_frm - i0)
-                    fplan = self._get_plan(cnt * k, h, w, dev, fnet_only=True)
+                # Frame 0 of a clip warps the ZERO state (hr_prev = 0, tecogan_nets.py:266-268): its warped frame is
+                # zero whatever the flow is, so it runs on an all-zero flow buffer WITHOUT waiting for the first flow
+                # pass -- bit-identical, and the only frame whose flow pass nothing could hide (0.4 ms per clip).
+                zkey = (k, plan.fh, plan.fw, str(dev))
+                zflow = getattr(self, '_zero_flow', None)
+                if zflow is None or zflow[0] != zkey:
+                    zflow = self._zero_flow = (zkey, torch.zeros(k * 2 * plan.fh * plan.fw, dtype=torch.float32, device=dev))
+                def srnet_frame(i, flow_ptr):
+                    L.check(lib.tg_frnet_step_srnet(plan.handle, flow_ptr, lr[i].data_ptr(), hr[i & 1].data_ptr(),
+                                                    hr[(i + 1) & 1].data_ptr(), u8[i].data_ptr(),
+                                                    main.cuda_stream), 'tg_frnet_step_srnet')
+
+                for b_, (i0, cnt) in enumerate(batches):
                     if ev_in is not None:
                         side.wait_event(ev_in[b_])
                         main.wait_event(ev_in[b_])
-                    if b_ >= 2:
-                        side.wait_event(ev_s[b_ - 2])       # flow slot b_&1 consumed by batch b_-2
-                    L.check(lib.tg_frnet_step_phase(fplan.handle, 1, b_ & 1,
-                                                    lr_ext[i0 + 1:i0 + 1 + cnt].data_ptr(),
-                                                    lr_ext[i0:i0 + cnt].data_ptr(), None, None, None,
-                                                    side.cuda_stream), 'tg_frnet_step_phase(1)')
-                    ev_f[b_].record(side)
-                    main.wait_event(ev_f[b_])
-                    flow0 = lib.tg_frnet_plan_flow(fplan.handle, b_ & 1)
-                    for j in range(cnt):
-                        i = i0 + j
-                        L.check(lib.tg_frnet_step_srnet(plan.handle, flow0 + j * fsz,
-                                                        lr[i].data_ptr(), hr[i & 1].data_ptr(),
-                                                        hr[(i + 1) & 1].data_ptr(), u8[i].data_ptr(),
-                                                        main.cuda_stream), 'tg_frnet_step_srnet')
+                    if i0 == 0:
+                        # enqueued BEFORE the first flow pass: the GPU has work ~0.3 ms earlier (the flow pass is one C
+                        # call of ~20 launches), which is all a 20-frame clip loses against a 60-frame one per frame
+                        srnet_frame(0, zflow[1].data_ptr())
+                    f0 = 1 if i0 == 0 else 0                 # frame 0's flow is never used: not estimated
+                    npair = cnt - f0
+                    if npair > 0:
+                        fplan = self._get_plan(npair * k, h, w, dev, fnet_only=True, wk=wk)
+                        if b_ >= 2:
+                            side.wait_event(ev_s[b_ - 2])   # flow slot b_&1 consumed by batch b_-2
+                        L.check(lib.tg_frnet_step_phase(fplan.handle, 1, b_ & 1,
+                                                        lr_ext[i0 + f0 + 1:i0 + 1 + cnt].data_ptr(),
+                                                        lr_ext[i0 + f0:i0 + cnt].data_ptr(), None, None, None,
+                                                        side.cuda_stream), 'tg_frnet_step_phase(1)')
+                        ev_f[b_].record(side)
+                        main.wait_event(ev_f[b_])
+                        flow0 = lib.tg_frnet_plan_flow(fplan.handle, b_ & 1)
+                        for j in range(f0, cnt):
+                            srnet_frame(i0 + j, flow0 + (j - f0) * fsz)
                     ev_s[b_].record(main)
                     if stream_io:                           # download batch b_ while batch b_+1 computes
                         copy.wait_event(ev_s[b_])
