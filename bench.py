@@ -818,10 +818,19 @@ def main():
                 'algorithmic_gflop_per_launch': dom_mf['gflop'] / dom_mf['launches'],
             }
             result['roofline']['traffic_stale'] = pmc_traffic_stale()
+            ct_gflop = 0.0                 # direct (non-Winograd) FLOPs inside the dominant launch
             if dom_mf['kernel'] == 'conv3x3_wino_resident_kernel':
                 nlay = 1 + 2 * 10
                 result['roofline']['layers_per_launch'] = nlay
+                plain_ct = [r for r in rows if r['kernel'] == 'convt3x3s2_mfma_kernel' and r['launches'] > 0]
+                if s == 4 and not plain_ct:
+                    # SRNet's first ConvTranspose2d runs as the launch's tail (direct fp32 MFMA products)
+                    ct_gflop = 2.0 * 64 * 9 * 64 * h * w / 1e9
+                    result['roofline']['tail'] = {'layer': 'ConvTranspose2d(64, 64, 3, 2, 1, 1) + ReLU on the resident blocks',
+                                                  'gflop': ct_gflop, 'form': 'direct fp32 MFMA (executed = algorithmic)',
+                                                  'separate_launch': 'TG_WINO_RES_CT=0'}
                 result['roofline']['avg_layer_us'] = 1e3 * dom_mf['ms_per_frame'] / nlay
+                result['roofline']['avg_layer_us_is'] = 'launch time / 21 conv layers' + (' (the tail included)' if ct_gflop else '')
                 result['roofline']['note'] = ('ONE persistent launch per frame: SRNet conv_in + 20 residual-block convs on '
                                               'LDS-resident 8x24-pixel blocks (tg_conv3x3_wino_res.hip); per-layer launches of '
                                               'the same arithmetic: TG_WINO_RES=0')
@@ -832,10 +841,13 @@ def main():
                 # the kernel actually occupies is frac * 16/36.
                 result['roofline']['form'] = ('Winograd F(2x2,3x3), fp32 MFMA 16x16x4: 16 of 36 algorithmic '
                                               'multiplies are executed')
-                result['roofline']['mfma_executed_tflops'] = ach * 16.0 / 36.0
-                result['roofline']['mfma_executed_frac'] = ach * 16.0 / 36.0 / MFMA_F32_PEAK_TFLOPS
+                # (a transposed-conv tail inside the launch is direct: its FLOPs are executed one for one)
+                g_all = dom_mf['gflop'] / dom_mf['launches']
+                ex_share = ((g_all - ct_gflop) * 16.0 / 36.0 + ct_gflop) / g_all
+                result['roofline']['mfma_executed_tflops'] = ach * ex_share
+                result['roofline']['mfma_executed_frac'] = ach * ex_share / MFMA_F32_PEAK_TFLOPS
                 # against the form's own ceiling (every MFMA issue slot busy = 157.3 x 36/16 algorithmic)
-                result['roofline']['frac_vs_winograd_ceiling'] = ach / (MFMA_F32_PEAK_TFLOPS * 2.25)
+                result['roofline']['frac_vs_winograd_ceiling'] = result['roofline']['mfma_executed_frac']
                 # `frac` is the share of the fp32-MFMA peak the kernel actually occupies (executed FLOPs): the
                 # algorithmic rate of a Winograd kernel may exceed the peak, and no line should print > 1
                 result['roofline']['frac_algorithmic'] = ach / MFMA_F32_PEAK_TFLOPS

@@ -233,6 +233,23 @@ int tg_conv3x3_wino_resident_supported(int n, int cout, int h, int w);
 int64_t tg_conv3x3_wino_resident_ws_bytes(int h, int w);
 int tg_conv3x3_wino_resident(const tg_wino_layer* layers, int n_layers, int cout, int h, int w,
                              void* workspace, int epoch, tg_stream_t stream);
+/* The same launch with SRNet's FIRST up-sampling layer (nn.ConvTranspose2d(64, 64, 3, 2, 1, output_padding=1) + ReLU,
+ * tecogan_nets.py:119-126) as its tail: after the last conv layer's ring exchange every workgroup applies the
+ * transposed convolution to its resident 8x24 block (+1 ring pixel right / below) and writes convt->y
+ * (64, 2h, 2w); layers[n_layers-1].y is then NOT written.  Direct fp32 MFMA products (no Winograd): the result
+ * equals tg_convt3x3s2_fwd on the same input up to the summation order (about 1e-6 relative).
+ * u_packed: tg_conv3x3_wino_resident_ct_pack of the layer's (cin 64, cout 64, 3, 3) weights
+ * (tg_conv3x3_wino_resident_ct_floats() floats).  convt == NULL: tg_conv3x3_wino_resident. */
+typedef struct tg_wres_convt {
+  const float* u_packed;
+  const float* bias;
+  float* y;
+  int act;
+} tg_wres_convt;
+size_t tg_conv3x3_wino_resident_ct_floats(void);
+int tg_conv3x3_wino_resident_ct_pack(const float* w_iohw, float* out, tg_stream_t stream);
+int tg_conv3x3_wino_resident_ct(const tg_wino_layer* layers, int n_layers, int cout, int h, int w,
+                                void* workspace, int epoch, const tg_wres_convt* convt, tg_stream_t stream);
 
 /* Dependent 3x3 layers of SMALL frames (the training unroll: 2 x 32 x 32 / 2 x 64 x 64 LR pixels per
  * frame, tecogan_nets.py:174-225) in ONE launch: one persistent workgroup per (image row, 32-pixel

@@ -47,6 +47,10 @@ class PackItem(C.Structure):
                 ('i_total', C.c_int), ('i_off', C.c_int)]
 
 
+class WresConvT(C.Structure):
+    _fields_ = [('u_packed', C.c_void_p), ('bias', C.c_void_p), ('y', C.c_void_p), ('act', C.c_int)]
+
+
 class LayerWeights(C.Structure):
     _fields_ = [('w', C.c_void_p), ('b', C.c_void_p), ('u', C.c_void_p)]
 
@@ -100,6 +104,9 @@ SIGNATURES = {
     'tg_upsample_bwd': (I, [P, P, I, I, I, I, I, F, P]),
     'tg_backward_warp_bwd': (I, [P, P, P, P, P, I, I, I, I, P]),
     'tg_backward_warp_bwd_acc': (I, [P, P, P, P, P, I, I, I, I, P]),
+    'tg_conv3x3_wino_resident_ct_floats': (SZ, []),
+    'tg_conv3x3_wino_resident_ct_pack': (I, [P, P, P]),
+    'tg_conv3x3_wino_resident_ct': (I, [P, I, I, I, I, P, I, P, P]),
     'tg_conv4x4s2_supported': (I, [I, I, I, I, I]),
     'tg_conv4x4s2_packed_floats': (SZ, [I, I]),
     'tg_conv4x4s2_pack': (I, [P, P, P, I, I, P]),

@@ -382,6 +382,7 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
                   resident_wanted(tg_conv3x3_prefers_wino(n, nf, nf, h, w) != 0) && (skip || c.in_nc + s2dc <= 64) && tg::conv3x3_wino_resident_ok(n, nf, h, w);
   for (int i = skip; i < 1 + 2 * c.nb && resident; ++i) resident = p->L[li + i].u != nullptr && p->L[li + i].b != nullptr;
   if (resident) chain = true;
+  bool ct_fold = false;
   if (chain) {
     if (skip)
       conv(lr_curr, c.in_nc * hw, c.in_nc, p->S2D, s2dc * hw, c.in_nc + s2dc, nf, h, w, TG_ACT_RELU,
@@ -411,6 +412,10 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     li += nchain;
     p->chain_layers = nchain;
     if (resident) {
+      // SRNet's first up-sampling layer rides on the same launch (tg_conv3x3_wino_res.hip: transposed-conv tail) when
+      // the plan holds its weights in that form (4x only: at 2x the single transposed conv is the Z-mode launch)
+      ct_fold = s == 4 && p->L[li].u != nullptr && p->L[li].b != nullptr;   // (the caller opts in by supplying the tail's pack)
+      if (ct_fold) { fl += 2.0 * nf * 9 * nf * px; by += 4.0 * px * nf * 4.0 + 4.0 * 9 * nf * nf; }
       go(K_WINO_RES, fl, by, [&] {
         if (!p->res_ready) {
           if (hipMemsetAsync(p->RESWS, 0, (size_t)tg::conv3x3_wino_resident_ws_bytes(h, w), (hipStream_t)st) != hipSuccess)
@@ -418,8 +423,9 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
           p->res_ready = true;
         }
         if (++p->epoch == 0) p->epoch = 1;
+        tg_wres_convt ct{p->L[li].u, p->L[li].b, p->U1, TG_ACT_RELU};
         return tg::conv3x3_wino_resident_launch(cl, nchain, nf, h, w, p->RESWS, p->chain_err, p->epoch << 5,
-                                                p->chain_poll_limit, st);
+                                                p->chain_poll_limit, st, ct_fold ? &ct : nullptr);
       });
     } else
     go(K_WINO_CHAIN, fl, by, [&] {
@@ -457,10 +463,11 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     const float* zin = A;
     if (s == 4) {
       float* ai = A;
-      go(K_CONVT, 2.0 * nf * 9 * nf * n * hw, 4.0 * n * hw * nf * 5.0, [&] {
-        return tg_convt3x3s2_fwd(ai, nf * hw, lw_up1.w, lw_up1.b, p->U1, nf * 4 * hw, n, nf, nf, h, w,
-                                 TG_ACT_RELU, st);
-      });
+      if (!ct_fold)
+        go(K_CONVT, 2.0 * nf * 9 * nf * n * hw, 4.0 * n * hw * nf * 5.0, [&] {
+          return tg_convt3x3s2_fwd(ai, nf * hw, lw_up1.w, lw_up1.b, p->U1, nf * 4 * hw, n, nf, nf, h, w,
+                                   TG_ACT_RELU, st);
+        });
       zin = p->U1;
     }
     const tg_layer_weights lw_last = s == 4 ? lw_up2 : lw_up1;
@@ -475,7 +482,7 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
     });
     return rc;
   }
-  {
+  if (!ct_fold) {
     float* ai = A;
     go(K_CONVT, 2.0 * nf * 9 * nf * n * hw, 4.0 * n * hw * nf * 5.0, [&] {
       return tg_convt3x3s2_fwd(ai, nf * hw, lw_up1.w, lw_up1.b, p->U1, nf * 4 * hw, n, nf, nf, h, w,

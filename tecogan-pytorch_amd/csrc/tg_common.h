@@ -81,7 +81,8 @@ int conv3x3_wino_chain_launch(const tg_wino_layer* layers, int n_layers, int n, 
 bool conv3x3_wino_resident_ok(int n, int cout, int h, int w);
 int64_t conv3x3_wino_resident_ws_bytes(int h, int w);
 int conv3x3_wino_resident_launch(const tg_wino_layer* layers, int n_layers, int cout, int h, int w, void* ws,
-                                 int32_t* err, unsigned base, int poll_limit, tg_stream_t stream);
+                                 int32_t* err, unsigned base, int poll_limit, tg_stream_t stream,
+                                 const tg_wres_convt* ct = nullptr);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

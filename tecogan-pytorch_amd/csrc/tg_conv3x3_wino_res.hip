@@ -105,6 +105,12 @@ struct WResArgs {
   unsigned base;       // tag of layer l of this launch = base + l + 1 (strictly increasing over launches)
   int poll_limit;
   int nlayer, h, w, nbx, nby, c1, cin0;
+  // optional tail: ConvTranspose2d(64, 64, 3, 2, 1, 1) + act of the last layer's output (SRNet's first up-sampling
+  // layer, tecogan_nets.py:119-126) on the resident blocks; ct_u == null: the last layer's output goes to y
+  const float* ct_u;   // tg_conv3x3_wino_resident_ct_pack form
+  const float* ct_bias;
+  float* ct_y;         // (64, 2h, 2w)
+  int ct_act;
   int abl;             // lab builds only: 1 no flag wait / ring loads, 2 no MFMA, 4 no weight loads, 8 no ring stores, 16 no window reads, 32 no hand-over at all
 };
 
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
 #endif
   }
 
+  const bool fold = a.ct_u != nullptr;        // launch-uniform
   for (int L = 0; L < a.nlayer; ++L) {
     const WResLayer& lay = a.L[L];
     const float* src = s_act + (L & 1) * (WR_NC * WR_CS);
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
 #endif
     RSTAMP(1);
     // ---- inverse transform A^T m A, bias / activation / residual -----------------------------
-    const bool last = L + 1 == a.nlayer;
+    const bool last = L + 1 == a.nlayer && !fold;   // with the transposed-conv tail the last layer hands over like any other
     const float slope = act_slope(lay.act);
     float bz[4];
 #pragma unroll
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
     };
     if (lay.res) epilogue(std::true_type{}); else epilogue(std::false_type{});
     // the next layer's first weights travel under the hand-over
-    if (!last) {
+    if (L + 1 < a.nlayer) {
       const f32x4* un = reinterpret_cast<const f32x4*>(a.L[L + 1].u) + ulane;
       load_u(un, 0, a.L[L + 1].nks, u0);
       load_u(un, 1, a.L[L + 1].nks, u1);
@@ -474,6 +481,116 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
     }
     RSTAMP(7);
   }
+  if (!fold) return;
+
+  // ---- tail: ConvTranspose2d(64, 64, 3, stride 2, pad 1, output_padding 1) + act on the resident block ------------
+  //   out[2y + py][2x + px] = bias + sum_ic sum_taps in[y + dy][x + dx] W[ic][oc][ky][kx],
+  //   py = 0: (dy 0, ky 1);  py = 1: (dy 0, ky 2), (dy 1, ky 0)   (the same along x; 9 taps over the 4 phases).
+  // The wave keeps its (tile group, 16-channel block): MFMA column n = Winograd tile n of the group, four column
+  // blocks = the tile's 2 x 2 pixels (a, b), so a lane's 3 x 3 window at its tile origin holds every operand:
+  // 9 LDS reads and 36 MFMAs per K step, 16 accumulators (4 pixels x 4 phases).  Weights straight from L2 (two
+  // K steps in flight), output as 16-byte stores of 4 consecutive columns.  Direct fp32 products: as a launch of
+  // its own this layer ran at 0.51 of peak on 670 workgroups and cost a kernel boundary in the frame's serial chain.
+  __syncthreads();                            // the ring of the last layer is complete for EVERY wave
+  {
+    // (the tail's geometry is derived from an opaque copy of the lane id: computed ahead of the layer loop it cost the
+    // loop a register and a scratch slot)
+    int l2 = l;
+    asm volatile("" : "+v"(l2));
+    const int T2 = WR_TILE[16 * g + (l2 & 15)];
+    const int ty = T2 / WR_TW, tx = T2 - ty * WR_TW, kk = l2 >> 4;
+    const int oc_base = 16 * q + 4 * kk;
+    const int gy0 = Y0 + 2 * ty, gx0 = X0 + 2 * tx;
+    const bool live = gy0 < a.h && gx0 < a.w;
+    const float* src = s_act + (a.nlayer & 1) * (WR_NC * WR_CS);
+    const int cb = kk * WR_CS + (2 * ty + 1) * WR_RS + (2 * tx + 1);
+    f32x4 ca[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) ca[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4* cu = reinterpret_cast<const f32x4*>(a.ct_u) + (size_t)(q * 3) * 64 + l2;
+    constexpr size_t CSTEP = (size_t)4 * 3 * 64;
+    constexpr int CT_NKS = WR_NC / 4;
+    auto load_w = [&](int ks, f32x4 (&w)[3]) {
+      if (ks >= CT_NKS) return;
+      const f32x4* pw = cu + (size_t)ks * CSTEP;
+      w[0] = pw[0]; w[1] = pw[64]; w[2] = pw[128];
+    };
+    auto cstep = [&](int ks, const f32x4 (&w)[3]) {
+      const float* sp = src + cb + ks * (4 * WR_CS);
+      float d[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) d[i][j] = sp[i * WR_RS + j];
+#pragma unroll
+      for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+        for (int pb2 = 0; pb2 < 2; ++pb2)
+#pragma unroll
+          for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+              for (int ey = 0; ey <= py; ++ey)
+#pragma unroll
+                for (int ex = 0; ex <= px; ++ex) {
+                  // phase coordinate 0: the single tap (d 0, k 1); coordinate 1: (d 0, k 2), (d 1, k 0)
+                  const int dy = py ? ey : 0, ky = py ? (ey ? 0 : 2) : 1;
+                  const int dx = px ? ex : 0, kx = px ? (ex ? 0 : 2) : 1;
+                  const int tap = ky * 3 + kx, ai = (pa * 2 + pb2) * 4 + py * 2 + px;
+                  ca[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap >> 2][tap & 3], d[pa + dy][pb2 + dx], ca[ai], 0, 0, 0);
+                }
+    };
+    f32x4 w0[3], w1[3];
+    load_w(0, w0);
+    load_w(1, w1);
+    for (int ks = 0; ks < CT_NKS; ks += 2) {
+      cstep(ks, w0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(ks + 2, w0);
+      cstep(ks + 1, w1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(ks + 3, w1);
+    }
+    if (live) {
+      const float cslope = act_slope(a.ct_act);
+      const size_t ohw = (size_t)4 * hw;
+      const int ow = 2 * a.w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float bz = a.ct_bias[oc_base + r];
+        float* yo = a.ct_y + (size_t)(oc_base + r) * ohw + (size_t)(2 * gy0) * ow + 2 * gx0;
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+          for (int py = 0; py < 2; ++py) {
+            float o4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {     // columns 4 tx' + e = (pixel b = e >> 1, phase px = e & 1)
+              float v = ca[(pa * 2 + (e >> 1)) * 4 + py * 2 + (e & 1)][r] + bz;
+              o4[e] = __builtin_fmaf(cslope, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f));
+            }
+            *reinterpret_cast<float4*>(yo + (size_t)(2 * pa + py) * ow) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+          }
+      }
+    }
+  }
+}
+
+// SRNet's first ConvTranspose2d weights (cin 64, cout 64, 3, 3) -> the tail's A operands:
+// [K step 16][channel block 4][j 3][lane 64][e 4]: element p = 4 j + e < 9 of lane (oc = 16 q + (lane & 15),
+// ic = 4 ks + (lane >> 4)) is W[ic][oc][p / 3][p % 3]; p >= 9 is padding.
+__global__ void wres_ct_pack_kernel(const float* __restrict__ w, float* __restrict__ out) {
+  const int total = 16 * 4 * 3 * 64 * 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int e = i & 3, lane = (i >> 2) & 63;
+    int t = i >> 8;
+    const int j = t % 3; t /= 3;
+    const int qq = t & 3, ks = t >> 2;
+    const int p = 4 * j + e;
+    const int oc = 16 * qq + (lane & 15), ic = 4 * ks + (lane >> 4);
+    out[i] = p < 9 ? w[((size_t)ic * WR_NC + oc) * 9 + p] : 0.f;
+  }
 }
 
 static int wres_capacity() {
@@ -510,7 +627,8 @@ int64_t conv3x3_wino_resident_ws_bytes(int h, int w) {
 }
 
 int conv3x3_wino_resident_launch(const tg_wino_layer* layers, int n_layers, int cout, int h, int w, void* ws,
-                                 int32_t* err, unsigned base, int poll_limit, tg_stream_t stream) {
+                                 int32_t* err, unsigned base, int poll_limit, tg_stream_t stream,
+                                 const tg_wres_convt* ct) {
   TG_REQUIRE(layers && ws && err, TG_E_ARG, "conv3x3_wino_resident: null pointer");
   TG_REQUIRE(n_layers >= 1 && n_layers <= WR_MAXL, TG_E_ARG, "conv3x3_wino_resident: %d layers (1..%d)", n_layers, WR_MAXL);
   TG_REQUIRE(conv3x3_wino_resident_ok(1, cout, h, w), TG_E_SHAPE,
@@ -542,6 +660,13 @@ int conv3x3_wino_resident_launch(const tg_wino_layer* layers, int n_layers, int 
   a.y = layers[n_layers - 1].y;
   a.xbuf = static_cast<float*>(ws);
   a.err = err; a.base = base; a.poll_limit = poll_limit;
+  if (ct) {
+    TG_REQUIRE(ct->u_packed && ct->bias && ct->y, TG_E_ARG, "conv3x3_wino_resident: transposed-conv tail: null pointer");
+    TG_REQUIRE(ct->act == TG_ACT_NONE || ct->act == TG_ACT_RELU || ct->act == TG_ACT_LRELU02, TG_E_ARG,
+               "conv3x3_wino_resident: transposed-conv tail: act=%d", ct->act);
+    TG_REQUIRE(n_layers + 1 < 32 && ((uintptr_t)ct->y % 16) == 0, TG_E_ARG, "conv3x3_wino_resident: transposed-conv tail: layers / alignment");
+    a.ct_u = ct->u_packed; a.ct_bias = ct->bias; a.ct_y = ct->y; a.ct_act = ct->act;
+  }
 #if TG_WRES_LAB
   { static const int abl = [] { const char* e = getenv("TG_WRES_ABL"); return e ? atoi(e) : 0; }(); a.abl = abl; }
 #endif
@@ -571,9 +696,22 @@ extern "C" int64_t tg_conv3x3_wino_resident_ws_bytes(int h, int w) {
 
 extern "C" int tg_conv3x3_wino_resident(const tg_wino_layer* layers, int n_layers, int cout, int h, int w,
                                         void* workspace, int epoch, tg_stream_t stream) {
+  return tg_conv3x3_wino_resident_ct(layers, n_layers, cout, h, w, workspace, epoch, nullptr, stream);
+}
+
+extern "C" int tg_conv3x3_wino_resident_ct(const tg_wino_layer* layers, int n_layers, int cout, int h, int w,
+                                           void* workspace, int epoch, const tg_wres_convt* convt, tg_stream_t stream) {
   TG_REQUIRE(workspace && epoch > 0, TG_E_ARG, "conv3x3_wino_resident: bad argument (epoch counts from 1)");
   const int64_t bytes = conv3x3_wino_resident_ws_bytes(h, w);
   int32_t* err = reinterpret_cast<int32_t*>(static_cast<char*>(workspace) + bytes - 256);
   return conv3x3_wino_resident_launch(layers, n_layers, cout, h, w, workspace, err, (unsigned)epoch * 32u,
-                                      TG_CHAIN_POLL_LIMIT_DEFAULT, stream);
+                                      TG_CHAIN_POLL_LIMIT_DEFAULT, stream, convt);
+}
+
+extern "C" size_t tg_conv3x3_wino_resident_ct_floats(void) { return (size_t)16 * 4 * 3 * 64 * 4; }
+
+extern "C" int tg_conv3x3_wino_resident_ct_pack(const float* w_iohw, float* out, tg_stream_t stream) {
+  TG_REQUIRE(w_iohw && out, TG_E_ARG, "conv3x3_wino_resident_ct_pack: null pointer");
+  hipLaunchKernelGGL(wres_ct_pack_kernel, dim3(96), dim3(256), 0, (hipStream_t)stream, w_iohw, out);
+  return check_launch("conv3x3_wino_resident_ct_pack");
 }

@@ -686,7 +686,7 @@ extern "C" int tg_conv4x4s2_supported(int n, int ci, int co, int h, int w) {
 // Split factor of the small-map forms (1 for the large ones) and the floats of partial sums a call needs
 // (0: none): the caller passes a workspace of that size.
 static int c4_pick_ksplit(int base_wgs, int nchunk) {
-  if (const char* e = getenv("TG_C4_KSPLIT")) return atoi(e) > 0 && nchunk % atoi(e) == 0 ? atoi(e) : 1;   // lab
+  if (const int e = TG_LAB_ENV("TG_C4_KSPLIT", 0)) return nchunk % e == 0 ? e : 1;   // lab builds only
   int ks = 1;
   while (base_wgs * ks < 320 && ks * 2 <= nchunk / 2 && nchunk % (ks * 2) == 0) ks *= 2;
   return ks;

@@ -247,6 +247,7 @@ class _StepPlan:
         self.workspace = torch.empty(nfl, dtype=torch.float32, device=device)
         self.keep = []          # packed tensors must outlive the plan
         layers = net.fnet.layers() + net.srnet.layers()
+        first_up = net.srnet.conv_up['0'] if hasattr(net.srnet, 'conv_up') and '0' in net.srnet.conv_up else None
         arr = (L.LayerWeights * len(layers))()
         for i, m in enumerate(layers):
             if m.cout <= 4:      # direct small-cout kernel takes plain OIHW
@@ -255,6 +256,11 @@ class _StepPlan:
                 wt, _ = m.packed()
             b = m.bias.detach().contiguous()
             u = m.packed_wino() if m.cout > 4 else None
+            if m is first_up and not fnet_only and net.scale == 4 and net.nf == 64 and n == 1 and \
+                    os.environ.get('TG_WINO_RES_CT', '1') != '0':
+                # SRNet's first up-sampling layer as the tail of the resident body launch (tg_conv3x3_wino_res.hip);
+                # the plan uses it when the frame runs that launch.  TG_WINO_RES_CT=0: always a launch of its own.
+                u = ops.pack_wres_convt(m.weight.detach().contiguous())
             self.keep += [wt, b, u]
             arr[i].w, arr[i].b = wt.data_ptr(), b.data_ptr()
             arr[i].u = u.data_ptr() if u is not None else None

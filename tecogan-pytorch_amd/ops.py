@@ -1206,6 +1206,18 @@ class WinoChain:
         return int(self.flags[-16].item())
 
 
+def pack_wres_convt(w):
+    """nn.ConvTranspose2d(64, 64, 3, 2, 1, 1).weight (cin, cout, 3, 3) -> the A operands of the resident launch's
+    transposed-conv tail (tg_conv3x3_wino_resident_ct_pack)."""
+    _chk(w, 'w')
+    if tuple(w.shape) != (64, 64, 3, 3):
+        raise L.TecoganHipError(f'pack_wres_convt: weight {tuple(w.shape)}, expected (64, 64, 3, 3)')
+    lib = L.lib()
+    out = torch.empty(lib.tg_conv3x3_wino_resident_ct_floats(), dtype=torch.float32, device=w.device)
+    L.check(lib.tg_conv3x3_wino_resident_ct_pack(w.data_ptr(), out.data_ptr(), _stream()), 'tg_conv3x3_wino_resident_ct_pack')
+    return out
+
+
 class WinoResident(WinoChain):
     """tg_conv3x3_wino_resident: the same dependent layers of ONE frame on persistent, LDS-resident
     workgroups (tg_conv3x3_wino_res.hip).  Only layers[0]['x'] / ['x2'] are read and only
@@ -1220,11 +1232,20 @@ class WinoResident(WinoChain):
     def supported(cout, h, w, n=1):
         return bool(L.lib().tg_conv3x3_wino_resident_supported(n, cout, h, w))
 
-    def run(self):
+    def run(self, convt=None):
+        """convt: None, or dict(u=pack_wres_convt(weight), bias=, y=(64, 2h, 2w) output, act=): SRNet's first
+        ConvTranspose2d + act as the launch's tail (tg_conv3x3_wino_resident_ct); layers[-1]['y'] is then not written."""
         self.epoch += 1
-        L.check(L.lib().tg_conv3x3_wino_resident(self.arr, len(self.keep), self.cout, self.h, self.w,
-                                                 self.ws.data_ptr(), self.epoch, _stream()),
-                'tg_conv3x3_wino_resident')
+        if convt is None:
+            L.check(L.lib().tg_conv3x3_wino_resident(self.arr, len(self.keep), self.cout, self.h, self.w,
+                                                     self.ws.data_ptr(), self.epoch, _stream()),
+                    'tg_conv3x3_wino_resident')
+            return
+        import ctypes as C
+        ct = L.WresConvT(convt['u'].data_ptr(), convt['bias'].data_ptr(), convt['y'].data_ptr(), convt.get('act', ACT_RELU))
+        L.check(L.lib().tg_conv3x3_wino_resident_ct(self.arr, len(self.keep), self.cout, self.h, self.w,
+                                                    self.ws.data_ptr(), self.epoch, C.byref(ct), _stream()),
+                'tg_conv3x3_wino_resident_ct')
 
     def bailouts(self):
         return int(self.ws[-64].item())

@@ -313,6 +313,53 @@ def test_winograd_resident_launch_equals_separate_launches(ops, h, w, nb, first)
         assert torch.equal(A1, A2), (it, (A1 - A2).abs().max().item(), int((A1 != A2).sum()))
 
 
+@pytest.mark.parametrize('h,w,nb', [(134, 320, 2), (26, 70, 1), (8, 24, 1), (30, 50, 2), (2, 2, 1)])
+def test_winograd_resident_launch_with_transposed_conv_tail(ops, h, w, nb):
+    """tg_conv3x3_wino_resident_ct: SRNet's first ConvTranspose2d(64, 64, 3, 2, 1, 1) + ReLU (tecogan_nets.py:119-126)
+    as the tail of the resident launch, against the per-layer launches followed by the stand-alone transposed-conv
+    kernel and against torch's CPU conv_transpose2d (fp64): 3e-6 relative to the output scale (fp32 products of
+    K = 576, another summation order), full / partial / single blocks, every output pixel written."""
+    if not ops.WinoResident.supported(64, h, w):
+        pytest.skip('frame does not fit one block per CU on this device')
+    g = torch.Generator().manual_seed(29)
+    lr = dev(torch.rand(1, 3, h, w, generator=g))
+    s2d = dev(torch.rand(1, 48, h, w, generator=g))
+    ws = [dev(torch.randn(64, 51, 3, 3, generator=g) * 0.04)] + \
+         [dev(torch.randn(64, 64, 3, 3, generator=g) * 0.03) for _ in range(2 * nb)]
+    bs = [dev(torch.randn(64, generator=g) * 0.1) for _ in range(2 * nb + 1)]
+    us = [ops.pack_conv3x3_wino(x) for x in ws]
+    wt = torch.randn(64, 64, 3, 3, generator=g) * 0.05          # (cin, cout, 3, 3)
+    bt = torch.randn(64, generator=g) * 0.1
+
+    def make(A, B):
+        layers = [dict(x=lr, x2=s2d, u=us[0], bias=bs[0], cin=51, act=1, y=A)]
+        for b in range(nb):
+            layers.append(dict(x=A, u=us[1 + 2 * b], bias=bs[1 + 2 * b], cin=64, act=1, y=B))
+            layers.append(dict(x=B, u=us[2 + 2 * b], bias=bs[2 + 2 * b], cin=64, act=0, res=A, y=A))
+        return layers
+    A1, B1, A2, B2 = (torch.empty(1, 64, h, w, device='cuda') for _ in range(4))
+    seq, res = make(A1, B1), ops.WinoResident(make(A2, B2), 64, h, w)
+    ct = dict(u=ops.pack_wres_convt(dev(wt)), bias=dev(bt), y=torch.empty(1, 64, 2 * h, 2 * w, device='cuda'), act=1)
+    pk, _, _, _ = ops.pack_conv3x3(dev(wt), transposed=True)
+    for it in range(3):
+        lr.uniform_(-1, 1); s2d.uniform_(-1, 1)
+        ct['y'].fill_(float('nan'))
+        for d in seq:
+            ops.conv3x3_wino(d['x'], d['u'], d['bias'], d['cin'], 64, d['act'], x2=d.get('x2'), res=d.get('res'), out=d['y'])
+        ref_gpu = ops.convt3x3s2(A1, pk, dev(bt), 64, 1)
+        res.run(convt=ct)
+        torch.cuda.synchronize()
+        assert res.bailouts() == 0
+        ref = torch.relu(torch.nn.functional.conv_transpose2d(A1.cpu().double(), wt.double(), bt.double(), 2, 1, 1))
+        scale = ref.abs().max().item()
+        assert not torch.isnan(ct['y']).any()
+        assert (ct['y'].cpu().double() - ref).abs().max().item() <= 3e-6 * scale, it
+        assert (ct['y'] - ref_gpu).abs().max().item() <= 3e-6 * scale, it
+    res.run()                                     # and the launch without the tail still writes the body's output
+    torch.cuda.synchronize()
+    assert torch.equal(A1, A2)
+
+
 def test_winograd_resident_rejects_foreign_buffer_patterns(ops):
     """The resident launch keeps the intermediate tensors in LDS, so it insists on the chain pattern of
     the reference's SRNet (tecogan_nets.py:85-100): anything else is refused, not silently mis-computed."""
@@ -444,15 +491,21 @@ def test_plan_with_resident_srnet_launch(tmp_path):
         "torch.save(dict(y0=y0.cpu(), y1=y1.cpu(), f=f.cpu(), resident=nl.value, state=plan.chain_state()), sys.argv[1])\n"
         % (ROOT_DIR, GOLDEN_DIR))
     outs = []
-    for flag in ('0', '1'):
-        env = dict(os.environ, TG_WINO_RES=flag, TG_CONV_WINO='1')
-        out = str(tmp_path / ('y%s.pt' % flag))
+    for flag, tail in (('0', '0'), ('1', '0'), ('1', '1')):
+        env = dict(os.environ, TG_WINO_RES=flag, TG_CONV_WINO='1', TG_WINO_RES_CT=tail)
+        out = str(tmp_path / ('y%s%s.pt' % (flag, tail)))
         subprocess.run([sys.executable, '-c', script, out], check=True, env=env, timeout=600)
         outs.append(torch.load(out))
-    assert outs[0]['resident'] == 0 and outs[1]['resident'] == 1, (outs[0]['resident'], outs[1]['resident'])
-    assert outs[1]['state'] == (0, True), outs[1]['state']
+    assert outs[0]['resident'] == 0 and outs[1]['resident'] == 1 and outs[2]['resident'] == 1
+    assert outs[1]['state'] == (0, True) and outs[2]['state'] == (0, True), (outs[1]['state'], outs[2]['state'])
     for k in ('y0', 'y1', 'f'):
         assert outs[0][k].shape == outs[1][k].shape and torch.equal(outs[0][k], outs[1][k]), k
+    # the default: the first transposed conv as the launch's tail (direct fp32 products in another summation order
+    # than the stand-alone kernel): fp32 frame to 2e-5, uint8 frames to one level on <= 0.2 % of the pixels
+    assert (outs[2]['f'] - outs[0]['f']).abs().max().item() <= 2e-5
+    for k in ('y0', 'y1'):
+        d = (outs[2][k].to(torch.int16) - outs[0][k].to(torch.int16)).abs()
+        assert d.max().item() <= 1 and (d > 0).float().mean().item() <= 2e-3, (k, d.max().item())
 
 
 def test_resident_launch_fault_surfaces_and_falls_back(tmp_path):
@@ -490,7 +543,9 @@ def test_resident_launch_fault_surfaces_and_falls_back(tmp_path):
         "y = net.infer_sequence(x[:1], dev, return_device_tensor=True); torch.cuda.synchronize()\n"
         "assert raises(lambda: net.infer_sequence(x[:1], dev, return_device_tensor=True)), 'next call silent'\n"
         "print('FAILSAFE-OK')\n" % (ROOT_DIR, GOLDEN_DIR))
-    env = dict(os.environ, TG_WINO_RES='1', TG_CONV_WINO='1')
+    # (TG_WINO_RES_CT=0: the healthy reference run keeps the first transposed conv a launch of its own, as the
+    # fallen-back plan does -- the comparison is about the fallback machinery, bit for bit)
+    env = dict(os.environ, TG_WINO_RES='1', TG_CONV_WINO='1', TG_WINO_RES_CT='0')
     r = subprocess.run([sys.executable, '-c', script], env=env, timeout=600, capture_output=True, text=True)
     assert r.returncode == 0 and 'FAILSAFE-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
