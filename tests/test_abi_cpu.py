@@ -152,3 +152,29 @@ def test_winograd_rule_and_packed_size_are_host_functions():
     assert lib.tg_conv3x3_wino_packed_floats(51, 64) == 16 * 4 * 4 * 64 * 4
     assert lib.tg_conv3x3_wino_packed_floats(27, 128) == 8 * 8 * 4 * 64 * 4
     assert lib.tg_conv3x3_wino_packed_floats(0, 64) == -1
+
+
+def test_round4_host_side_shape_rules():
+    """Host-side rules of the round-4 entry points (no launch): which Conv2d(4, 2, 1) shapes the direct kernels take,
+    how much workspace their small-map forms need (the input channels split over workgroups + a summing launch),
+    pack sizes, and null-pointer / shape refusals as error codes."""
+    lib = L.lib()
+    sup = lib.tg_conv4x4s2_supported
+    assert sup(24, 64, 64, 128, 128) and sup(12, 64, 128, 64, 64) and sup(1, 128, 256, 2, 192)
+    assert sup(24, 64, 128, 32, 32) and sup(24, 128, 256, 16, 16)          # the small maps of the deeper blocks
+    assert not sup(24, 27, 64, 128, 128) and not sup(24, 64, 96, 128, 128)  # 64-channel blocks both ways
+    assert not sup(24, 64, 64, 6, 32) and not sup(24, 64, 64, 8, 16) and not sup(24, 64, 64, 16, 48)
+    assert not sup(0, 64, 64, 128, 128) and not sup(1, 64, 64, 127, 128)
+    wsf = lib.tg_conv4x4s2_workspace_floats
+    assert wsf(24, 64, 64, 128, 128, 0) == 0 and wsf(24, 64, 64, 128, 128, 1) == 0      # large maps: one launch
+    out_f, dx_f = 24 * 256 * 8 * 8, 24 * 128 * 16 * 16
+    kf, kd = wsf(24, 128, 256, 16, 16, 0), wsf(24, 128, 256, 16, 16, 1)
+    assert kf % out_f == 0 and 2 <= kf // out_f <= 16 and kd % dx_f == 0 and 2 <= kd // dx_f <= 16
+    assert wsf(24, 27, 64, 128, 128, 0) == 0
+    assert lib.tg_conv4x4s2_packed_floats(64, 128) == 64 * 128 * 16
+    assert lib.tg_conv4x4s2_fwd(None, None, None, None, 24, 64, 64, 128, 128, None) == -2
+    assert lib.tg_conv4x4s2_dgrad(None, None, None, 0, None, None, 24, 64, 64, 128, 128, None) == -2
+    assert lib.tg_conv4x4s2_pack(None, None, None, 64, 64, None) == -2
+    assert lib.tg_conv3x3_wino_resident_ct_floats() == 16 * 4 * 3 * 64 * 4
+    assert lib.tg_conv3x3_wino_resident_ct_pack(None, None, None) == -2
+    assert lib.tg_backward_warp_s2d_fwd(None, None, None, 1, 3, 8, 8, 4, None) == -2
