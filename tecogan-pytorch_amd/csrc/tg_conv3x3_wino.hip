@@ -131,18 +131,32 @@ template <bool COH> __device__ __forceinline__ void st1(float* p, float v) {
 // workgroups of consecutive layers run in the same launch, possibly behind different L2s.
 constexpr int AUX_SC1 = 16;       // cache-policy bit of the buffer instructions on gfx940+
 
-template <bool COH>
+// TR: tile rows of the workgroup's 16 Winograd tiles (TR x 16/TR tiles = 2 TR x 32/TR pixels).  1: one tile row of 32
+// pixels (the form everything was tuned on); 2 / 4: 4 x 16 / 8 x 8 pixels for maps narrower than a 32-pixel tile
+// (FNet's 17x40 and 34x80 maps at inference, its 16x16 maps on the training frames: 17-50 % of every 32-pixel-wide
+// tile lay outside the map).  Every output's arithmetic and its order are the same in all three: bit-identical.
+template <int TR> struct WGeo3 {
+  static constexpr int TC = 16 / TR;                 // tile columns
+  static constexpr int PR = 2 * TR + 2, PC = 2 * TC + 2;   // raw patch rows / columns per input channel
+  static constexpr int PE = PR * PC;
+  static constexpr int RS = TR == 1 ? W_RS : (TR == 2 ? 24 : 12);   // LDS row stride: the float2 reads of 32 lanes
+                                                                     // (2 channels x 16 tiles) hit 64 distinct banks
+  static_assert(PR * RS <= W_ICSTR, "patch of one channel fits the channel stride");
+};
+
+template <bool COH, int TR = 1>
 __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int ocg, int n) {
+  using G = WGeo3<TR>;
   __shared__ __attribute__((aligned(16))) float s_raw[W_ICS * W_ICSTR];   // 10 KB
   __shared__ __attribute__((aligned(16))) float s_v[2 * W_ICS * 16 * W_VS];   // 2 x 20 KB: [buffer][ic][tile][16 positions + pad]
 
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int x0 = tx * 32, y0 = ty * 2;
+  const int x0 = tx * (2 * G::TC), y0 = ty * (2 * TR);
   const int hw = a.h * a.w;
 
   // ---- raw patch staging: element e = t + 256 k = (ic, row, col) of the 16 x 4 x 34 patch ------
-  constexpr int RAW_ELEMS = W_ICS * 4 * 34;
+  constexpr int RAW_ELEMS = W_ICS * G::PE;
   constexpr int RAW_PER_T = (RAW_ELEMS + 255) / 256;   // 9
   // byte offset of the element inside a channel plane, or OOB: the buffer bounds check then
   // returns 0 for the zero padding, for channels past cin (K padded to a multiple of 16) and
@@ -152,7 +166,7 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
 #pragma unroll
   for (int k = 0; k < RAW_PER_T; ++k) {
     const int e = t + 256 * k;
-    const int ic = e / 136, rem = e - ic * 136, r = rem / 34, c = rem - r * 34;
+    const int ic = e / G::PE, rem = e - ic * G::PE, r = rem / G::PC, c = rem - r * G::PC;
     const int gy = y0 - 1 + r, gx = x0 - 1 + c;
     roff[k] = (e < RAW_ELEMS && gy >= 0 && gy < a.h && gx >= 0 && gx < a.w)
                   ? (unsigned)(ic * hw + gy * a.w + gx) * 4u : OOB;
@@ -179,8 +193,8 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
 #pragma unroll
     for (int k = 0; k < RAW_PER_T; ++k) {
       const int e = t + 256 * k;
-      const int ic = e / 136, rem = e - ic * 136, r = rem / 34, c = rem - r * 34;
-      if (e < RAW_ELEMS) s_raw[ic * W_ICSTR + r * W_RS + c] = reg[k];
+      const int ic = e / G::PE, rem = e - ic * G::PE, r = rem / G::PC, c = rem - r * G::PC;
+      if (e < RAW_ELEMS) s_raw[ic * W_ICSTR + r * G::RS + c] = reg[k];
     }
   };
 
@@ -203,7 +217,7 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
 
   // transform assignment: thread -> (ic = t >> 4, tile = t & 15)
   constexpr int VBUF4 = W_ICS * 16 * W_VS / 4;          // one V buffer in 16-byte units
-  const float* traw = s_raw + (t >> 4) * W_ICSTR + 2 * (t & 15);
+  const float* traw = s_raw + (t >> 4) * W_ICSTR + 2 * ((t & 15) / G::TC) * G::RS + 2 * ((t & 15) % G::TC);
   f32x4* tv = reinterpret_cast<f32x4*>(s_v + t * W_VS);                                        // 4 x 16 bytes per buffer
   const f32x4* bv = reinterpret_cast<const f32x4*>(s_v + ((l >> 4) * 16 + (l & 15)) * W_VS);   // + ks * 4*16*W_VS floats
 
@@ -236,8 +250,8 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
     float d[3][4];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const float2 p0 = *reinterpret_cast<const float2*>(traw + (r + hp) * W_RS);
-      const float2 p1 = *reinterpret_cast<const float2*>(traw + (r + hp) * W_RS + 2);
+      const float2 p0 = *reinterpret_cast<const float2*>(traw + (r + hp) * G::RS);
+      const float2 p1 = *reinterpret_cast<const float2*>(traw + (r + hp) * G::RS + 2);
       d[r][0] = p0.x; d[r][1] = p0.y; d[r][2] = p1.x; d[r][3] = p1.y;
     }
     float qa[4], qb[4];
@@ -251,7 +265,8 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
   };
 
   // epilogue geometry (needed early: the residual is fetched under the last stage's MFMAs)
-  const int ox = x0 + 2 * (l & 15);
+  const int ox = x0 + 2 * ((l & 15) % G::TC);
+  const int oy0 = y0 + 2 * ((l & 15) / G::TC);      // first output row of the lane's tile
   const int oc_base = ocg * 64 + wv * 16 + 4 * (l >> 4);
   const float* rn = a.res ? a.res + (size_t)n * a.res_ns : nullptr;
   const bool res_pre = rn && a.vec_ok;
@@ -299,8 +314,8 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         rpre[r][i] = make_float2(0.f, 0.f);
-        if (res_pre && oc_base + r < a.cout && ox < a.w && y0 + i < a.h)
-          rpre[r][i] = ld2<COH>(rn + (size_t)(oc_base + r) * hw + (size_t)(y0 + i) * a.w + ox);
+        if (res_pre && oc_base + r < a.cout && ox < a.w && oy0 + i < a.h)
+          rpre[r][i] = ld2<COH>(rn + (size_t)(oc_base + r) * hw + (size_t)(oy0 + i) * a.w + ox);
       }
     kstep(4 * last + 3, u1, cur, nothing);
   }
@@ -322,7 +337,7 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
     const float bz = a.bias ? a.bias[oc] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int oy = y0 + i;
+      const int oy = oy0 + i;
       if (oy >= a.h) continue;
       float v0 = ((sr[i][0] + sr[i][1]) + sr[i][2]) + bz;
       float v1 = ((sr[i][1] - sr[i][2]) - sr[i][3]) + bz;
@@ -347,6 +362,7 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
   }
 }
 
+template <int TR>
 __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   if (WABL(64)) return;                      // empty launch
   int b = blockIdx.x;
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wino_kernel(WinoArgs a) {
   const int ty = __builtin_amdgcn_readfirstlane(b % a.tiles_y); b /= a.tiles_y;
   const int ocg = __builtin_amdgcn_readfirstlane(b % a.nocg);
   const int n = __builtin_amdgcn_readfirstlane(b / a.nocg);
-  wino_tile<false>(a, tx, ty, ocg, n);
+  wino_tile<false, TR>(a, tx, ty, ocg, n);
 }
 
 // ---- several dependent layers in ONE launch ----------------------------------------------------
@@ -513,7 +529,19 @@ int conv3x3_wino_launch(const float* x, int64_t x_ns, int c1, const float* x2, i
   a.x = x; a.x2 = x2; a.u = u; a.bias = bias; a.res = res; a.mask = mask; a.y = y;
   a.x_ns = x_ns; a.x2_ns = x2_ns; a.res_ns = res_ns; a.mask_ns = mask_ns; a.y_ns = y_ns;
   a.c1 = x2 ? c1 : cin; a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
-  a.tiles_x = cdiv(w, 32); a.tiles_y = cdiv(h, 2);
+  // tile arrangement of a workgroup's 16 tiles: the one that covers the map with the fewest workgroups
+  // (ties: the widest -- longest coalesced rows); lab builds: TG_WINO_TR forces one
+  int tr = 1;
+  {
+    long long best = (long long)cdiv(w, 32) * cdiv(h, 2);
+    for (int cand = 2; cand <= 4; cand *= 2) {
+      const long long c = (long long)cdiv(w, 32 / cand) * cdiv(h, 2 * cand);
+      if (c < best) { best = c; tr = cand; }
+    }
+    static const int tr_env = TG_LAB_ENV("TG_WINO_TR", 0);
+    if (tr_env == 1 || tr_env == 2 || tr_env == 4) tr = tr_env;
+  }
+  a.tiles_x = cdiv(w, 32 / tr); a.tiles_y = cdiv(h, 2 * tr);
   a.nstage = cdiv(cin, 16); a.nocg = cdiv(cout, 64); a.nocb = 4 * a.nocg;
   auto al8 = [](const void* p, int64_t ns) { return ((uintptr_t)p % 8) == 0 && ns % 2 == 0; };
   a.vec_ok = (w % 2 == 0) && ((int64_t)h * w) % 2 == 0 && al8(y, y_ns) && (!res || al8(res, res_ns)) &&
@@ -525,7 +553,9 @@ int conv3x3_wino_launch(const float* x, int64_t x_ns, int c1, const float* x2, i
   const bool xcd = xcd_env >= 0 ? xcd_env != 0 : blocks >= 512;
   a.nblocks = xcd ? (int)blocks : 0;
   const unsigned grid = xcd ? (unsigned)(8 * ((blocks + 7) / 8)) : (unsigned)blocks;
-  hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (tr == 1) hipLaunchKernelGGL(conv3x3_wino_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else if (tr == 2) hipLaunchKernelGGL(conv3x3_wino_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(conv3x3_wino_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("conv3x3_wino");
 }
 }  // namespace tg
