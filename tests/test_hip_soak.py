@@ -83,6 +83,44 @@ def test_soak_winograd_body_launches_under_memory_pressure(ops, kind, n, h, w):
     assert one.bailouts() == 0
 
 
+def test_soak_resident_launch_with_transposed_conv_tail_under_memory_pressure(ops):
+    """The production form of the headline frame (tg_conv3x3_wino_resident_ct: 21 body layers + the first
+    transposed conv as the launch's tail, one more ring exchange than the plain launch): every launch of the same
+    input must repeat its first result BIT FOR BIT while a second stream thrashes L2 / HBM, and stay within 3e-6
+    of the per-layer launches + stand-alone transposed conv."""
+    h, w, nb = 134, 320, 10
+    if not ops.WinoResident.supported(64, h, w):
+        pytest.skip('frame does not fit one block per CU on this device')
+    lr, s2d, make = _body_layers(ops, 1, h, w, nb, seed=47)
+    A1, B1, A2, B2 = (torch.empty(1, 64, h, w, device='cuda') for _ in range(4))
+    seq, one = make(A1, B1), ops.WinoResident(make(A2, B2), 64, h, w)
+    g = torch.Generator().manual_seed(48)
+    wt, bt = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+    ct = dict(u=ops.pack_wres_convt(wt), bias=bt, y=torch.empty(1, 64, 2 * h, 2 * w, device='cuda'), act=1)
+    pk = ops.pack_conv3x3(wt, transposed=True)[0]
+    th = Thrash()
+    ref = None
+    for it in range(ITERS):
+        fresh = it % 4 == 0
+        if fresh:
+            lr.uniform_(-1, 1); s2d.uniform_(-1, 1)
+            th.kick()
+            for d in seq:
+                ops.conv3x3_wino(d['x'], d['u'], d['bias'], d['cin'], 64, d['act'], x2=d.get('x2'), res=d.get('res'), out=d['y'])
+            want = ops.convt3x3s2(A1, pk, bt, 64, 1)
+        th.kick()
+        ct['y'].fill_(float('nan'))
+        one.run(convt=ct)
+        torch.cuda.current_stream().synchronize()
+        if fresh:
+            assert (ct['y'] - want).abs().max().item() <= 3e-6 * want.abs().max().item(), it
+            ref = ct['y'].clone()
+        else:
+            assert torch.equal(ct['y'], ref), (it, int((ct['y'] != ref).sum()))
+    torch.cuda.synchronize()
+    assert one.bailouts() == 0
+
+
 def test_soak_row_chain_training_frames_under_memory_pressure(ops):
     n, h, w, nb = 2, 32, 32, 10
     lr, s2d, make = _body_layers(ops, n, h, w, nb, seed=43, wino=False)
