@@ -485,11 +485,12 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
         c0 = dict(DU.COMM_COUNTS)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nupd = 0
-        for i in range(steps):
+        nupd0 = getattr(m, 'cnt_upd_D', 0.0)
+        for i in range(steps):                    # (the log is NOT read per step: like a run that prints every 100 iterations)
             m.prepare_training_data(data[i % 2]); m.train()
-            nupd += 1 if m.log_dict.get('l_gan_D', 0) != 0 else 0
+        m.sync_log()                              # the last iteration's scalars and fault check
         torch.cuda.synchronize()
+        nupd = int(getattr(m, 'cnt_upd_D', 0.0) - nupd0)
         dt = (time.perf_counter() - t0) / steps
         m.comm_per_step = {k: (DU.COMM_COUNTS[k] - c0[k]) / steps for k in c0}
         if dist_on:

@@ -19,11 +19,12 @@ class BaseModel:
         self.blur_kernel = None
         self.dist = opt['dist']
         self.is_train = opt['is_train']
+        self._log_dict, self._pending_log, self._log_queue, self._log_pinned = OrderedDict(), None, [], []
+        self.log_decay = 0.99
         if self.is_train:
             self.lr_data, self.gt_data = None, None
             self.ckpt_dir = opt['train'].get('ckpt_dir')
             self.log_decay = opt['logger'].get('decay', 0.99)
-            self.log_dict = OrderedDict()
             self.running_log_dict = OrderedDict()
 
     # -- data ---------------------------------------------------------------
@@ -106,6 +107,76 @@ class BaseModel:
             d['lr_D'] = self.optim_D.param_groups[0]['lr']
         return d
 
+    # -- the iteration's scalars, read asynchronously ----------------------------------------------------------------
+    # train() ends with ONE asynchronous device-to-host copy of all its scalars into pinned memory and an event;
+    # `log_dict` (and everything that reads it) waits for that event only when somebody looks.  The reference reads its
+    # losses with .item() inside the iteration (vsrgan_model.py:166-173, 206-286): the host then cannot enqueue the next
+    # iteration before the GPU has finished this one, and the first ~40 launches of every iteration run behind an empty
+    # queue (0.4 ms of a 10.4 ms step at the REDS crop, tools/prof_train_gaps.sh).  The fail-safe check of the chained
+    # launches rides on the same scalars: a fault of iteration k raises on the first look at its log, at the latest at
+    # the end of iteration k + 1 (whose update the device-side guard drops as well) and before every save().
+    @property
+    def log_dict(self):
+        self._drain_log_queue()
+        self._materialize_log()
+        return self._log_dict
+
+    @log_dict.setter
+    def log_dict(self, value):
+        self._pending_log = None
+        self._log_dict = value
+
+    def _pinned_like(self, scal):
+        for i, t in enumerate(self._log_pinned):
+            if t.numel() == scal.numel():
+                return self._log_pinned.pop(i)
+        return torch.empty(scal.numel(), dtype=torch.float32, pin_memory=True)
+
+    def _set_pending_log(self, scal, build):
+        """scal: device tensor of the iteration's scalars; build(list of floats) -> OrderedDict (may raise)."""
+        prev, self._pending_log = self._pending_log, None
+        if prev is not None:          # nobody looked at the previous iteration: its checks still run (its event is long
+            self._resolve(prev)       # complete).  A fault raises HERE, before this iteration's scalars are recorded.
+        host = self._pinned_like(scal)
+        host.copy_(scal, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending_log = (ev, host, build)
+
+    def _resolve(self, pending):
+        ev, host, build = pending
+        ev.synchronize()
+        vals = host.tolist()
+        self._log_pinned.append(host)
+        return build(vals)
+
+    def _materialize_log(self):
+        p = self._pending_log
+        if p is not None:
+            self._pending_log = None
+            self._log_dict = self._resolve(p)
+
+    def sync_log(self):
+        """Wait for the last iteration's scalars (and its fault check) now."""
+        return self.log_dict
+
+    def _drain_log_queue(self, ready_only=False):
+        """ready_only: fold in the queued iterations whose scalars have ARRIVED (no waiting) -- called every iteration, so
+        a fault is reported within an iteration or two although nobody waits for the log."""
+        q = self._log_queue
+        n = len(q)
+        if ready_only:
+            n = 0
+            while n < len(q) and q[n][0].query():
+                n += 1
+        q, self._log_queue = q[:n], q[n:]
+        d = self.log_decay
+        for p in q:
+            self._log_dict = cur_log = self._resolve(p)
+            for k, cur in cur_log.items():
+                run = self.running_log_dict.get(k)
+                self.running_log_dict[k] = cur if run is None else d * run + (1.0 - d) * cur
+
     def reduce_log(self):
         """base_model.py:156-168: mean over ranks, result on rank 0."""
         if self.dist:
@@ -117,6 +188,12 @@ class BaseModel:
             self.log_dict = OrderedDict((k, v.item()) for k, v in zip(keys, vals))
 
     def update_running_log(self):
+        if not self.dist and self._pending_log is not None:
+            # single process: the running mean is folded in when somebody asks for it (get_running_log / the log line)
+            self._log_queue.append(self._pending_log)
+            self._pending_log = None
+            self._drain_log_queue(ready_only=len(self._log_queue) < 64)
+            return
         self.reduce_log()
         d = self.log_decay
         for k, cur in self.log_dict.items():
@@ -127,6 +204,7 @@ class BaseModel:
         return self.log_dict
 
     def get_running_log(self):
+        self._drain_log_queue()
         return self.running_log_dict
 
     def get_format_msg(self, epoch, iter):

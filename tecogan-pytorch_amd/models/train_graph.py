@@ -387,17 +387,21 @@ def stamp_fault(optim):
         ops.fault_to_slot(err, optim.fault_slot)
 
 
-def chain_check(slot_value=0.0):
-    """Call after a host synchronisation (the training step's scalar read): raises if a chained launch
-    recorded a fault since the last check, here (pinned counter) or on any rank (`slot_value`: the fault slot
-    of the generator's gradient buffer after its all-reduce, read with the step's scalars).  The iteration's
-    generator update was dropped on every rank by the device-side guard; every later step runs one launch
-    per layer."""
+def chain_check(slot_value=0.0, counter=True):
+    """Raises if a chained launch recorded a fault: on any rank in the iteration whose scalars are being looked at
+    (`slot_value`: the fault slot of the generator's gradient buffer after its all-reduce, read with that iteration's
+    scalars), or -- `counter`, for callers that have just synchronised the device -- on this rank since the last check
+    (pinned counter).  The training step resolves its scalars asynchronously (base_model: a later iteration may
+    already be in flight and adding to the counter), so it passes counter=False and relies on the slot, which is
+    exact per iteration; the counter is cleared only after a device synchronisation.  The iteration's generator
+    update was dropped on every rank by the device-side guard; every later step runs one launch per layer."""
     err = _ChainState.err
-    local = err is not None and int(err[0]) != 0
+    local = counter and err is not None and int(err[0]) != 0
     if local or slot_value != 0.0:
         from .. import _lib as L
-        lost = int(err[0]) if local else 0
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()            # nothing in flight may add to the counter after it is cleared
+        lost = int(err[0]) if err is not None else 0
         if err is not None:
             err.zero_()
         _ChainState.disabled = True
@@ -405,7 +409,7 @@ def chain_check(slot_value=0.0):
             'chained SRNet launch (training): %s timed out waiting for a neighbour tile; the results of this '
             'step are INVALID and its optimiser step was DROPPED on every rank (weights and Adam moments '
             'untouched).  Later steps run one launch per layer.'
-            % (f'{lost} workgroup(s) of this rank' if local else 'workgroups of another rank'))
+            % (f'{lost} workgroup(s) of this rank' if lost else 'workgroups of another rank'))
 
 
 def srnet_body(tape, srnet, lr, tran):

@@ -62,11 +62,15 @@ class VSRModel(BaseModel):
         self.optim_G.step()
         if getattr(self.optim_G, 'fault_slot', None) is not None:
             losses[2:3].copy_(self.optim_G.fault_slot)
-        vals = losses.tolist()                       # the iteration's only host sync
-        TG.chain_check(vals[2])  # fail-safe of the chained launches: raises on EVERY rank, the update was dropped
-        self.log_dict = OrderedDict(l_pix_G=vals[0])
-        if self.warp_crit is not None:
-            self.log_dict['l_warp_G'] = vals[1]
+        has_warp = self.warp_crit is not None
+
+        def build(vals):                             # runs when the log is looked at (base_model: asynchronous scalars)
+            TG.chain_check(vals[2], counter=False)  # fail-safe of the chained launches: raises on EVERY rank, the update was dropped
+            d = OrderedDict(l_pix_G=vals[0])
+            if has_warp:
+                d['l_warp_G'] = vals[1]
+            return d
+        self._set_pending_log(losses, build)
 
     def infer(self, device_output=False):
         """vsr_model.py:97-113: temporal padding, inference, crop the padding back.
@@ -81,4 +85,5 @@ class VSRModel(BaseModel):
         return hr_seq[n_pad_front:]
 
     def save(self, current_iter):
+        self.sync_log()          # (a pending fault check must run before weights are written)
         self.save_network(self.net_G, 'G', current_iter)

@@ -210,30 +210,38 @@ class VSRGANModel(VSRModel):
         if getattr(self.optim_G, 'fault_slot', None) is not None:
             scal[14:15].copy_(self.optim_G.fault_slot)
 
-        # === logging: one host read of all scalars ===
-        sc_ = scal.tolist()
-        TG.chain_check(sc_[14])  # fail-safe of the chained launches: raises on EVERY rank, G's update was dropped
-        sr, sf, sg, ls = sc_[0:3], sc_[3:6], sc_[6:9], sc_[9:14]
-        self.log_dict = OrderedDict()
-        self.log_dict['l_gan_D'] = (sr[0] + sf[0]) if upd_D else 0.0
-        self.log_dict['p_real_D'] = sr[1]
-        self.log_dict['p_fake_D'] = sf[1]
-        if update_policy == 'adaptive':
-            self.log_dict['distance'] = distance
-            self.log_dict['n_upd_D'] = self.cnt_upd_D
-        if self.pix_crit is not None:
-            self.log_dict['l_pix_G'] = ls[0]
-        if self.warp_crit is not None:
-            self.log_dict['l_warp_G'] = ls[1]
-        if self.feat_crit is not None:
-            self.log_dict['l_feat_G'] = ls[3]
-        if self.pp_crit is not None:
-            self.log_dict['l_pp_G'] = ls[2]
-        if self.fm_crit is not None:
-            self.log_dict['l_fm_G'] = ls[4]
-        self.log_dict['l_gan_G'] = gan_w * sg[0]
-        self.log_dict['p_fake_G'] = sg[1]
+        # === logging: ONE asynchronous read of all scalars (base_model: resolved when the log is looked at) ===
+        cnt_upd, adaptive = self.cnt_upd_D, update_policy == 'adaptive'
+        dist_val = distance if adaptive else None
+        has = dict(pix=self.pix_crit is not None, warp=self.warp_crit is not None, feat=self.feat_crit is not None,
+                   pp=self.pp_crit is not None, fm=self.fm_crit is not None)
+
+        def build(sc_):
+            TG.chain_check(sc_[14], counter=False)  # fail-safe of the chained launches: raises on EVERY rank, G's update was dropped
+            sr, sf, sg, ls = sc_[0:3], sc_[3:6], sc_[6:9], sc_[9:14]
+            d = OrderedDict()
+            d['l_gan_D'] = (sr[0] + sf[0]) if upd_D else 0.0
+            d['p_real_D'] = sr[1]
+            d['p_fake_D'] = sf[1]
+            if adaptive:
+                d['distance'] = dist_val
+                d['n_upd_D'] = cnt_upd
+            if has['pix']:
+                d['l_pix_G'] = ls[0]
+            if has['warp']:
+                d['l_warp_G'] = ls[1]
+            if has['feat']:
+                d['l_feat_G'] = ls[3]
+            if has['pp']:
+                d['l_pp_G'] = ls[2]
+            if has['fm']:
+                d['l_fm_G'] = ls[4]
+            d['l_gan_G'] = gan_w * sg[0]
+            d['p_fake_G'] = sg[1]
+            return d
+        self._set_pending_log(scal, build)
 
     def save(self, current_iter):
+        self.sync_log()          # (a pending fault check must run before weights are written)
         self.save_network(self.net_G, 'G', current_iter)
         self.save_network(self.net_D, 'D', current_iter)

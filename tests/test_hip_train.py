@@ -208,7 +208,7 @@ def test_guarded_adam_step_and_fault_slot():
 def test_training_step_with_chain_fault_drops_the_update_and_raises():
     """A chained-launch fault during a training iteration (injected: negative poll limit) must NOT reach the
     weights: the generator's Adam step is a no-op on the device (fault slot of the gradient bucket), the
-    iteration raises after its host sync, and the next iteration runs one launch per layer from the
+    iteration's log (sync_log / log_dict / the next iteration's end) raises, and the next iteration runs one launch per layer from the
     unchanged weights.  (the check used to run after the optimiser step.)"""
     import subprocess
     import sys
@@ -229,8 +229,8 @@ def test_training_step_with_chain_fault_drops_the_update_and_raises():
         "before = {k: v.detach().clone() for k, v in m.net_G.state_dict().items()}\n"
         "mom = [(a.clone(), b.clone()) for a, b in (m.optim_G.state[id(p)] for p in m.optim_G.params)]\n"
         "TG._ChainState.poll_limit = -1               # every waiting workgroup gives up at once\n"
-        "try:\n"
-        "    m.train(); raise SystemExit('no error reported')\n"
+        "try:                                        # the fault surfaces with the scalars: at the end of train() or on the first look at the log\n"
+        "    m.train(); m.sync_log(); raise SystemExit('no error reported')\n"
         "except _lib.TecoganHipError as e:\n"
         "    assert 'DROPPED' in str(e) and 'timed out' in str(e), str(e)\n"
         "after = m.net_G.state_dict()\n"
@@ -292,3 +292,39 @@ def test_backward_warp_s2d_equals_warp_then_space_to_depth(scale, shape):
     assert torch.allclose(acc, base + rimg, rtol=1e-5, atol=1e-6)
     only_flow = ops.backward_warp_bwd(x, flow, dy, need_img=False, s2d=scale)
     assert only_flow[0] is None and torch.equal(only_flow[1], rflow)
+
+
+def test_asynchronous_log_equals_reading_it_every_iteration():
+    """base_model: train() leaves its scalars as ONE pending asynchronous device-to-host copy; log_dict /
+    update_running_log / get_running_log resolve it lazily.  A run that never looks at the log inside the loop
+    (update_running_log only queues) must end with exactly the running means of a run that reads the log every
+    iteration (the reference's .item() loop, base_model.py:170-186), and the last log must be the last iteration's."""
+    from tecogan_pytorch_amd.models import define_model
+    runs = []
+    for read_each in (True, False):
+        torch.manual_seed(0)
+        m = define_model(make_opt('TecoGAN', 0.4))
+        m.net_G.load_state_dict(generator_state_dict(scale=SCALE, degradation='BD'), strict=True)
+        m.net_D.load_state_dict(discriminator_state_dict(spatial_size=CROP, scale=SCALE, degradation='BD'), strict=True)
+        logs = []
+        for it in range(4):
+            m.prepare_training_data({'gt': batch(100 + 10 * it)})
+            m.train()
+            assert m._pending_log is not None           # nothing has been waited for yet
+            if read_each:
+                logs.append(dict(m.log_dict))
+                assert m._pending_log is None
+            m.update_running_log()
+            if not read_each:
+                assert m._pending_log is None and len(m._log_queue) >= 1
+        runs.append((dict(m.get_running_log()), dict(m.log_dict), logs))
+        assert not m._log_queue and m._pending_log is None
+    (run_a, last_a, logs), (run_b, last_b, _) = runs
+    assert last_a == logs[-1]
+    d, ema = 0.99, None
+    for lg in logs:                                     # base_model.py:175-186 by hand
+        ema = dict(lg) if ema is None else {k: d * ema[k] + (1.0 - d) * v for k, v in lg.items()}
+    assert all(abs(ema[k] - run_a[k]) <= 1e-12 * (1.0 + abs(ema[k])) for k in ema)
+    # the two runs are the same computation up to the order of the step's atomic adds (warp / up-sampling scatters)
+    close = lambda x, y: all(abs(x[k] - y[k]) <= 2e-3 * abs(x[k]) + 1e-6 for k in x) and x.keys() == y.keys()
+    assert close(last_a, last_b) and close(run_a, run_b), (last_a, last_b, run_a, run_b)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--batch', type=int, default=2)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--log-every', type=int, default=0, help='wait for the scalars every N iterations (0: only at the end)')
     ap.add_argument('--model', default='TecoGAN')
     ap.add_argument('--force-d', action='store_true', help='update D every step (threshold = +inf)')
     ap.add_argument('--feature-crit', action='store_true',
@@ -72,17 +73,21 @@ def main():
                     from tecogan_pytorch_amd import ops as _ops
                     _ops.bump_version(p)
     gen = torch.Generator().manual_seed(1 + rank)
-    data = [{'gt': torch.rand(a.batch, a.tempo, 3, a.crop + 8, a.crop + 8, generator=gen)}
+    # (resident in HBM like bench.py's training leg and like the LMDB front end's batches: data/__init__.py)
+    data = [{'gt': torch.rand(a.batch, a.tempo, 3, a.crop + 8, a.crop + 8, generator=gen).cuda()}
             for _ in range(2)]
     for i in range(a.warmup):
         m.prepare_training_data(data[i % 2]); m.train()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    nupd = 0
+    nupd0 = getattr(m, 'cnt_upd_D', 0.0)
     for i in range(a.steps):
         m.prepare_training_data(data[i % 2]); m.train()
-        nupd += 1 if m.log_dict.get('l_gan_D', 0) != 0 else 0
+        if a.log_every and (i + 1) % a.log_every == 0:
+            m.sync_log()                 # what reading the losses every `log_every` iterations costs (1: the reference's loop)
+    m.sync_log()
     torch.cuda.synchronize()
+    nupd = int(getattr(m, 'cnt_upd_D', 0.0) - nupd0)
     dt = (time.perf_counter() - t0) / a.steps
     dt = dist_utils.max_over_ranks(dt, device='cuda') if opt['dist'] else dt
     tt = 2 * a.tempo - 1 if a.model != 'FRVSR' else a.tempo
