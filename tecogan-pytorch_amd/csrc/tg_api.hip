@@ -226,7 +226,7 @@ static bool hr_fuse_enabled() {
 // -6.5 % at 4, -4.6 % at 268x640, +-0 at 8 clips, and +3..15 % (slower) for a single 134x320 clip, whose
 // 670 workgroups are all resident at once and therefore cannot pipeline.  TG_WINO_CHAIN=0 / 1: never / whenever eligible.
 static bool chain_wanted(long long ntile) {
-  static const int v = [] { const char* e = getenv("TG_WINO_CHAIN"); return e ? atoi(e) : -1; }();
+  static const int v = [] { const char* e = getenv("TG_WINO_CHAIN"); return e && *e ? atoi(e) : -1; }();
   if (v >= 0) return v != 0;
   return ntile > 768 && ntile <= 3000;
 }
@@ -234,7 +234,7 @@ static bool chain_wanted(long long ntile) {
 // enough for the Winograd form to be the per-layer choice (a single 134x320-class frame).  TG_WINO_RES=0
 // selects the per-layer / chained launches, 1 the resident launch wherever it is supported (A/B runs, tests).
 static bool resident_wanted(bool layer_prefers_wino) {
-  static const int v = [] { const char* e = getenv("TG_WINO_RES"); return e ? atoi(e) : -1; }();
+  static const int v = [] { const char* e = getenv("TG_WINO_RES"); return e && *e ? atoi(e) : -1; }();
   return v >= 0 ? v != 0 : layer_prefers_wino;     // 1: whenever supported (tests run small frames through it)
 }
 // the fused tail writes (n, H, W, c) uint8 frames for any n; the unfused quantise pass only n == 1

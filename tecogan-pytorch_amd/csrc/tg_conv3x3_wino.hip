@@ -499,7 +499,7 @@ extern "C" int64_t tg_conv3x3_wino_packed_floats(int cin, int cout) {
 // kernels win by 5-30 %.
 // TG_CONV_WINO=0/1 overrides (lab / A-B).
 extern "C" int tg_conv3x3_prefers_wino(int n, int cin, int cout, int h, int w) {
-  static const int env = [] { const char* e = getenv("TG_CONV_WINO"); return e ? atoi(e) : -1; }();
+  static const int env = [] { const char* e = getenv("TG_CONV_WINO"); return e && *e ? atoi(e) : -1; }();
   if (env == 0) return 0;
   if (n <= 0 || cin < 16 || cout <= 0 || cout % 64 != 0 || h < 2 || w < 2) return 0;
   const long long wgs = (long long)cdiv(w, 32) * cdiv(h, 2) * (cout / 64) * n;
