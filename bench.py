@@ -468,7 +468,7 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
             'logger': {'decay': 0.99},
         }
 
-    def run(crop, steps, warm=3):
+    def run(crop, steps, warm=8):
         torch.manual_seed(0 + rank)                       # base_utils.py:46
         m = define_model(opt_for(crop))                   # broadcasts rank 0's weights under DDP
         if dist_on and world > 1:
@@ -483,16 +483,22 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
             _barrier(dist, local_rank)
         from tecogan_pytorch_amd.utils import dist_utils as DU
         c0 = dict(DU.COMM_COUNTS)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        import gc
+        gc.collect()                              # (a collection of this long-lived process inside 10 steps is 5 % of them)
         nupd0 = getattr(m, 'cnt_upd_D', 0.0)
-        for i in range(steps):                    # (the log is NOT read per step: like a run that prints every 100 iterations)
-            m.prepare_training_data(data[i % 2]); m.train()
-        m.sync_log()                              # the last iteration's scalars and fault check
-        torch.cuda.synchronize()
-        nupd = int(getattr(m, 'cnt_upd_D', 0.0) - nupd0)
-        dt = (time.perf_counter() - t0) / steps
-        m.comm_per_step = {k: (DU.COMM_COUNTS[k] - c0[k]) / steps for k in c0}
+        blocks = []
+        for _ in range(3):                        # three blocks of `steps` iterations, the median block is reported
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):                # (the log is NOT read per step: like a run that prints every 100 iterations)
+                m.prepare_training_data(data[i % 2]); m.train()
+            m.sync_log()                          # the last iteration's scalars and fault check
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / steps)
+        nupd = int(getattr(m, 'cnt_upd_D', 0.0) - nupd0) // 3
+        dt = sorted(blocks)[1]
+        m.train_blocks_ms = [1e3 * b for b in blocks]
+        m.comm_per_step = {k: (DU.COMM_COUNTS[k] - c0[k]) / (3 * steps) for k in c0}
         if dist_on:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -533,6 +539,7 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
                     '(adaptive policy with threshold +inf: the full G + D step incl. both gradient exchanges)',
         'n_gpus': world, 'ms_per_step': 1e3 * dt, 'clips_per_s': world * 2 / dt,
         'hr_frames_per_s': world * 2 * 19 / dt, 'd_updates': nupd, 'steps': args.train_steps,
+        'ms_per_step_blocks': getattr(m, 'train_blocks_ms', None), 'statistic': 'median of three blocks of `steps` iterations',
         'scaling': 'weak'})
     # the two gradient buckets on their own
     for name, optim in (('G', m.optim_G), ('D', m.optim_D)):
