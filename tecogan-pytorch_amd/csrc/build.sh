@@ -15,9 +15,11 @@ PIDS=()
 for f in tg_*.hip; do
   o="${f%.hip}.o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ tg_common.h -nt "$o" ] || [ ../../include/tecogan_hip.h -nt "$o" ]; then
-    echo "hipcc $f"
+    # per-file flags: a line `// TG_FILE_FLAGS: ...` in the source (e.g. -fno-slp-vectorize for a hand-scheduled loop)
+    ff=$(sed -n 's/^\/\/ TG_FILE_FLAGS: *//p' "$f" | head -1)
+    echo "hipcc $f $ff"
     rm -f "$o"                       # a failed compile must not leave a stale object to link
-    $HIPCC $FLAGS ${EXTRA_FLAGS:-} -c "$f" -o "$o" &
+    $HIPCC $FLAGS $ff ${EXTRA_FLAGS:-} -c "$f" -o "$o" &
     PIDS+=($!)
   fi
   OBJS+=("$o")

@@ -25,6 +25,11 @@
 // directions): the launcher refuses grids above the device's CU count minus a margin, and the kernel
 // is FAIL-SAFE like the other chained launches (poll limit -> fault counter in pinned host memory
 // -> the plan reports TG_E_HIP and runs one launch per layer for good).
+//
+// TG_FILE_FLAGS: -fno-slp-vectorize
+// (build.sh passes this line's flags to hipcc for THIS file.  With the K loop one straight-line block the SLP
+// vectorizer pairs the transform's adds into v_pk_add_f32 and pays for it with ~12 v_mov_b32 per K step -- every VALU
+// instruction adds to the fp32-MFMA time on this pipe: 21.2 vs 18.9 us per layer, round 5.)
 #include <type_traits>
 
 #include "tg_common.h"
@@ -45,6 +50,15 @@
 #define TG_WRES_LAB 0   // 1: ablation switches (env TG_WRES_ABL) compiled in -- tools/build_lab_libs.sh, timing only
 #endif
 #define RABL(bit) (TG_WRES_LAB && (a.abl & (bit)))
+#ifndef WR_FAKEBANK
+#define WR_FAKEBANK 0   // lab, TIMING ONLY (wrong results): window origins spread over distinct bank pairs -- the ceiling of any layout fix
+#endif
+#ifndef WR_RDFORM
+#define WR_RDFORM 0     // 0: the compiler's window reads (it merges them into ds_read2_b64); 1: eight ds_read_b64 (inline asm)
+#endif
+#ifndef WR_PREF
+#define WR_PREF 1       // 1: K step ks + 1's window is requested before K step ks's MFMAs (second register set)
+#endif
 
 namespace tg {
 
@@ -111,7 +125,7 @@ struct WResArgs {
   const float* ct_bias;
   float* ct_y;         // (64, 2h, 2w)
   int ct_act;
-  int abl;             // lab builds only: 1 no flag wait / ring loads, 2 no MFMA, 4 no weight loads, 8 no ring stores, 16 no window reads, 32 no hand-over at all
+  int abl;             // lab builds only: 1 no flag wait / ring loads, 2 no MFMA, 4 no weight loads, 8 no ring stores, 16 no window reads, 32 no hand-over at all, 64 no input transform, 128 weights from L1, 256 half the weight bytes, 512 half the window bytes
 };
 
 __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WResArgs a) {
@@ -177,7 +191,11 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
   if (WR_PRIO_B > 0 && !interior) __builtin_amdgcn_s_setprio(WR_PRIO_B);
   if (WR_PRIO_I > 0 && interior) __builtin_amdgcn_s_setprio(WR_PRIO_I);
   const int kk = l >> 4;                      // K index inside a K step (B operand) / output-channel quad (D)
+#if WR_FAKEBANK
+  const int rb = kk * WR_CS + 2 * (l & 15);
+#else
   const int rb = kk * WR_CS + (2 * ty) * WR_RS + 2 * tx;        // window origin in the resident block (floats)
+#endif
   const int oc_base = 16 * q + 4 * kk;
   const int wb = oc_base * WR_CS + (2 * ty + 1) * WR_RS + 2 * tx + 1;   // own 2x2 pixels, channel oc_base
   const int gy0 = Y0 + 2 * ty, gx0 = X0 + 2 * tx;               // image position of the tile
@@ -188,10 +206,69 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
 
   const size_t ulane = (size_t)(q * 4) * 64 + l;               // this lane's 16 bytes inside a K step's block
   constexpr size_t USTEP = (size_t)4 * 4 * 64;                  // f32x4 per K step (64 output channels)
+  // The weight prefetch (round 5).  Two things kept a K step from ever running ahead of its weights:
+  //  * a prefetch behind `if (ks < nks)` makes the compiler's s_waitcnt insertion merge the two paths at the join and
+  //    assume the FEWER loads in flight: every K step waited `vmcnt(3..0)`, i.e. for the block requested a moment ago
+  //    as well as for its own;
+  //  * branch-free (past the last K step the last block is requested again: an L1 hit, never used) the same pass
+  //    still emitted `vmcnt(0)` in this loop nest.
+  // So the loads and their waits are written out (WR_UASM): the compiler does not see these loads, the waits carry the
+  // exact counts -- a block's four loads are always followed by the four loads of the other block before it is used,
+  // so `vmcnt(7..4)` releases it (at a layer's first K steps more has been issued in between: the wait is then merely
+  // stronger than needed).  The compiler's own waits (ring, stores) count only its own operations and can only be
+  // stronger than needed as well.  The stream of blocks runs ACROSS the layers: the last two K steps of a layer
+  // request the first two blocks of the next one (they arrive under the epilogue and the hand-over), so exactly two
+  // blocks are in flight at every point of the launch and the epilogue issues no request of its own.
+#ifndef WR_UASM
+#define WR_UASM 1        // 0: compiler-visible loads (the round-4 form with -DWR_BRANCHY_U=1), for A/B
+#endif
+#if WR_UASM && WR_USETS != 2
+#error "the hand-written waits assume two weight blocks in flight"
+#endif
+#ifndef WR_BRANCHY_U
+#define WR_BRANCHY_U 0
+#endif
+  const f32x4* un = nullptr;                   // WR_UASM: the next layer's blocks (the K loop runs on into them)
   auto load_u = [&](const f32x4* ub, int ks, int nks, f32x4 (&u)[4]) {
+#if WR_BRANCHY_U
     if (ks >= nks || (RABL(4) && ks > 1)) return;
-    const f32x4* p = ub + (size_t)ks * USTEP;
-    u[0] = p[0]; u[1] = p[64]; u[2] = p[128]; u[3] = p[192];
+#elif WR_UASM
+    if (RABL(4) && ks > 1) return;
+    if (ks >= nks) { ub = un; ks -= nks; }      // uniform: a scalar select, no branch
+#else
+    if (RABL(4) && ks > 1) return;
+    ks = ks < nks ? ks : nks - 1;
+#endif
+    const f32x4* p = ub + (size_t)(RABL(128) ? (ks & 1) : ks) * USTEP;     // lab 128: always the same two blocks (L1 hits)
+#if WR_UASM
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(u[0]) : "v"(p));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(u[1]) : "v"(p));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(u[2]) : "v"(p));
+    asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(u[3]) : "v"(p));
+#else
+    u[0] = p[0]; u[1] = p[64];
+    if (RABL(256)) return;                     // lab 256: half the weight bytes
+    u[2] = p[128]; u[3] = p[192];
+#endif
+  };
+  // Behind the K loop two blocks nobody uses are still in flight (the clamped requests of the last two K steps): the
+  // compiler takes their registers for dead and would hand them to the next instruction -- a landing load then
+  // overwrites, say, the address of the epilogue's first request (a memory fault, found on the GPU).  The drain keeps
+  // the eight registers allocated until every load has landed.
+  auto drain_u = [&](f32x4 (&ua)[4], f32x4 (&ub_)[4]) {
+#if WR_UASM
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ua[0]), "+v"(ua[1]), "+v"(ua[2]), "+v"(ua[3]),
+                                        "+v"(ub_[0]), "+v"(ub_[1]), "+v"(ub_[2]), "+v"(ub_[3]));
+#endif
+  };
+  // the block `u` was requested one block ago (see above): release it quarter by quarter
+  auto wait_u = [&](f32x4 (&u)[4]) {
+#if WR_UASM
+    asm volatile("s_waitcnt vmcnt(7)" : "+v"(u[0]));
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(u[1]));
+    asm volatile("s_waitcnt vmcnt(5)" : "+v"(u[2]));
+    asm volatile("s_waitcnt vmcnt(4)" : "+v"(u[3]));
+#endif
   };
 
   f32x4 u0[4], u1[4];
@@ -214,6 +291,8 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
     float* dst = s_act + ((L & 1) ^ 1) * (WR_NC * WR_CS);
     const f32x4* ub = reinterpret_cast<const f32x4*>(lay.u) + ulane;
     const int nks = lay.nks;
+    // (behind the last layer its own first blocks are requested once more; drain_u retires them)
+    un = reinterpret_cast<const f32x4*>(a.L[L + 1 < a.nlayer ? L + 1 : L].u) + ulane;
 
     RSTAMP(0);
     f32x4 acc[16];
@@ -224,9 +303,63 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
     // instructions of the waves of a SIMD do NOT overlap on gfx950 -- tools/valu_lab.hip: 16 MFMAs + 32
     // adds take exactly the sum of both -- so the order inside a step matters little; a burst form with
     // the next window prefetched measured slower: 24.4 vs 21.5 us per layer, it costs registers.)
+    // the 4 x 4 window of channel 4 ks + kk at this lane's tile
+    auto win_load = [&](int ks, float (&d)[4][4]) {
+      const float* sp = src + rb + (RABL(16) ? 0 : ks * (4 * WR_CS));
+#if WR_RDFORM == 1
+      // eight ds_read_b64 (2 x 32 lanes, 256 B/clk) instead of the four ds_read2_b64 the compiler merges them into
+      // (4 x 16 lanes per access, 128 B/clk -- MI355X_MICROARCH.md section LDS)
+      const unsigned ad = (unsigned)(uintptr_t)sp;      // LDS byte address = low 32 bits of the generic pointer
+      v2f p[8];
+#define WR_DSR(i, off) asm volatile("ds_read_b64 %0, %1 offset:" #off : "=v"(p[i]) : "v"(ad))
+      WR_DSR(0, 0); WR_DSR(1, 8); WR_DSR(2, 112); WR_DSR(3, 120); WR_DSR(4, 224); WR_DSR(5, 232); WR_DSR(6, 336); WR_DSR(7, 344);
+#undef WR_DSR
+      static_assert(WR_RS == 28, "the byte offsets above are rows of 28 floats");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { d[r][0] = p[2 * r].x; d[r][1] = p[2 * r].y; d[r][2] = p[2 * r + 1].x; d[r][3] = p[2 * r + 1].y; }
+#else
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (RABL(512) && r >= 2) {             // lab 512: half the window bytes
+          d[r][0] = d[r - 2][1]; d[r][1] = d[r - 2][0]; d[r][2] = d[r - 2][3]; d[r][3] = d[r - 2][2];
+          continue;
+        }
+        const float2 p0 = *reinterpret_cast<const float2*>(sp + r * WR_RS);
+        const float2 p1 = *reinterpret_cast<const float2*>(sp + r * WR_RS + 2);
+        d[r][0] = p0.x; d[r][1] = p0.y; d[r][2] = p1.x; d[r][3] = p1.y;
+      }
+#endif
+    };
+    // one K step: window -> B^T d B in registers -> 16 MFMAs.  (fp32 MFMAs and VALU
+    // instructions of the waves of a SIMD do NOT overlap on gfx950 -- tools/valu_lab.hip: 16 MFMAs + 32
+    // adds take exactly the sum of both -- so the order inside a step matters little; a burst form with
+    // the next window prefetched measured slower: 24.4 vs 21.5 us per layer, it costs registers.)
+    auto kcompute = [&](const float (&d)[4][4], f32x4 (&u)[4]) {
+      wait_u(u);
+      f32x4 bq[4];
+      if (RABL(64)) {                          // lab: no input transform (wrong results; what the 32 adds cost)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bq[r] = f32x4{d[r][0], d[r][1], d[r][2], d[r][3]};
+      } else {
+        float qa[4], qb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { qa[c] = d[0][c] - d[2][c]; qb[c] = d[1][c] + d[2][c]; }
+        bq[0] = f32x4{qa[0] - qa[2], qa[1] + qa[2], qa[2] - qa[1], qa[1] - qa[3]};
+        bq[1] = f32x4{qb[0] - qb[2], qb[1] + qb[2], qb[2] - qb[1], qb[1] - qb[3]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { qa[c] = d[2][c] - d[1][c]; qb[c] = d[1][c] - d[3][c]; }
+        bq[2] = f32x4{qa[0] - qa[2], qa[1] + qa[2], qa[2] - qa[1], qa[1] - qa[3]};
+        bq[3] = f32x4{qb[0] - qb[2], qb[1] + qb[2], qb[2] - qb[1], qb[1] - qb[3]};
+      }
+      if (RABL(2)) { acc[0] += bq[0] + bq[1] + bq[2] + bq[3] + u[0] + u[1] + u[2] + u[3]; return; }
+#pragma unroll
+      for (int p = 0; p < 16; ++p)
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[p >> 2][p & 3], bq[p >> 2][p & 3], acc[p], 0, 0, 0);
+    };
+#if WR_PK
     auto kstep = [&](int ks, const f32x4 (&u)[4]) {
       const float* sp = src + rb + (RABL(16) ? 0 : ks * (4 * WR_CS));
-#if WR_PK
       // B^T d B on packed fp32 (v_pk_add_f32: the two columns of an 8-byte LDS read are one operand): 8 packed
       // row combinations, then per combination {q0 - q2, q1 - q3} (packed) and {q1 + q2, q2 - q1} -- ONE
       // v_pk_add_f32 with op_sel / neg_hi picking the halves (the compiler needs three instructions for that
@@ -252,34 +385,39 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
       };
       cols(lo[0] - lo[2], hi[0] - hi[2], lo[1] + lo[2], hi[1] + hi[2], bq[0], bq[1]);
       cols(lo[2] - lo[1], hi[2] - hi[1], lo[1] - lo[3], hi[1] - hi[3], bq[2], bq[3]);
-#else
-      float d[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float2 p0 = *reinterpret_cast<const float2*>(sp + r * WR_RS);
-        const float2 p1 = *reinterpret_cast<const float2*>(sp + r * WR_RS + 2);
-        d[r][0] = p0.x; d[r][1] = p0.y; d[r][2] = p1.x; d[r][3] = p1.y;
-      }
-      f32x4 bq[4];
-      {
-        float qa[4], qb[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { qa[c] = d[0][c] - d[2][c]; qb[c] = d[1][c] + d[2][c]; }
-        bq[0] = f32x4{qa[0] - qa[2], qa[1] + qa[2], qa[2] - qa[1], qa[1] - qa[3]};
-        bq[1] = f32x4{qb[0] - qb[2], qb[1] + qb[2], qb[2] - qb[1], qb[1] - qb[3]};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { qa[c] = d[2][c] - d[1][c]; qb[c] = d[1][c] - d[3][c]; }
-        bq[2] = f32x4{qa[0] - qa[2], qa[1] + qa[2], qa[2] - qa[1], qa[1] - qa[3]};
-        bq[3] = f32x4{qb[0] - qb[2], qb[1] + qb[2], qb[2] - qb[1], qb[1] - qb[3]};
-      }
-#endif
       if (RABL(2)) { acc[0] += bq[0] + bq[1] + bq[2] + bq[3] + u[0] + u[1] + u[2] + u[3]; return; }
 #pragma unroll
       for (int p = 0; p < 16; ++p)
         acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[p >> 2][p & 3], bq[p >> 2][p & 3], acc[p], 0, 0, 0);
     };
+#else
+    auto kstep = [&](int ks, f32x4 (&u)[4]) {
+      float d[4][4];
+      win_load(ks, d);
+      kcompute(d, u);
+    };
+#endif
 
-#if WR_USETS == 3
+#if WR_PREF
+    {   // window of K step ks + 1 in flight under the MFMAs of K step ks (the LDS latency of a K step is otherwise
+        // exposed at its head: a wave that is alone on its SIMD -- the interior waves during the hand-over -- idles there)
+      float dA[4][4], dB[4][4];
+      win_load(0, dA);
+      for (int ks = 0; ks < nks; ks += 2) {
+        win_load(ks + 1, dB);
+        __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the reads to the end of the K step)
+        kcompute(dA, u0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(ub, ks + 2, nks, u0);
+        win_load(ks + 2 < nks ? ks + 2 : ks, dA);
+        __builtin_amdgcn_sched_barrier(0);
+        kcompute(dB, u1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(ub, ks + 3, nks, u1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#elif WR_USETS == 3
     {   // three weight blocks in flight (two K steps of distance): a wave that runs alone on its SIMD -- the
         // interior waves during the hand-over -- otherwise waits for L2 every K step
       int ks = 0;
@@ -302,9 +440,11 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
       kstep(ks, u0);
       __builtin_amdgcn_sched_barrier(0);
       load_u(ub, ks + 2, nks, u0);
+      __builtin_amdgcn_sched_barrier(0);        // (straight-line code now: without it the scheduler sinks the loads into the next K step)
       kstep(ks + 1, u1);
       __builtin_amdgcn_sched_barrier(0);
       load_u(ub, ks + 3, nks, u1);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #endif
     RSTAMP(1);
@@ -343,14 +483,17 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
     };
     if (lay.res) epilogue(std::true_type{}); else epilogue(std::false_type{});
     // the next layer's first weights travel under the hand-over
-    if (L + 1 < a.nlayer) {
-      const f32x4* un = reinterpret_cast<const f32x4*>(a.L[L + 1].u) + ulane;
-      load_u(un, 0, a.L[L + 1].nks, u0);
-      load_u(un, 1, a.L[L + 1].nks, u1);
+#if !WR_UASM
+    {   // (branch-free for the same reason as load_u: behind the last layer the last layer's blocks are requested again)
+      const int Ln = L + 1 < a.nlayer ? L + 1 : L;
+      const f32x4* un2 = reinterpret_cast<const f32x4*>(a.L[Ln].u) + ulane;
+      load_u(un2, 0, a.L[Ln].nks, u0);
+      load_u(un2, 1, a.L[Ln].nks, u1);
 #if WR_USETS == 3
-      load_u(un, 2, a.L[L + 1].nks, u2);
+      load_u(un2, 2, a.L[Ln].nks, u2);
 #endif
     }
+#endif
     if (live) {
       if (last) {
 #pragma unroll
@@ -388,7 +531,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
       }
     }
     RSTAMP(2);
-    if (last) break;
+    if (last) { drain_u(u0, u1); break; }
     if (RABL(32)) { __syncthreads(); continue; }
 
     // ---- hand-over -------------------------------------------------------------------------------
@@ -482,6 +625,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
     RSTAMP(7);
   }
   if (!fold) return;
+  drain_u(u0, u1);                            // (the requests behind the last layer's epilogue)
 
   // ---- tail: ConvTranspose2d(64, 64, 3, stride 2, pad 1, output_padding 1) + act on the resident block ------------
   //   out[2y + py][2x + px] = bias + sum_ic sum_taps in[y + dy][x + dx] W[ic][oc][ky][kx],
@@ -510,12 +654,25 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
     const f32x4* cu = reinterpret_cast<const f32x4*>(a.ct_u) + (size_t)(q * 3) * 64 + l2;
     constexpr size_t CSTEP = (size_t)4 * 3 * 64;
     constexpr int CT_NKS = WR_NC / 4;
+    // (weights: the same hand-written request / wait pairs as the layers' -- see load_u; three 16-byte loads per block)
     auto load_w = [&](int ks, f32x4 (&w)[3]) {
+#if WR_UASM
+      const f32x4* pw = cu + (size_t)(ks < CT_NKS ? ks : CT_NKS - 1) * CSTEP;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(w[0]) : "v"(pw));
+      asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(w[1]) : "v"(pw));
+      asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(w[2]) : "v"(pw));
+#else
       if (ks >= CT_NKS) return;
       const f32x4* pw = cu + (size_t)ks * CSTEP;
       w[0] = pw[0]; w[1] = pw[64]; w[2] = pw[128];
+#endif
     };
-    auto cstep = [&](int ks, const f32x4 (&w)[3]) {
+    auto cstep = [&](int ks, f32x4 (&w)[3]) {
+#if WR_UASM
+      asm volatile("s_waitcnt vmcnt(5)" : "+v"(w[0]));
+      asm volatile("s_waitcnt vmcnt(4)" : "+v"(w[1]));
+      asm volatile("s_waitcnt vmcnt(3)" : "+v"(w[2]));
+#endif
       const float* sp = src + cb + ks * (4 * WR_CS);
       float d[3][3];
 #pragma unroll
@@ -548,10 +705,16 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
       cstep(ks, w0);
       __builtin_amdgcn_sched_barrier(0);
       load_w(ks + 2, w0);
+      __builtin_amdgcn_sched_barrier(0);
       cstep(ks + 1, w1);
       __builtin_amdgcn_sched_barrier(0);
       load_w(ks + 3, w1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+#if WR_UASM
+    // (the last two requests are never used: keep their registers until they have landed -- see drain_u)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]));
+#endif
     if (live) {
       const float cslope = act_slope(a.ct_act);
       const size_t ohw = (size_t)4 * hw;

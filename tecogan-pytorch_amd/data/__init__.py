@@ -3,7 +3,7 @@
 import torch
 
 from .device_clip_store import DeviceClipStore
-from .lmdb_io import LMDBReader, LMDBWriter, make_key, parse_lmdb_key
+from .lmdb_io import LMDBReader, LMDBWriter, is_frame_key, make_key, parse_lmdb_key
 from .paired_lmdb_dataset import PairedLMDBDataset
 from .unpaired_lmdb_dataset import ClipPlan, UnpairedLMDBDataset
 
@@ -45,7 +45,7 @@ class TrainSource:
         """every frame any sample can touch -- the keys of the selected sequences -- into HBM"""
         reader = LMDBReader(seq_dir)
         frames = [k.decode('ascii') for k in reader.keys()]
-        frames = [k for k in frames if k.count('_') >= 2 and parse_lmdb_key(k)[0] in seqs]
+        frames = [k for k in frames if is_frame_key(k) and parse_lmdb_key(k)[0] in seqs]
         store = DeviceClipStore.from_lmdb(reader, frames, device)
         reader.close()
         return store

@@ -288,6 +288,19 @@ class LMDBWriter:
         return len(items)
 
 
+_FRAME_KEY = None
+
+
+def is_frame_key(key):
+    """`{seq}_{n}x{h}x{w}_{i:04d}` (scripts/create_lmdb.py:57) -- anything else in an LMDB (bookkeeping entries such
+    as `__len__`) is not a frame."""
+    global _FRAME_KEY
+    if _FRAME_KEY is None:
+        import re
+        _FRAME_KEY = re.compile(r'^.+_\d+x\d+x\d+_\d+$')
+    return _FRAME_KEY.match(key) is not None
+
+
 def parse_lmdb_key(key):
     """`{seq}_{n}x{h}x{w}_{i:04d}` -> (seq, (n_frames, h, w), frame)  (base_dataset.py:35-41)."""
     parts = key.split('_')

@@ -18,7 +18,7 @@ import random
 import numpy as np
 import torch
 
-from .lmdb_io import LMDBReader, make_key, parse_lmdb_key
+from .lmdb_io import LMDBReader, is_frame_key, make_key, parse_lmdb_key
 from .unpaired_lmdb_dataset import ClipPlan
 
 
@@ -27,7 +27,15 @@ def _keys_of(seq_dir):
     if osp.isfile(meta_path):
         with open(meta_path, 'rb') as f:
             return sorted(pickle.load(f)['keys'])
-    return sorted(k.decode('ascii') for k in LMDBReader(seq_dir).keys())
+    # no meta_info.pkl (the reference requires it, paired_lmdb_dataset.py:24-27): the frame keys of the LMDB itself --
+    # `{seq}_{n}x{h}x{w}_{i:04d}`, filtered as data.TrainSource._load filters them, so that bookkeeping entries are
+    # not mistaken for frames -- and the reader is closed again (the dataset opens its own per worker)
+    reader = LMDBReader(seq_dir)
+    try:
+        keys = [k.decode('ascii') for k in reader.keys()]
+    finally:
+        reader.close()
+    return sorted(k for k in keys if is_frame_key(k))
 
 
 class PairedLMDBDataset:

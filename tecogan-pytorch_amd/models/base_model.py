@@ -164,14 +164,12 @@ class BaseModel:
         """ready_only: fold in the queued iterations whose scalars have ARRIVED (no waiting) -- called every iteration, so
         a fault is reported within an iteration or two although nobody waits for the log."""
         q = self._log_queue
-        n = len(q)
-        if ready_only:
-            n = 0
-            while n < len(q) and q[n][0].query():
-                n += 1
-        q, self._log_queue = q[:n], q[n:]
         d = self.log_decay
-        for p in q:
+        # one entry at a time, each removed only once it has been looked at: a fault raised by an entry's checks
+        # (chained-launch fail-safe) then leaves the LATER entries -- and their pinned buffers -- queued for the next
+        # call instead of dropping them; the faulty entry itself is consumed (it has been reported)
+        while q and (not ready_only or q[0][0].query()):
+            p = q.pop(0)
             self._log_dict = cur_log = self._resolve(p)
             for k, cur in cur_log.items():
                 run = self.running_log_dict.get(k)

@@ -365,7 +365,28 @@ class FRNet(nn.Module):
                                   self.srnet.up_mode())
         return self.srnet(lr_curr, s2d)
 
-    def infer_sequence(self, lr_data, device, pipeline=True, return_device_tensor=False):
+    def infer_sequence(self, lr_data, device, pipeline=True, return_device_tensor=False, on_fault='rerun'):
+        """tecogan_nets.py:254-281; see _infer_sequence for the data path.
+
+        on_fault: what happens when a one-launch SRNet body (the LDS-resident / chained launch, whose workgroups wait
+        for each other and therefore need the GPU to themselves) recorded a fault in this clip -- another tenant or a
+        co-running stream kept part of the grid from starting.  The plan has then fallen back to one launch per layer
+        for good.  'rerun' (default): warn and compute the clip again on that path -- the caller gets correct frames,
+        as from the reference, which has no such failure mode; 'raise': TecoganHipError.  With
+        return_device_tensor=True nothing is synchronised, so a fault can only be REPORTED (at the next call's entry
+        or by check_faults() after the caller's own synchronisation): that mode always raises."""
+        try:
+            return self._infer_sequence(lr_data, device, pipeline, return_device_tensor)
+        except L.TecoganHipError as e:
+            if on_fault != 'rerun' or return_device_tensor or 'timed out' not in str(e):
+                raise
+            import warnings
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()             # whatever of the faulted clip is still queued
+            warnings.warn('infer_sequence: %s -- the clip is computed again with one launch per layer' % e, RuntimeWarning)
+            return self._infer_sequence(lr_data, device, pipeline, False)
+
+    def _infer_sequence(self, lr_data, device, pipeline=True, return_device_tensor=False):
         """lr_data: (t,c,h,w) fp32 (host or device) -> (t, s*h, s*w, c) uint8
         numpy, zero initial state (tecogan_nets.py:254-281).  Frames are quantised on the
         device and there is ONE host synchronisation at the end instead of one per frame.

@@ -73,10 +73,17 @@ class Adam:
             else:
                 p.grad.zero_()              # memset
 
+    def undo_step_count(self):
+        """A step whose update the device-side guard DROPPED (chained-launch fault, models/train_graph.py) must not
+        advance the bias-correction exponent: the caller takes the count back once it learns of the drop."""
+        if self.steps > 0:
+            self.steps -= 1
+
     def step(self):
         g = self.param_groups[0]
         self.steps += 1
-        if self._is_flat() and all(p.requires_grad for p in self.params):
+        flat = self._is_flat()
+        if flat and all(p.requires_grad for p in self.params):
             n = self._ntot
             ops.adam_step(self.flat_param[:n], self.flat_grad[:n], self.flat_m[:n], self.flat_v[:n], g['lr'],
                           g['betas'], g['eps'], g['weight_decay'], self.steps, skip=self.fault_slot)
@@ -89,8 +96,9 @@ class Adam:
             st = self.state.get(id(p))
             if st is None:
                 st = self.state[id(p)] = (torch.zeros_like(p), torch.zeros_like(p))
+            # (frozen parameters: the per-tensor launches carry the same device-side guard as the fused one)
             ops.adam_step(p.data, p.grad, st[0], st[1], g['lr'], g['betas'], g['eps'],
-                          g['weight_decay'], self.steps)
+                          g['weight_decay'], self.steps, skip=self.fault_slot if flat else None)
             # the kernel writes through the raw pointer, which torch's version counter does
             # not see; the packed-weight caches key on this explicit counter as well
             ops.bump_version(p)

@@ -339,6 +339,8 @@ class _ChainState:
     flags = {}
     err = None
     supported = {}
+    dirty = False           # chained launches were enqueued since the last SYNCHRONOUS look at the counter
+    reported_epoch = 0      # launches up to this epoch are covered by a fault that has already been raised
 
     @classmethod
     def buffers(cls, nlayer, n, h, w, device):
@@ -353,6 +355,7 @@ class _ChainState:
         if cls.err is None:
             cls.err = torch.zeros(16, dtype=torch.int32).pin_memory()
         cls.epoch = cls.epoch + 1 if cls.epoch < 0x7fffffff else 1
+        cls.dirty = True
         return fl, cls.err, cls.epoch
 
     @classmethod
@@ -377,39 +380,85 @@ class _ChainState:
         return cls.parts(n, h, w) > 0
 
 
+def guard_available(optim):
+    """The device-side guard of the chained launches' fail-safe exists for this optimiser: its flat gradient buffer
+    (with the fault slot behind the last tensor) is still what the parameters' .grad views point into."""
+    return optim is not None and getattr(optim, 'fault_slot', None) is not None and optim._is_flat()
+
+
 def stamp_fault(optim):
     """Before a network's gradient exchange / optimiser step: add 1 to the FAULT SLOT of its flat gradient
     buffer if a chained launch of this process has recorded a fault (a one-thread kernel reads the pinned
     counter).  The slot is all-reduced with the gradients and guards the Adam step on the device
-    (tg_adam_step_guarded): gradients built on stale tiles are then applied on NO rank."""
+    (tg_adam_step_guarded): gradients built on stale tiles are then applied on NO rank.
+
+    An optimiser WITHOUT that slot (`Adam(flatten=False)`, views replaced by `net.to()` / `p.grad = None`) has no
+    asynchronous guard: the step then falls back to the synchronous protocol ONCE -- wait for the device, look at the
+    counter (on every rank: one max-all-reduce of the flag), raise BEFORE the update is applied -- and every later
+    step runs one launch per layer, so the check is never needed again."""
     err = _ChainState.err
-    if err is not None and optim is not None and getattr(optim, 'fault_slot', None) is not None and optim._is_flat():
+    if err is None or optim is None:
+        return
+    if guard_available(optim):
         ops.fault_to_slot(err, optim.fault_slot)
+        return
+    if not _ChainState.dirty:
+        return
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    _ChainState.dirty = False
+    _ChainState.disabled = True
+    local = int(err[0]) != 0
+    anywhere = local
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from ..utils import dist_utils
+            anywhere = dist_utils.max_over_ranks(1.0 if local else 0.0, device=optim.params[0].device) != 0.0
+    except ImportError:
+        pass
+    if anywhere:
+        chain_check(0.0 if local else 1.0, counter=True)
 
 
-def chain_check(slot_value=0.0, counter=True):
+def chain_check(slot_value=0.0, counter=True, epoch=None):
     """Raises if a chained launch recorded a fault: on any rank in the iteration whose scalars are being looked at
     (`slot_value`: the fault slot of the generator's gradient buffer after its all-reduce, read with that iteration's
     scalars), or -- `counter`, for callers that have just synchronised the device -- on this rank since the last check
     (pinned counter).  The training step resolves its scalars asynchronously (base_model: a later iteration may
     already be in flight and adding to the counter), so it passes counter=False and relies on the slot, which is
     exact per iteration; the counter is cleared only after a device synchronisation.  The iteration's generator
-    update was dropped on every rank by the device-side guard; every later step runs one launch per layer."""
+    update was dropped on every rank by the device-side guard; every later step runs one launch per layer.
+
+    `epoch`: the chained-launch epoch at which the iteration was stamped.  An iteration that was already in flight
+    when an earlier one raised carries the same fault in its slot (the pinned counter is cleared only by the raise):
+    it is reported ONCE -- the call then returns True (update dropped, nothing raised).  Returns False when the
+    iteration is clean."""
     err = _ChainState.err
     local = counter and err is not None and int(err[0]) != 0
-    if local or slot_value != 0.0:
-        from .. import _lib as L
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()            # nothing in flight may add to the counter after it is cleared
-        lost = int(err[0]) if err is not None else 0
-        if err is not None:
-            err.zero_()
-        _ChainState.disabled = True
-        raise L.TecoganHipError(
-            'chained SRNet launch (training): %s timed out waiting for a neighbour tile; the results of this '
-            'step are INVALID and its optimiser step was DROPPED on every rank (weights and Adam moments '
-            'untouched).  Later steps run one launch per layer.'
-            % (f'{lost} workgroup(s) of this rank' if lost else 'workgroups of another rank'))
+    if not (local or slot_value != 0.0):
+        return False
+    if not local and epoch is not None and epoch <= _ChainState.reported_epoch:
+        return True
+    from .. import _lib as L
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()            # nothing in flight may add to the counter after it is cleared
+    lost = int(err[0]) if err is not None else 0
+    if err is not None:
+        err.zero_()
+    _ChainState.disabled = True
+    _ChainState.dirty = False
+    _ChainState.reported_epoch = _ChainState.epoch     # everything enqueued so far has completed (synchronised above)
+    raise L.TecoganHipError(
+        'chained SRNet launch (training): %s timed out waiting for a neighbour tile; the results of this '
+        'step are INVALID and its optimiser step was DROPPED on every rank (weights and Adam moments '
+        'untouched).  Later steps run one launch per layer.'
+        % (f'{lost} workgroup(s) of this rank' if lost else 'workgroups of another rank'))
+
+
+def chain_epoch():
+    """The epoch of the last chained launch enqueued by this process (see chain_check)."""
+    return _ChainState.epoch
 
 
 def srnet_body(tape, srnet, lr, tran):

@@ -63,9 +63,16 @@ class VSRModel(BaseModel):
         if getattr(self.optim_G, 'fault_slot', None) is not None:
             losses[2:3].copy_(self.optim_G.fault_slot)
         has_warp = self.warp_crit is not None
+        ep, optim_G = TG.chain_epoch(), self.optim_G
 
         def build(vals):                             # runs when the log is looked at (base_model: asynchronous scalars)
-            TG.chain_check(vals[2], counter=False)  # fail-safe of the chained launches: raises on EVERY rank, the update was dropped
+            try:                                     # fail-safe of the chained launches: raises on EVERY rank, the update was dropped
+                dropped = TG.chain_check(vals[2], counter=False, epoch=ep)
+            except Exception:
+                optim_G.undo_step_count()
+                raise
+            if dropped:                              # in flight behind an iteration that already raised
+                optim_G.undo_step_count()
             d = OrderedDict(l_pix_G=vals[0])
             if has_warp:
                 d['l_warp_G'] = vals[1]

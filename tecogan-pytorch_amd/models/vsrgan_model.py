@@ -121,7 +121,7 @@ class VSRGANModel(VSRModel):
             (fake_pred, _), _ = self.net_D(hr_data, d_in)        # no input grad: == hr_data.detach()
             n_clip = real_pred.numel()
 
-        scal = torch.zeros(15, dtype=torch.float32, device=self.device)   # every scalar of the step (+ the fault slot)
+        scal = torch.zeros(16, dtype=torch.float32, device=self.device)   # every scalar of the step (+ the fault slots of G [14] and D [15])
         st_real, st_fake, st_g, losses = scal[0:3], scal[3:6], scal[6:9], scal[9:14]
         red = self.gan_crit[1]
         lsgan = self.gan_crit[0] == 'LSGAN'        # LSGANLoss (losses.py:17-28) instead of VanillaGANLoss
@@ -209,6 +209,7 @@ class VSRGANModel(VSRModel):
         self.optim_G.step()
         if getattr(self.optim_G, 'fault_slot', None) is not None:
             scal[14:15].copy_(self.optim_G.fault_slot)
+        ep, optim_G, optim_D = TG.chain_epoch(), self.optim_G, self.optim_D
 
         # === logging: ONE asynchronous read of all scalars (base_model: resolved when the log is looked at) ===
         cnt_upd, adaptive = self.cnt_upd_D, update_policy == 'adaptive'
@@ -217,7 +218,17 @@ class VSRGANModel(VSRModel):
                    pp=self.pp_crit is not None, fm=self.fm_crit is not None)
 
         def build(sc_):
-            TG.chain_check(sc_[14], counter=False)  # fail-safe of the chained launches: raises on EVERY rank, G's update was dropped
+            def took_back():                        # the guard dropped these updates: their step counts do not advance
+                optim_G.undo_step_count()
+                if upd_D and sc_[15] != 0.0:
+                    optim_D.undo_step_count()
+            try:                                    # fail-safe of the chained launches: raises on EVERY rank, G's update was dropped
+                dropped = TG.chain_check(sc_[14], counter=False, epoch=ep)
+            except Exception:
+                took_back()
+                raise
+            if dropped:                             # in flight behind an iteration that already raised
+                took_back()
             sr, sf, sg, ls = sc_[0:3], sc_[3:6], sc_[6:9], sc_[9:14]
             d = OrderedDict()
             d['l_gan_D'] = (sr[0] + sf[0]) if upd_D else 0.0

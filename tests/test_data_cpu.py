@@ -172,3 +172,33 @@ def test_paired_dataset_refuses_mismatched_sets(tmp_path):
     opt = {'gt_seq_dir': gt_dir, 'lr_seq_dir': lr_dir, 'filter_file': None, 'data_type': 'rgb', 'gt_crop_size': 16}
     with pytest.raises(ValueError):            # the sets are 2x apart
         PairedLMDBDataset(opt, scale=4, tempo_extent=3)
+
+
+def test_paired_dataset_without_meta_info_lists_frame_keys_only(tmp_path):
+    """without meta_info.pkl the key list comes from the LMDB itself -- frame keys only (a bookkeeping
+    entry such as `__len__` is not a frame), the listing reader is closed, and the pairs match the meta_info form."""
+    from tecogan_pytorch_amd.data import LMDBWriter as W, PairedLMDBDataset
+    from tecogan_pytorch_amd.data import paired_lmdb_dataset as P
+    dirs = []
+    for name, frames in (('gt', F.all_frames()), ('lr', F.all_lr_frames())):
+        d = os.path.join(str(tmp_path), name)
+        os.makedirs(d)
+        items = {k: v.tobytes() for k, v in frames.items()}
+        items['__len__'] = b'%d' % len(frames)
+        W(d).write(items)
+        dirs.append(d)
+    closed = []
+    real_close = P.LMDBReader.close
+
+    def close(self):
+        closed.append(self)
+        return real_close(self)
+    P.LMDBReader.close = close
+    try:
+        keys = P._keys_of(dirs[0])
+    finally:
+        P.LMDBReader.close = real_close
+    assert len(closed) == 1 and keys == sorted(F.all_frames().keys())
+    ds = PairedLMDBDataset({'gt_seq_dir': dirs[0], 'lr_seq_dir': dirs[1], 'filter_file': None, 'data_type': 'rgb',
+                            'gt_crop_size': F.PAIRED_GT_CROP}, scale=F.PAIRED_SCALE, tempo_extent=F.TEMPO)
+    assert len(ds) == sum(n for _, n, _, _ in F.SEQS)

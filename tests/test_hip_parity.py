@@ -535,10 +535,19 @@ def test_resident_launch_fault_surfaces_and_falls_back(tmp_path):
         "ref_net, _ = fresh(False)\n"
         "ref = ref_net.infer_sequence(x, dev)\n"
         "net, plan = fresh(True)\n"
-        "assert raises(lambda: net.infer_sequence(x, dev)), 'no error on the host-output path'\n"
+        "assert raises(lambda: net.infer_sequence(x, dev, on_fault='raise')), 'no error on the host-output path'\n"
         "torch.cuda.synchronize()\n"
         "f, active = plan.chain_state(); assert f > 0 and not active, (f, active)\n"
         "assert np.array_equal(net.infer_sequence(x, dev), ref), 'fallback differs'\n"
+        "# the default (on_fault='rerun'): the caller gets the correct clip and a warning, not an error (ADVICE r4)\n"
+        "import warnings\n"
+        "net, plan = fresh(True)\n"
+        "with warnings.catch_warnings(record=True) as wl:\n"
+        "    warnings.simplefilter('always')\n"
+        "    y = net.infer_sequence(x, dev)\n"
+        "assert any('computed again' in str(w_.message) for w_ in wl), [str(w_.message) for w_ in wl]\n"
+        "assert np.array_equal(y, ref), 'rerun differs'\n"
+        "f, active = plan.chain_state(); assert f > 0 and not active, (f, active)\n"
         "net, plan = fresh(True)\n"
         "y = net.infer_sequence(x[:1], dev, return_device_tensor=True); torch.cuda.synchronize()\n"
         "assert raises(lambda: net.infer_sequence(x[:1], dev, return_device_tensor=True)), 'next call silent'\n"
@@ -584,7 +593,7 @@ def test_chained_launch_fault_surfaces_on_every_path(tmp_path):
         "    return go\n"
         "# (a) host-output exit (the entry check of a later frame's call may fire first: same error)\n"
         "net, plan = fresh(True)\n"
-        "assert raises(lambda: net.infer_sequence(x, dev)), 'a: no error on the host-output path'\n"
+        "assert raises(lambda: net.infer_sequence(x, dev, on_fault='raise')), 'a: no error on the host-output path'\n"
         "torch.cuda.synchronize()\n"
         "f, active = plan.chain_state(); assert f > 0 and not active, (f, active)\n"
         "assert np.array_equal(net.infer_sequence(x, dev), ref), 'a: fallback differs'\n"

@@ -228,6 +228,7 @@ def test_training_step_with_chain_fault_drops_the_update_and_raises():
         "assert not TG._ChainState.disabled and TG._ChainState.err is not None\n"
         "before = {k: v.detach().clone() for k, v in m.net_G.state_dict().items()}\n"
         "mom = [(a.clone(), b.clone()) for a, b in (m.optim_G.state[id(p)] for p in m.optim_G.params)]\n"
+        "steps0 = m.optim_G.steps\n"
         "TG._ChainState.poll_limit = -1               # every waiting workgroup gives up at once\n"
         "try:                                        # the fault surfaces with the scalars: at the end of train() or on the first look at the log\n"
         "    m.train(); m.sync_log(); raise SystemExit('no error reported')\n"
@@ -237,12 +238,53 @@ def test_training_step_with_chain_fault_drops_the_update_and_raises():
         "assert all(torch.equal(before[k], after[k]) for k in before), 'weights moved although the step faulted'\n"
         "assert all(torch.equal(a, c) and torch.equal(b, d) for (a, b), (c, d) in zip(mom, (m.optim_G.state[id(p)] for p in m.optim_G.params))), 'Adam moments moved'\n"
         "assert TG._ChainState.disabled\n"
+        "assert m.optim_G.steps == steps0, 'a dropped update advanced the bias-correction step count (ADVICE r4)'\n"
         "TG._ChainState.poll_limit = 1 << 21\n"
-        "m.train()                                   # one launch per layer from the unchanged weights\n"
+        "m.train(); m.sync_log()                     # one launch per layer from the unchanged weights; nothing left to report\n"
         "assert any(not torch.equal(before[k], v) for k, v in m.net_G.state_dict().items())\n"
+        "assert m.optim_G.steps == steps0 + 1\n"
         "print('DROP-OK')\n" % (root, os.path.join(root, 'tests', 'golden')))
     r = subprocess.run([sys.executable, '-c', script], timeout=900, capture_output=True, text=True)
     assert r.returncode == 0 and 'DROP-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_chain_fault_without_the_flat_gradient_buffer_raises_before_the_update():
+    """an optimiser whose .grad views were replaced (here: `p.grad = None`, as after `net.to()`)
+    has no fault slot, so the asynchronous guard cannot drop the update.  The step must then fall back to the
+    synchronous protocol: the fault raises INSIDE train(), before the optimiser step, the weights stay untouched and
+    later steps run one launch per layer."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from tests.test_hip_train import make_opt\n"
+        "from procedural_weights import smooth_clip, generator_state_dict\n"
+        "from tecogan_pytorch_amd.models import define_model, train_graph as TG\n"
+        "from tecogan_pytorch_amd import _lib\n"
+        "opt = make_opt('FRVSR'); opt['dataset']['train']['crop_size'] = 128\n"
+        "m = define_model(opt)\n"
+        "m.net_G.load_state_dict(generator_state_dict(scale=4, degradation='BD'), strict=True)\n"
+        "m.prepare_training_data({'gt': torch.stack([smooth_clip(4, 3, 136, 136, seed=11 + i, shift=1.0) for i in range(2)])})\n"
+        "m.train(); m.sync_log()\n"
+        "assert TG.guard_available(m.optim_G)\n"
+        "for p in m.net_G.parameters(): p.grad = None        # the views into the flat gradient buffer are gone\n"
+        "assert not TG.guard_available(m.optim_G)\n"
+        "before = {k: v.detach().clone() for k, v in m.net_G.state_dict().items()}\n"
+        "TG._ChainState.poll_limit = -1\n"
+        "try:\n"
+        "    m.train(); raise SystemExit('train() returned although the chained body faulted and no guard exists')\n"
+        "except _lib.TecoganHipError as e:\n"
+        "    assert 'timed out' in str(e), str(e)\n"
+        "torch.cuda.synchronize()\n"
+        "assert all(torch.equal(before[k], v) for k, v in m.net_G.state_dict().items()), 'weights moved'\n"
+        "assert TG._ChainState.disabled and not TG._ChainState.dirty\n"
+        "TG._ChainState.poll_limit = 1 << 21\n"
+        "m.train(); m.sync_log()\n"
+        "assert any(not torch.equal(before[k], v) for k, v in m.net_G.state_dict().items())\n"
+        "print('NOSLOT-OK')\n" % (root, os.path.join(root, 'tests', 'golden')))
+    r = subprocess.run([sys.executable, '-c', script], timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0 and 'NOSLOT-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_deep_body_runs_without_the_chained_launch():

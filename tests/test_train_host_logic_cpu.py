@@ -3,6 +3,7 @@ space-to-depth weight embeddings that let the transposed convs and the
 discriminator's 4x4/stride-2 convs reuse the 3x3/stride-1 MFMA kernels
 (models/train_graph.py), verified against torch's own convs."""
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -94,3 +95,57 @@ def test_adam_state_dict_round_trip():
         Adam(qs[:1], lr=1.0).load_state_dict(sd)
     with pytest.raises(ValueError):
         Adam([torch.nn.Parameter(torch.zeros(4, 3)), qs[1]], lr=1.0).load_state_dict(sd)
+
+
+def test_chain_check_reports_a_fault_once_and_flags_the_iterations_behind_it():
+    """iteration k + 1 is already stamped when iteration k's fault is raised; its later resolve must not
+    raise a second time with a misleading text -- chain_check(epoch=...) returns True (update dropped, already
+    reported) for every iteration stamped up to the epoch the raise covered."""
+    import torch
+    from tecogan_pytorch_amd import _lib
+    from tecogan_pytorch_amd.models import train_graph as TG
+    S = TG._ChainState
+    saved = (S.err, S.epoch, S.disabled, S.dirty, S.reported_epoch)
+    try:
+        S.err, S.epoch, S.disabled, S.dirty, S.reported_epoch = torch.zeros(16, dtype=torch.int32), 7, False, True, 0
+        assert TG.chain_check(0.0, counter=False, epoch=6) is False            # clean iteration
+        with pytest.raises(_lib.TecoganHipError, match='another rank'):
+            TG.chain_check(1.0, counter=False, epoch=6)                         # iteration k: raises, covers epochs <= 7
+        assert S.disabled and not S.dirty and S.reported_epoch == 7
+        assert TG.chain_check(1.0, counter=False, epoch=7) is True              # iteration k + 1: dropped, not raised again
+        S.epoch = 9
+        with pytest.raises(_lib.TecoganHipError):
+            TG.chain_check(1.0, counter=False, epoch=9)                         # a NEW fault still raises
+        S.err[0] = 3
+        with pytest.raises(_lib.TecoganHipError, match='3 workgroup'):
+            TG.chain_check(0.0, counter=True)                                   # the synchronous form reads the counter
+        assert int(S.err[0]) == 0
+    finally:
+        S.err, S.epoch, S.disabled, S.dirty, S.reported_epoch = saved
+
+
+def test_log_queue_keeps_the_entries_behind_a_faulting_one():
+    """_drain_log_queue resolves one entry at a time; an entry whose checks raise is consumed, the entries
+    behind it stay queued (with their pinned buffers) for the next call."""
+    import torch
+    from collections import OrderedDict
+    from tecogan_pytorch_amd.models.base_model import BaseModel
+
+    class Ev:
+        def query(self): return True
+        def synchronize(self): pass
+    m = BaseModel.__new__(BaseModel)
+    m._log_queue, m._log_pinned, m._pending_log = [], [], None
+    m._log_dict, m.running_log_dict, m.log_decay = OrderedDict(), OrderedDict(), 0.5
+
+    def ok(v):
+        return OrderedDict(x=v[0])
+
+    def bad(v):
+        raise RuntimeError('fault')
+    m._log_queue = [(Ev(), torch.tensor([1.0]), ok), (Ev(), torch.tensor([2.0]), bad), (Ev(), torch.tensor([3.0]), ok)]
+    with pytest.raises(RuntimeError, match='fault'):
+        m._drain_log_queue()
+    assert len(m._log_queue) == 1 and m.running_log_dict['x'] == 1.0
+    m._drain_log_queue()
+    assert not m._log_queue and m.running_log_dict['x'] == 2.0 and len(m._log_pinned) == 3
