@@ -507,6 +507,7 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
 
     out = {}
     m, dt, nupd = run(128, args.train_steps)
+    from tecogan_pytorch_amd.utils import dist_utils as DU
     if dist_on:
         # readiness checks of the first real multi-GPU run: every rank must see the world the driver asked for
         seen = dist.get_world_size()
@@ -515,7 +516,19 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
         out['process_group'] = {'world_seen_by_rank0': seen, 'backend': dist.get_backend(),
                                 'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version())
                                 if dist.get_backend() == 'nccl' else None,
-                                'transport': os.environ.get('TECOGAN_COMM', 'torch.distributed')}
+                                'transport': os.environ.get('TECOGAN_COMM', 'torch.distributed'),
+                                # what every rank compared at model construction (BaseModel.check_ranks_agree: one
+                                # all-gather; a mixed build refuses to start instead of hanging in the first bucket)
+                                'agreement_vector': m.agreement_vector(),
+                                'agreement_vector_is': '[tg_version, chained-launch parts at the training shape, '
+                                                       'pair_pass, c_abi transport, G bucket floats, D bucket floats]'}
+        if os.environ.get('TECOGAN_COMM', '') == 'c_abi':
+            import ctypes
+            from tecogan_pytorch_amd import _lib as L_
+            seen_c, rank_c = ctypes.c_int(-1), ctypes.c_int(-1)
+            if L_.lib().tg_comm_query(DU._c_comm(), ctypes.byref(seen_c), ctypes.byref(rank_c)) == 0:
+                out['process_group']['ranks_seen'] = seen_c.value          # ncclCommCount: RCCL's own answer
+                assert seen_c.value == world and rank_c.value == rank, (seen_c.value, rank_c.value, world, rank)
         cps = getattr(m, 'comm_per_step', {})
         out['rccl_comm_count'] = {
             'all_reduce_per_step': cps.get('all_reduce'), 'all_gather_per_step': cps.get('all_gather'),

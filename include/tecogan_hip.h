@@ -736,6 +736,10 @@ int tg_comm_init_rank(const uint8_t id[TG_COMM_ID_BYTES], int world, int rank, t
 int tg_comm_destroy(tg_comm* comm);
 int tg_comm_world(const tg_comm* comm);
 int tg_comm_rank(const tg_comm* comm);
+/* what RCCL ITSELF reports for the communicator (ncclCommCount, ncclCommUserRank) -- the reference reads the same from
+ * torch.distributed (dist.get_world_size() / get_rank(), utils/dist_utils.py:27-34); a launcher / library mismatch shows
+ * here before the first collective.  TG_E_HIP when the bound librccl lacks the two queries. */
+int tg_comm_query(const tg_comm* comm, int* ranks_seen, int* rank_seen);
 const char* tg_comm_library_origin(void); /* which librccl was bound ("" = none yet) */
 /* in-place SUM over ranks (flat gradient bucket: 10.4 MB G / 3.3 MB D; BN backward sums) */
 int tg_allreduce_sum_f32(tg_comm* comm, float* buf, int64_t count, tg_stream_t stream);

@@ -174,6 +174,7 @@ SIGNATURES = {
     'tg_comm_destroy': (I, [P]),
     'tg_comm_world': (I, [P]),
     'tg_comm_rank': (I, [P]),
+    'tg_comm_query': (I, [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'tg_comm_library_origin': (C.c_char_p, []),
     'tg_allreduce_sum_f32': (I, [P, P, I64, P]),
     'tg_allgather_f32': (I, [P, P, P, I64, P]),

@@ -33,6 +33,8 @@ struct Rccl {
   int (*AllReduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, rccl_comm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(rccl_comm_t, int*) = nullptr;        // optional: what the LIBRARY says the communicator spans
+  int (*CommUserRank)(rccl_comm_t, int*) = nullptr;     // optional
   const char* origin = "";
 };
 
@@ -55,6 +57,8 @@ Rccl* rccl() {
   r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
   r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+  r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+  r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
   if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.AllGather) {
     r.handle = nullptr;
     return nullptr;
@@ -114,6 +118,18 @@ extern "C" int tg_comm_destroy(tg_comm* c) {
   int rc = r ? r->CommDestroy(c->comm) : 0;
   delete c;
   return rc == 0 ? TG_OK : rccl_fail("ncclCommDestroy", rc);
+}
+
+// What RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank) -- NOT the numbers the caller passed
+// to tg_comm_init_rank: the first multi-GPU run checks that the library agrees with the launcher (bench.py: ranks_seen).
+extern "C" int tg_comm_query(const tg_comm* c, int* ranks_seen, int* rank_seen) {
+  TG_REQUIRE(c && ranks_seen && rank_seen, TG_E_ARG, "comm_query: null pointer");
+  TG_NEED_RCCL(r);
+  TG_REQUIRE(r->CommCount && r->CommUserRank, TG_E_HIP, "comm_query: this librccl has no ncclCommCount / ncclCommUserRank");
+  int rc = r->CommCount(c->comm, ranks_seen);
+  if (rc != 0) return rccl_fail("ncclCommCount", rc);
+  rc = r->CommUserRank(c->comm, rank_seen);
+  return rc == 0 ? TG_OK : rccl_fail("ncclCommUserRank", rc);
 }
 
 extern "C" int tg_comm_world(const tg_comm* c) { return c ? c->world : 0; }

@@ -27,6 +27,31 @@ class BaseModel:
             self.log_decay = opt['logger'].get('decay', 0.99)
             self.running_log_dict = OrderedDict()
 
+    def agreement_vector(self):
+        """What every rank of a data-parallel run must have in common for the step's exchange pattern to match: the
+        library's ABI / build number, whether the chained body launches are available on this device for the training
+        frames (they decide whether a fault slot is stamped), the critic's pair pass (19 vs 27 collectives per step),
+        the flat gradient buckets' sizes, the gradient transport."""
+        import os
+        from .. import _lib as L
+        from . import train_graph as TG
+        crop = int(self.opt.get('dataset', {}).get('train', {}).get('crop_size', 0) or 0)
+        lr = crop // max(1, self.scale)
+        chain = -1
+        if self.device.type == 'cuda' and lr > 0:
+            chain = 0 if TG._ChainState.disabled else int(TG._ChainState.parts(2, lr, lr))
+        flat = [int(o.flat_grad.numel()) if getattr(o, 'flat_grad', None) is not None else -1
+                for o in (getattr(self, 'optim_G', None), getattr(self, 'optim_D', None)) if o is not None]
+        return [int(L.lib().tg_version()), chain, int(bool(getattr(self, 'pair_pass', False))),
+                int(os.environ.get('TECOGAN_COMM', '') == 'c_abi')] + flat
+
+    def check_ranks_agree(self):
+        """One small all-gather at construction (dist_utils.assert_ranks_agree): a mixed build cannot deadlock the first
+        gradient bucket."""
+        if self.dist:
+            dist_utils.assert_ranks_agree(self.agreement_vector(), 'library version / chained-launch capability / '
+                                          'pair_pass / transport / gradient-bucket sizes', device=self.device)
+
     # -- data ---------------------------------------------------------------
     def _blur_weight(self, sigma, c):
         """create_kernel (data_utils.py:11-27) as the (c, c, 9, 9) block-diagonal tensor."""

@@ -18,6 +18,7 @@ class VSRModel(BaseModel):
         if self.is_train:
             self.set_criterions()
             self.set_optimizers()
+            self.check_ranks_agree()
 
     def set_networks(self):
         self.net_G = self.model_to_device(define_generator(self.opt))

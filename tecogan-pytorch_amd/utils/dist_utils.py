@@ -58,6 +58,30 @@ def max_over_ranks(value, device='cpu'):
     return t.item()
 
 
+def assert_ranks_agree(values, what, device='cpu'):
+    """Every rank passes the same small vector of INTEGERS (library version, kernel capabilities, option switches);
+    ONE all-gather compares them and every rank raises the same error when they differ.  The training step's exchange
+    pattern depends on these (a rank that pairs D's real / fake pass issues 19 collectives per step, one that does not
+    issues 27; a rank whose chained launches are unavailable stamps no fault slot): a mixed build would otherwise
+    surface as a hang inside the first gradient bucket.  Reference: DDP checks parameter shapes across ranks at
+    construction (base_model.py:130-136 wraps with DistributedDataParallel, which verifies them)."""
+    rank, world = get_dist_info()
+    vals = [int(v) for v in values]
+    if world == 1:
+        return vals
+    t = torch.tensor(vals, dtype=torch.int64, device=device)
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        t = t.cpu()
+    got = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(got, t)
+    rows = [g.tolist() for g in got]
+    if any(r != rows[0] for r in rows):
+        bad = {i: r for i, r in enumerate(rows) if r != rows[0]}
+        raise RuntimeError(f'ranks disagree on {what}: rank 0 has {rows[0]}, differing ranks {bad} -- '
+                           f'a mixed build / environment; refusing to start (the exchange patterns would not match)')
+    return vals
+
+
 def reduce_sum_to_master(values, device='cpu'):
     """Per-sequence metric vectors: SUM-reduce to rank 0 (each sequence is
     non-zero on exactly one rank), metric_calculator.py:68-117."""

@@ -1,4 +1,4 @@
-/* A stand-in for librccl.so used ONLY by tests/test_comm_stub_cpu.py: the six nccl* entry points
+/* A stand-in for librccl.so used ONLY by tests/test_comm_stub_cpu.py: the nccl* entry points the library binds
  * libtecogan_hip.so binds with dlopen (csrc/tg_comm.hip), implemented over POSIX shared memory for
  * HOST buffers, so that the id exchange / init order / collective semantics of tg_comm_* can run
  * with world sizes 2 and 8 in a container that has no GPU.  Not a product file; never shipped. */
@@ -111,6 +111,20 @@ int ncclAllGather(const void* send, void* recv, size_t count, int dtype, void* c
     for (int k = 0; k < c->world; ++k) memcpy(r + (size_t)k * count + o, c->sh->slot[k], n * sizeof(float));
     barrier(c);
   }
+  return 0;
+}
+
+int ncclCommCount(void* comm, int* count) {
+  comm_t* c = (comm_t*)comm;
+  if (!c || !count) return 4;
+  *count = c->sh->world;                            /* what rank 0 registered, not what this rank asked for */
+  return 0;
+}
+
+int ncclCommUserRank(void* comm, int* rank) {
+  comm_t* c = (comm_t*)comm;
+  if (!c || !rank) return 4;
+  *rank = c->rank;
   return 0;
 }
 

@@ -42,6 +42,9 @@ WORKER = textwrap.dedent('''
     check(lib.tg_comm_init_rank(ident, world, rank, ctypes.byref(comm)), 'init_rank')
     assert 'librccl' in lib.tg_comm_library_origin().decode()
     assert lib.tg_comm_world(comm) == world and lib.tg_comm_rank(comm) == rank
+    seen, me = ctypes.c_int(-1), ctypes.c_int(-1)
+    check(lib.tg_comm_query(comm, ctypes.byref(seen), ctypes.byref(me)), 'comm_query')     # what the LIBRARY reports
+    assert (seen.value, me.value) == (world, rank), (seen.value, me.value)
     lib.tg_allreduce_sum_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     lib.tg_allgather_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     n = 200003                                                   # > one 64 Ki chunk of the stub, odd

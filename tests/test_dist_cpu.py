@@ -39,7 +39,14 @@ def _worker(rank, world, port, num_seq, out):
     gsum = [g.tolist() for g in grads]
     calls = []
     D.master_only(lambda: calls.append(rank))()
-    out[rank] = (mine, red.tolist(), tmax, calls, gsum)
+    # start-up agreement: identical vectors pass, a differing rank makes EVERY rank raise
+    agree = D.assert_ranks_agree([101, 4, 1, 0, 2589440, 819648], 'test vector') == [101, 4, 1, 0, 2589440, 819648]
+    try:
+        D.assert_ranks_agree([101, 4 if rank == 0 else 0, 1], 'chain capability')
+        mismatch = 'not raised'
+    except RuntimeError as e:
+        mismatch = str(e)
+    out[rank] = (mine, red.tolist(), tmax, calls, gsum, agree, mismatch)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -59,6 +66,26 @@ def test_two_rank_sharding_and_reductions():
     assert a[3] == [0] and b[3] == []                           # master_only
     expect = [[[0.0, 1.5, 3.0], [4.5, 6.0, 7.5]], [1.5] * 5, [6.0]]
     assert a[4] == expect and b[4] == expect                    # flat-bucket mean, shapes kept
+    assert a[5] and b[5]
+    for m in (a[6], b[6]):                                      # both ranks refuse, naming the differing rank
+        assert 'ranks disagree on chain capability' in m and '{1: [101, 0, 1]}' in m, m
+
+
+def test_gradient_bucket_sizes_are_the_documented_ones():
+    """The flat gradient buckets the data-parallel step all-reduces (10.36 MB G,
+    3.28 MB D): the Adam layout's arithmetic (64-float alignment per tensor + one block holding the fault slot) on the
+    shipped TecoGAN networks -- what `bench.py --gpus N` prints as allreduce_G / allreduce_D bytes."""
+    from tecogan_pytorch_amd.models.networks import FRNet, SpatioTemporalDiscriminator
+    from tecogan_pytorch_amd.models.optim import Adam
+
+    def bucket_bytes(net):
+        tot = sum((p.numel() + Adam.ALIGN - 1) // Adam.ALIGN * Adam.ALIGN for p in net.parameters())
+        return 4 * (tot + Adam.ALIGN)
+    g = FRNet(3, 3, 64, 10, 'BD', 4)
+    d = SpatioTemporalDiscriminator(3, 128, 3, 'BD', 4)
+    assert sum(p.numel() for p in g.parameters()) == 1745506 + 843587       # SURVEY.md G9: FNet + SRNet
+    assert bucket_bytes(g) == 10357504, bucket_bytes(g)
+    assert bucket_bytes(d) == 3278336, bucket_bytes(d)
 
 
 def test_single_process_defaults():

@@ -15,6 +15,7 @@
 Tolerances are stated per assertion (fp32 everywhere; the differences are
 summation order, compounded through the recurrence)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -23,6 +24,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN_DIR = os.path.join(ROOT_DIR, 'tests', 'golden')
 
 from oracle import tecogan_oracle as O
 from procedural_weights import generator_state_dict, discriminator_state_dict, smooth_clip
@@ -168,7 +170,17 @@ def _train_opt(crop, tempo, thr):
     }
 
 
-TOL_G, TOL_D = 1e-2, 1e-2      # relative L2 of a watched gradient against the oracle autograd; measured (round 4, gpurun_out/train_grad_rel_l2_crop*.json): G <= 4.7e-3 (crop 256), D <= 8.4e-3 (crop 128)
+# Relative L2 of a watched gradient.  Round 5: the bound is no longer a number picked above the
+# worst value seen (round 4: 1e-2 against a measured 9.95e-3) but a TRIANGULATION against the same step evaluated in
+# float64 (tests/golden/train_fp64_grads.npz, written by tests/golden/make_golden_fp64_grads.py from the oracle on the
+# same seeded inputs): the oracle's own fp32 autograd is 5.4e-3 .. 7.3e-3 away from the fp64 gradients of the critic
+# at crop 128 (1e-3 .. 4e-3 at crop 256) and 0.3e-3 .. 1.6e-3 for the generator -- a 19-frame BPTT and four
+# BatchNorm layers whose real / fake halves nearly cancel at initialisation are that ill-conditioned in fp32 --
+# so two fp32 evaluations legitimately differ by up to the sum of their errors.  What is asserted:
+#   ||HIP - fp64|| <= FP64_FACTOR * ||oracle-fp32 - fp64|| + FP64_FLOOR      (the HIP backward is as good an fp32
+#                                                                            evaluation as ATen's)
+#   ||HIP - oracle-fp32|| <= ||HIP - fp64|| + ||oracle-fp32 - fp64|| + 1e-6   (consistency of the three)
+FP64_FACTOR, FP64_FLOOR = 2.0, 2e-4
 
 
 def _rel_l2(a, b):
@@ -212,18 +224,35 @@ def test_fullsize_tecogan_train_step_vs_oracle(crop, tag):
         assert abs(log[k] - v) <= rtol * abs(v) + atol, (tag, k, log[k], v)
     eG = {k: _rel_l2(gG[k], rG[k]) for k in WATCH_G}
     eD = {k: _rel_l2(gD[k], rD[k]) for k in WATCH_D}
-    try:      # the measured values, for the record (DESIGN.md section 5 quotes them; bounds = ~2x the worst seen)
+    # fp64 triangulation (see FP64_FACTOR above)
+    if GOLDEN_DIR not in sys.path:
+        sys.path.insert(0, GOLDEN_DIR)
+    from make_golden_fp64_grads import pick
+    g64 = np.load(os.path.join(GOLDEN_DIR, 'train_fp64_grads.npz'))
+
+    def vs64(t, key):
+        a = t.detach().double().cpu().reshape(-1).numpy()
+        b = g64[key].astype(np.float64)
+        return float(np.linalg.norm(a[pick(a.size)] - b) / np.linalg.norm(b))
+    hip64 = {'G': {k: vs64(gG[k], 'c%d_G_%s' % (crop, k)) for k in WATCH_G},
+             'D': {k: vs64(gD[k], 'c%d_D_%s' % (crop, k)) for k in WATCH_D}}
+    ora64 = {'G': {k: vs64(rG[k], 'c%d_G_%s' % (crop, k)) for k in WATCH_G},
+             'D': {k: vs64(rD[k], 'c%d_D_%s' % (crop, k)) for k in WATCH_D}}
+    try:      # the measured values, for the record (DESIGN.md section 5 quotes them)
         import json
         out = os.path.join(ROOT_DIR, 'gpurun_out')
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, 'train_grad_rel_l2_crop%d.json' % crop), 'w') as f:
-            json.dump({'gradG': eG, 'gradD': eD}, f, indent=1)
+            json.dump({'hip_vs_oracle_fp32': {'G': eG, 'D': eD}, 'hip_vs_fp64': hip64, 'oracle_fp32_vs_fp64': ora64,
+                       'note': 'relative L2 of the watched gradients; fp64 = oracle/tecogan_oracle.py::vsrgan_train_step '
+                               'in float64 on the same inputs (tests/golden/train_fp64_grads.npz)'}, f, indent=1)
     except OSError:
         pass
-    for k in WATCH_G:
-        assert eG[k] <= TOL_G, (tag, 'gradG', k, eG[k])
-    for k in WATCH_D:
-        assert eD[k] <= TOL_D, (tag, 'gradD', k, eD[k])
+    for net, names, e32 in (('G', WATCH_G, eG), ('D', WATCH_D, eD)):
+        for k in names:
+            h, o = hip64[net][k], ora64[net][k]
+            assert h <= FP64_FACTOR * o + FP64_FLOOR, (tag, 'grad' + net, k, 'HIP vs fp64', h, 'oracle-fp32 vs fp64', o)
+            assert e32[k] <= h + o + 1e-6, (tag, 'grad' + net, k, e32[k], h, o)
     # BatchNorm running statistics after the iteration's three D passes.  The third pass runs
     # AFTER D's Adam step (every weight moved by lr * sign(g); weights whose summed gradient is
     # ~0 flip sign under fp32 re-association), so 0.1 x its batch statistics carry that
