@@ -276,6 +276,38 @@ def _aten_step(O, sd, lr_curr, lr_prev, hr_prev, scale, deg):
     return out + up(lr_curr)
 
 
+def copy_ceiling(dev, nbytes, blocks, threads, rotate_bytes=0, reps=48):
+    """A float4 copy of `nbytes` (read once + written once = 2 nbytes of traffic) with the warp launch's own grid
+    (tg_copy_ceiling): what a plain streaming kernel of that size reaches on this GPU.  rotate_bytes > 0: the launches
+    rotate over enough buffer pairs that none finds its input in L2 / Infinity Cache (the batched warp line's protocol);
+    0: one buffer pair, re-used back to back (the one-frame line's protocol: the previous frame was written a moment
+    ago and is read from the caches)."""
+    from tecogan_pytorch_amd import _lib as L
+    from tecogan_pytorch_amd import ops
+    nbytes = int(nbytes) // 16 * 16
+    npair = max(1, int(rotate_bytes // (2 * nbytes)) + 1) if rotate_bytes else 1
+    bufs = [(torch.rand(nbytes // 4, device=dev), torch.empty(nbytes // 4, device=dev)) for _ in range(npair)]
+    lib = L.lib()
+
+    def go(i):
+        a, b = bufs[i % npair]
+        L.check(lib.tg_copy_ceiling(a.data_ptr(), b.data_ptr(), nbytes, blocks, threads, ops._stream()), 'tg_copy_ceiling')
+    for i in range(npair + 2):
+        go(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(reps):
+        go(i)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    return {'GBps': 2 * nbytes / us * 1e-3, 'avg_launch_us': us, 'bytes_read_plus_written': 2 * nbytes,
+            'grid': [blocks, threads], 'buffer_pairs': npair,
+            'what': 'float4 grid-stride copy, same grid as the warp launch, back-to-back launches between HIP events '
+                    '(so a launch boundary is inside each sample, as in the batched warp line)'}
+
+
 def warp_batched_roofline(dev, h, w, scale, deg, clips=8, reps=48):
     """The fused flow-upsample + warp + space_to_depth kernel on `clips` independent clips
     in one launch (the serving configuration: one frame step of `clips` streams).  At n=1
@@ -315,8 +347,13 @@ def warp_batched_roofline(dev, h, w, scale, deg, clips=8, reps=48):
     # algorithmic bytes: read HR frame once + LR flow once, write the s2d tensor once
     mbytes = per_set / 1e6
     gbs = mbytes / us * 1e3
+    nseg = -(-scale * w // 256)
+    tiles = nseg * h * clips                       # the launcher's grid: one block per (LR row, 256-column segment, clip)
+    cc = copy_ceiling(dev, per_set // 2, tiles, 256 if tiles > 2048 and scale == 4 else (512 if scale == 4 else 256),
+                      rotate_bytes=600e6, reps=reps)
     return {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': gbs / HBM_PEAK_GBS, 'traffic': None, 'clips_per_launch': clips,
+            'frac': gbs / HBM_PEAK_GBS, 'copy_ceiling': cc, 'frac_of_copy_ceiling': gbs / cc['GBps'],
+            'traffic': None, 'clips_per_launch': clips,
             'avg_launch_us': us, 'algorithmic_mbytes_per_launch': mbytes,
             'flow': 'camera motion: pan +-4 HR px, zoom +-1 %, roll +-0.005 rad, per clip',
             'note': 'back-to-back launches on one stream over %d rotating buffer sets, HIP '
@@ -884,6 +921,11 @@ def main():
                     'traffic_source': 'profiles/pmc_traffic.json (committed PMC passes); NOT measured in this run',
                     'kernel': wk['kernel'], 'avg_launch_us': 1e3 * wk['ms_per_frame'],
                     'algorithmic_mbytes_per_launch': wk['mbytes']}
+                # what a plain copy of the same bytes with the same grid reaches (back-to-back launches between two events,
+                # exactly how the kernel table times the warp launch: a launch boundary is inside every sample of both)
+                cc1 = copy_ceiling(dev, int(wk['mbytes'] * 1e6) // 2, -(-s * w // 256) * h, 512 if s == 4 else 256)
+                result['roofline_warp']['copy_ceiling'] = cc1
+                result['roofline_warp']['frac_of_copy_ceiling'] = wk['gbs'] / cc1['GBps']
                 result['roofline_warp_batched'] = warp_batched_roofline(
                     dev, h, w, s, deg)
             result['kernels'] = rows

@@ -431,6 +431,10 @@ int tg_flowup_warp_s2d_fwd(const float* lr_flow, int fh, int fw,
                            int64_t out_nstride, float* hr_flow_out, int n,
                            int c, int h, int w, int scale, int up_mode,
                            tg_stream_t stream);
+/* Measurement aid (bench.py roofline_warp*.copy_ceiling; no counterpart in the reference): a float4 grid-stride copy of
+ * `bytes` (read once, written once) launched with the given grid -- the fused warp kernel's own -- so that its HBM
+ * fraction can also be read against what a plain copy of the same size reaches on this part. */
+int tg_copy_ceiling(const void* src, void* dst, int64_t bytes, int blocks, int threads, tg_stream_t stream);
 
 /* backward_warp(x, flow): codes/utils/net_utils.py:50-82 (grid_sample bilinear,
  * border, align_corners=True; flow ch0 = x, ch1 = y, in pixels). */

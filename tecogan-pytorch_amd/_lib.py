@@ -80,6 +80,7 @@ SIGNATURES = {
     'tg_conv3x3_small_fwd_u8': (I, [P, I64, P, P, P, I, I, P, I64, P, I, I, I, I, I, I, P]),
     'tg_conv3x3_small_can_fuse_u8': (I, [P, I64, P, I64, I, I, I, I]),
     'tg_flowup_warp_s2d_fwd': (I, [P, I, I, P, P, I64, P, I, I, I, I, I, I, P]),
+    'tg_copy_ceiling': (I, [P, P, I64, I, I, P]),
     'tg_backward_warp_fwd': (I, [P, P, P, I, I, I, I, P]),
     'tg_space_to_depth': (I, [P, P, I64, I, I, I, I, I, P]),
     'tg_upsample_fwd': (I, [P, P, I, I, I, I, I, F, P]),

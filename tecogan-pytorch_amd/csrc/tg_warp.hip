@@ -115,7 +115,11 @@ __device__ __forceinline__ float warp_coord_c(int i, int n, float flow, float st
 #define TG_WARP_ABL 0   // lab only (tools/warp_lab.py): 1 no stores, 2 one tap row instead of two, 4 no flow loads
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int S, int C, int R, int RPT>
+#ifndef TG_WARP_PF
+#define TG_WARP_PF 0    // 1: speculative touch of the previous frame under the flow loads for one-frame launches (see PF below);
+                        // measured +-0 on MI355X (6.3 - 7.8 us per launch with and without, round 5): off
+#endif
+template <int S, int C, int R, int RPT, int PF = 0>
 __global__ __launch_bounds__(128 * (R / RPT)) void flowup_warp_s2d_kernel(FusedArgs a) {
   constexpr int SEG = 256;
   constexpr int NT = 128 * (R / RPT);      // threads: 128 pixel pairs x R/RPT row groups
@@ -158,6 +162,23 @@ __global__ __launch_bounds__(128 * (R / RPT)) void flowup_warp_s2d_kernel(FusedA
   const bool bicubic = a.up_mode == TG_UP_BICUBIC;
   const bool vec_out = (a.w & 3) == 0 && a.out_aligned;   // dwordx4 stores need 16-byte rows
 
+  // PF (round 5, one-frame launches: every block is resident at once and the kernel's duration is ONE block's chain
+  // of dependent round trips -- flow patch, gathers, stores).  The gathers cannot start before the flow is known, but
+  // the flow only moves a sample by a few pixels: the 16 bytes at the thread's OWN position are requested at once, so
+  // the previous frame's lines travel towards this CU's L2 / L1 while the flow patch is in flight and the real gathers
+  // find them there.  The values are never used (the asm at the end only keeps the loads alive).
+  // (requested BEHIND the flow loads: vmcnt retires in order, so the flow patch must not queue behind them)
+  f32x4 pf[C];
+  auto issue_pf = [&]() {
+    if constexpr (PF != 0) {
+      const int ptp = t & 127, pr = (t >> 7) * RPT;
+      const unsigned po = ((unsigned)(hy0 + pr) * (unsigned)WW + (unsigned)(x0 + 2 * ptp)) * 4u;
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch)
+        pf[ch] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ri, (int)po, (int)(ch * hrhw * 4u), 0));
+    }
+  };
+
   // ---- 1. LR-flow terms
   if (bicubic) {
     {   // every load of the patch is issued before the first LDS store: a loop of load -> store
@@ -172,6 +193,7 @@ __global__ __launch_bounds__(128 * (R / RPT)) void flowup_warp_s2d_kernel(FusedA
         const unsigned o = ((unsigned)reflect_src(clampi(oy - 1 + p, 0, a.h - 1), a.fh) * a.fw + cc) * 4u;
         fv[i] = (it < 2 * 4 * NV && !(TG_WARP_ABL & 4)) ? bload(rf, o, (ch & 1) * fhw * 4u) : 0.01f;
       }
+      issue_pf();
 #pragma unroll
       for (int i = 0; i < FPT; ++i) {
         const int it = t + i * NT;
@@ -212,6 +234,7 @@ __global__ __launch_bounds__(128 * (R / RPT)) void flowup_warp_s2d_kernel(FusedA
         b1[i] = make_float2(bload(rf, o1, 0), bload(rf, o1, fhw * 4u));
       }
     }
+    issue_pf();
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
       const int it = t + i * NT;
@@ -337,6 +360,10 @@ __global__ __launch_bounds__(128 * (R / RPT)) void flowup_warp_s2d_kernel(FusedA
     }
   }
   __syncthreads();
+  if constexpr (PF != 0) {
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) asm volatile("" ::"v"(pf[ch]));
+  }
 
   // ---- 3. space_to_depth: staged as s_out[(r, sx, ch)][ox]
   if (vec_out) {
@@ -653,11 +680,29 @@ extern "C" int tg_flowup_warp_s2d_fwd(const float* lr_flow, int fh, int fw, cons
   const int rpt = rpt_env ? rpt_env : (tiles <= 2048 ? 1 : 2);
   if (scale == 4) {
     if (rpt == 2) hipLaunchKernelGGL((flowup_warp_s2d_kernel<4, 3, 4, 2>), dim3(tiles), dim3(256), 0, s, a);
+    else if (TG_WARP_PF) hipLaunchKernelGGL((flowup_warp_s2d_kernel<4, 3, 4, 1, 1>), dim3(tiles), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((flowup_warp_s2d_kernel<4, 3, 4, 1>), dim3(tiles), dim3(512), 0, s, a);
   } else {
     hipLaunchKernelGGL((flowup_warp_s2d_kernel<2, 3, 2, 1>), dim3(tiles), dim3(256), 0, s, a);
   }
   return check_launch("flowup_warp_s2d");
+}
+
+// Same-bytes copy ceiling of the fused warp kernel (bench.py: roofline_warp*.copy_ceiling): a float4 grid-stride copy
+// with the warp launch's own grid, so that `frac` can also be read against what THIS part delivers for a launch of
+// that size (MI355X_MICROARCH.md: 6.29 TB/s of the 8 TB/s peak only for large copies).
+__global__ __launch_bounds__(512) void copy_f32x4_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long long n4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+extern "C" int tg_copy_ceiling(const void* src, void* dst, int64_t bytes, int blocks, int threads, tg_stream_t stream) {
+  TG_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0, TG_E_ARG, "copy_ceiling: bytes=%lld (a positive multiple of 16)", (long long)bytes);
+  TG_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, TG_E_ARG, "copy_ceiling: 16-byte aligned buffers");
+  TG_REQUIRE(blocks > 0 && threads > 0 && threads <= 512 && threads % 64 == 0, TG_E_ARG, "copy_ceiling: grid %d x %d", blocks, threads);
+  hipLaunchKernelGGL(copy_f32x4_kernel, dim3((unsigned)blocks), dim3((unsigned)threads), 0, (hipStream_t)stream,
+                     static_cast<const f32x4*>(src), static_cast<f32x4*>(dst), (long long)(bytes / 16));
+  return check_launch("copy_ceiling");
 }
 
 extern "C" int tg_backward_warp_fwd(const float* x, const float* flow, float* y, int n, int c,

@@ -358,7 +358,9 @@ def test_asynchronous_log_equals_reading_it_every_iteration():
                 assert m._pending_log is None
             m.update_running_log()
             if not read_each:
-                assert m._pending_log is None and len(m._log_queue) >= 1
+                # queued (or already folded in, when the device had finished the iteration before the host got here:
+                # ready entries are resolved without waiting)
+                assert m._pending_log is None
         runs.append((dict(m.get_running_log()), dict(m.log_dict), logs))
         assert not m._log_queue and m._pending_log is None
     (run_a, last_a, logs), (run_b, last_b, _) = runs
