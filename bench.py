@@ -908,8 +908,11 @@ def main():
                 result['roofline']['frac_vs_winograd_ceiling'] = result['roofline']['mfma_executed_frac']
                 # `frac` is the share of the fp32-MFMA peak the kernel actually occupies (executed FLOPs): the
                 # algorithmic rate of a Winograd kernel may exceed the peak, and no line should print > 1
+                # ONE stable pair of keys: `frac_executed` and `frac_algorithmic`; `frac` IS
+                # `frac_executed`, for good (round 3 printed the algorithmic number under `frac`: trend readers beware)
                 result['roofline']['frac_algorithmic'] = ach / MFMA_F32_PEAK_TFLOPS
-                result['roofline']['frac'] = result['roofline']['mfma_executed_frac']
+                result['roofline']['frac_executed'] = result['roofline']['mfma_executed_frac']
+                result['roofline']['frac'] = result['roofline']['frac_executed']
                 result['roofline']['frac_is'] = ('executed MFMA FLOPs (16/36 of the algorithmic ones) / peak; `achieved` is the '
                                                  'ALGORITHMIC rate of the 3x3 convolutions (SURVEY 8d) and may exceed `peak` in this form')
             warp = [r for r in rows if r['kernel'].startswith('flowup_warp')]
