@@ -12,7 +12,8 @@
 // Tuning / ablation switches read from the environment exist only in lab builds
 // (tools/build_lab_libs.sh, -DTG_LAB=1).  The shipped library reads exactly three variables,
 // all documented in INTEGRATION.md: TG_CONV_WINO, TG_WINO_CHAIN and TG_WINO_RES (kernel-form selection
-// for A/B runs; every setting produces reference-parity results).
+// for A/B runs; every setting produces reference-parity results).  The Python mirror has switches of its own
+// (TG_FNET_BATCH, TG_FNET_FIRST_BATCH, TG_WINO_RES_CT, TG_CONV4_DIRECT, TECOGAN_COMM, TECOGAN_HIP_LIB): INTEGRATION.md.
 #ifndef TG_LAB
 #define TG_LAB 0
 #endif

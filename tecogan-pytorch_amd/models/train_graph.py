@@ -672,7 +672,11 @@ def convt3x3s2(tape, layer, x, act=RELU):
 #   2*oy - 1 + ky = 2*(oy + ty - 1) + py
 # ---------------------------------------------------------------------------
 _K4 = {0: (1, 0), 1: (0, 1), 2: (1, 1), 3: (0, 2)}   # ky -> (py, ty)
-DIRECT_CONV4 = os.environ.get('TG_CONV4_DIRECT', '1') != '0'   # 0: the embedded form everywhere (lab / tests)
+
+
+def direct_conv4():
+    """TG_CONV4_DIRECT=0: the embedded form everywhere (lab / tests).  Read per call, so a test can toggle it."""
+    return os.environ.get('TG_CONV4_DIRECT', '1') != '0'
 
 
 def _conv4_embed(w4):
@@ -684,14 +688,15 @@ def _conv4_embed(w4):
 
 def conv4x4s2(tape, holder, x, need_dx=True):
     """holder.weight: (co, ci, 4, 4).  Returns (n, co, h/2, w/2).
-    Forward and data gradient run on the direct K = 16 ci kernel (tg_conv4x4s2_fwd / _dgrad, round 4) where it
-    applies (ci, co multiples of 64, w a multiple of 64); smaller maps and the weight gradient use the embedding
-    into a phase-masked 3x3 conv on space_to_depth(x, 2) -- the copy is then made in backward, only when the
-    weights take a gradient."""
+    Forward and data gradient run on the direct K = 16 ci kernels (tg_conv4x4s2_fwd / _dgrad, round 4) wherever
+    `tg_conv4x4s2_supported` says so: ci, co multiples of 64 and an input 64 or more wide (a multiple of 64) on the
+    row-tile kernels, 32 / 16 wide on the small-map kernels (folded pixel tiles, split-K + a summing launch).  Every
+    other shape and the weight gradient use the embedding into a phase-masked 3x3 conv on space_to_depth(x, 2) --
+    that copy is then made in backward, only when the weights take a gradient."""
     w = holder.weight
     co, ci = w.shape[:2]
     n, _, h_, w_ = x.shape
-    direct = DIRECT_CONV4 and ops.conv4x4s2_supported(n, ci, co, h_, w_)
+    direct = direct_conv4() and ops.conv4x4s2_supported(n, ci, co, h_, w_)
     sparse = ci % 8 == 0 and co > 32
     if direct:
         pk4 = _CACHE.get(holder, ('c4x',), _ver(w), lambda: ops.pack_conv4x4s2(w.detach().contiguous()))
