@@ -123,3 +123,23 @@ def test_main_test_mode_device_psnr_matches_host_metric():
         ref = float(np.mean([compute_psnr(d['gt'].numpy()[k], hr[k]) for k in range(len(hr))]))
         assert abs(got[i] - ref) <= 1e-3, (i, got[i], ref)
         assert 5.0 < ref < 60.0
+
+
+def test_copy_ceiling_copies_and_validates_arguments():
+    """tg_copy_ceiling (bench.py: roofline_warp*.copy_ceiling): a float4 grid-stride copy with a caller-chosen grid --
+    every byte arrives for grids smaller and larger than the data, bad arguments are refused."""
+    from tecogan_pytorch_amd import _lib as L
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for n4, blocks, threads in ((1, 1, 64), (1000, 3, 256), (514560, 670, 512), (514560, 4096, 256)):
+        a = torch.rand(4 * n4, device='cuda')
+        b = torch.zeros(4 * n4 + 4, device='cuda')
+        L.check(lib.tg_copy_ceiling(a.data_ptr(), b.data_ptr(), 16 * n4, blocks, threads, st), 'tg_copy_ceiling')
+        torch.cuda.synchronize()
+        assert torch.equal(b[:4 * n4], a) and float(b[4 * n4:].abs().sum()) == 0.0
+    a = torch.rand(64, device='cuda')
+    b = torch.empty(64, device='cuda')
+    assert lib.tg_copy_ceiling(a.data_ptr(), b.data_ptr(), 100, 1, 64, st) != 0          # not a multiple of 16
+    assert lib.tg_copy_ceiling(a.data_ptr() + 4, b.data_ptr(), 64, 1, 64, st) != 0       # misaligned
+    assert lib.tg_copy_ceiling(a.data_ptr(), b.data_ptr(), 64, 1, 100, st) != 0          # threads not a multiple of 64
+    assert lib.tg_copy_ceiling(None, b.data_ptr(), 64, 1, 64, st) != 0
