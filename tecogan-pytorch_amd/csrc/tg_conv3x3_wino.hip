@@ -55,6 +55,9 @@ struct WinoArgs {
   int abl;             // lab builds only (TG_WINO_LAB, env TG_WINO_ABL): 1 no weight loads, 2 no input loads, 4 no stores, 16 no MFMA, 32 weights from L1, 64 empty launch, 128 no main loop
 };
 
+#ifndef W_BRANCHY_U
+#define W_BRANCHY_U 0   // 1: the round 2-4 form of the weight prefetch, for A/B
+#endif
 constexpr int W_ICS = 16;             // input channels per stage
 constexpr int W_RS = 40;              // LDS row stride of the raw patch (floats); 4 rows = 160 = 32 mod 64 banks
 constexpr int W_ICSTR = 4 * W_RS;
@@ -204,7 +207,16 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
   const int ktotal = 4 * a.nstage;
   // one half (positions 8*half .. 8*half+7) of the weights of K step `kstep`
   auto load_uh = [&](int kstep, int half, f32x4 (&u)[4]) {
+#if W_BRANCHY_U
     if (kstep >= ktotal || (WABL(1) && kstep > 1)) return;
+#else
+    // BRANCH-FREE (round 5): behind `if (kstep < ktotal)` the compiler's s_waitcnt insertion merges both paths at the
+    // join assuming the FEWER loads in flight, and every K step waited `vmcnt(1) / vmcnt(0)` -- for the half-block
+    // requested a moment ago as well as for its own.  Past the last K step the last block is requested again (an L1
+    // hit, never used); the waits then carry the exact counts (vmcnt(7) .. (4) in the ISA).
+    if (WABL(1) && kstep > 1) return;
+    kstep = kstep < ktotal ? kstep : ktotal - 1;
+#endif
     if (WABL(32)) kstep &= 1;
     const f32x4* p = ug + (size_t)kstep * ustep + half * 128;
     u[2 * half] = p[0];
@@ -295,7 +307,8 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
     const int cur = s & 1, nxt = cur ^ 1;
     kstep(4 * s + 0, u0, cur, nothing);
     __syncthreads();                         // patch of stage s+1 visible
-    if (s + 2 <= last) load_raw(s + 2, rawreg);
+    if (s + 2 <= last) load_raw(s + 2, rawreg);    // (a branch-free form of THIS prefetch measured +-0: its loads are consumed
+                                                   // in the same iteration, round 5)
     kstep(4 * s + 1, u1, cur, [&] { transform_half(nxt, 0); });
     kstep(4 * s + 2, u0, cur, [&] { transform_half(nxt, 1); });
     kstep(4 * s + 3, u1, cur, nothing);
