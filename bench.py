@@ -60,6 +60,8 @@ def parse():
                     help='max frames of the CPU baseline sample (0 disables)')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-live-pmc', action='store_true',
+                    help='do not run the two rocprofv3 --pmc child passes that measure roofline.traffic in this run')
     ap.add_argument('--no-pipeline', action='store_true',
                     help='single-stream clip inference only (for kernel-trace profiles whose per-kernel '
                          'durations are not inflated by the FNet/SRNet stream overlap)')
@@ -155,6 +157,74 @@ def pmc_traffic(kernel, tag=None):
                 return v
     except Exception:
         pass
+    return None
+
+
+def live_pmc_traffic(lr_size, scale, deg, timeout_s=150):
+    """HBM bytes per launch of every tg:: kernel of the frame, MEASURED IN THIS RUN: two child invocations of this script
+    under `rocprofv3 --pmc` -- FETCH_SIZE and WRITE_SIZE in passes of their own, with --kernel-trace only, as
+    MI355X_MICROARCH.md (section HBM / rocprofv3 PMC) prescribes -- on a 1-clip single-stream run of the same workload.
+    Returns {kernel symbol without arguments: bytes per launch} or None (no rocprofv3, a pass failed or timed out: the
+    line then falls back to the committed passes).  Values are the raw counters (KB -> B), the same convention as
+    profiles/pmc_traffic.json: FETCH_SIZE under-counts 16-byte-per-lane streaming reads by 2x on gfx950 and WRITE_SIZE
+    is uncalibrated (the guide), so ratios between rounds are exact and absolutes are a lower bound."""
+    import csv
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    rp = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(rp):
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', '6', '--warmup', '2', '--clips', '1', '--lr-size', lr_size,
+           '--scale', str(scale), '--degradation', deg, '--no-roofline', '--no-pipeline', '--no-secondary',
+           '--no-parity-check', '--no-train-leg', '--cpu-frames', '0', '--aten-frames', '0', '--no-live-pmc']
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    per = {}
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='tg_pmc_', dir='/tmp')
+        try:
+            proc = subprocess.Popen([rp, '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'pmc', '--'] + cmd,
+                                    cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)        # exactly the group this call started
+                proc.wait()
+                return None
+            path = None
+            for root_, _, files in os.walk(d):
+                if 'pmc_counter_collection.csv' in files:
+                    path = os.path.join(root_, 'pmc_counter_collection.csv')
+            if rc != 0 or path is None:
+                return None
+            acc = {}
+            with open(path) as f:
+                for r in csv.DictReader(f):
+                    if 'tg::' not in r['Kernel_Name'] or r['Counter_Name'] != ctr:
+                        continue
+                    name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('tg::', '').replace(' ', '')
+                    a_ = acc.setdefault(name, [0.0, 0])
+                    a_[0] += float(r['Counter_Value']); a_[1] += 1
+            for name, (tot, n) in acc.items():
+                per.setdefault(name, {})[ctr] = tot / n * 1024.0
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {k: v['FETCH_SIZE'] + v['WRITE_SIZE'] for k, v in per.items() if len(v) == 2} or None
+
+
+def _live_lookup(table, kernel):
+    if not table:
+        return None
+    want = kernel.replace(' ', '').rstrip('>')
+    for k, v in table.items():
+        if k.startswith(want):
+            return v
     return None
 
 
@@ -933,6 +1003,25 @@ def main():
                 result['roofline_warp']['frac_of_copy_ceiling'] = wk['gbs'] / cc1['GBps']
                 result['roofline_warp_batched'] = warp_batched_roofline(
                     dev, h, w, s, deg)
+            # roofline.traffic MEASURED IN THIS RUN (it used to come from the committed passes only): two
+            # rocprofv3 --pmc child passes of ~15 s each; the committed value stays beside it
+            if world == 1 and not dist_on and not args.no_live_pmc:
+                live = live_pmc_traffic(args.lr_size, s, deg)
+                for key in ('roofline', 'roofline_warp'):
+                    ro = result.get(key)
+                    if ro is None:
+                        continue
+                    lv = _live_lookup(live, ro['kernel'])
+                    ro['traffic_committed'] = ro['traffic']
+                    if lv is not None:
+                        ro['traffic'] = lv
+                        ro['traffic_source'] = ('measured in THIS run: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (own passes, '
+                                                '--kernel-trace only) over a 1-clip single-stream child run of this script; '
+                                                'raw counters KB -> B per launch (MI355X_MICROARCH.md: FETCH_SIZE under-counts '
+                                                '16-byte-per-lane reads 2x on gfx950, WRITE_SIZE uncalibrated); '
+                                                '`traffic_committed` = profiles/pmc_traffic.json')
+                    else:
+                        ro['traffic_live'] = 'unavailable (no rocprofv3, or a counter pass failed / timed out): committed passes used'
             result['kernels'] = rows
             result['gpu_ms_per_frame_sum_of_kernels'] = sum(r['ms_per_frame'] for r in rows)
             result['slowest_kernel_class'] = dom['kernel']

@@ -5,6 +5,6 @@ EXPR=$1; shift
 for rep in 1 2; do
 for v in "$@"; do
   LIBENV=""; [ "$v" != "default" ] && LIBENV="TECOGAN_HIP_LIB=$REPO/tools/_lab_libs/libtecogan_$v.so"
-  echo "$v: $(env $LIBENV python $REPO/bench.py --steps 40 --warmup 10 --no-train-leg --no-secondary --no-parity-check --cpu-frames 0 --aten-frames 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print($EXPR)")"
+  echo "$v: $(env $LIBENV python $REPO/bench.py --steps 40 --warmup 10 --no-train-leg --no-secondary --no-parity-check --no-live-pmc --cpu-frames 0 --aten-frames 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print($EXPR)")"
 done
 done
