@@ -1,9 +1,15 @@
 #!/usr/bin/env python
 """Benchmark of the MI355X-native TecoGAN/FRVSR recurrent frame (FRNet.step).
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1
-it is launched under torch.distributed.run with one rank per GPU.  Rank 0
-prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1
+either the driver launches it under torch.distributed.run (RANK / WORLD_SIZE /
+MASTER_* in the environment), or -- plain `python bench.py --gpus N` with no
+RANK set -- this file brings up its own N ranks (launch_ranks(): one child per
+GPU, the reference's `torch.distributed.launch --nproc_per_node N` of
+train.sh:42-53 / codes/utils/dist_utils.py:8-24).  Rank 0 prints ONE JSON line
+whose `n_gpus` is the number of ranks the process group actually joined
+(`ranks_seen`: a sum all-reduce of ones), asserted equal to --gpus; a --gpus N
+request on a box with fewer than N GPUs exits non-zero and prints no line.
 
 Workload = BASELINE.json configs[1]: TecoGAN 4xSR BD generator-only inference,
 synthetic 3x134x320 LR clip (the shape the reference's published 27 FPS is
@@ -73,6 +79,105 @@ def parse():
     ap.add_argument('--aten-frames', type=int, default=30,
                     help='frames of the ATen/MIOpen-on-GPU context baseline (0 disables)')
     return ap.parse_args()
+
+
+def _die(msg, code=2):
+    print(f'bench.py: {msg}', file=sys.stderr, flush=True)
+    sys.exit(code)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) with no RANK in the environment: start N children of this
+    very command line, one rank per GPU, on a free local port; relay rank 0's stdout (the one JSON
+    line), pass every rank's stderr through, and return non-zero as soon as ANY child fails (the
+    others are then terminated: a rank that lost its peer would sit in a collective for ever).
+    The reference's counterpart is `python -m torch.distributed.launch --nproc_per_node N`
+    (train.sh:42-53) + init_dist (codes/utils/dist_utils.py:8-24)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    probe = os.environ.get('TG_BENCH_LAUNCH_PROBE') == '1'
+    rehearsal = os.environ.get('TG_BENCH_REHEARSAL') == '1'
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not probe and not rehearsal and have < n:
+        _die(f'--gpus {n} requested but {have} GPU(s) visible on this box: refusing to print a line for fewer ranks')
+    if rehearsal and have < 1:
+        _die('TG_BENCH_REHEARSAL=1 needs one GPU')
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(n), 'LOCAL_WORLD_SIZE': str(n),
+                    'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0',
+                    'TG_BENCH_LAUNCHED_BY': 'bench.py'})
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    import threading
+    lines = []
+    th = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    th.start()
+    rc, live = 0, set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is not None:
+                live.discard(r)
+                if c != 0:
+                    rc = c if c > 0 else 1
+                    print(f'bench.py: rank {r} exited with code {c}; stopping the other ranks', file=sys.stderr, flush=True)
+        time.sleep(0.05)
+    for r in live:                         # only the PIDs started here
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+    th.join(timeout=10)
+    if rc == 0:
+        js = [ln for ln in lines if ln.lstrip().startswith('{')]
+        if len(js) != 1:
+            _die(f'rank 0 printed {len(js)} JSON lines, expected exactly one', 3)
+        seen = json.loads(js[0]).get('n_gpus')
+        if seen != n:
+            _die(f'the line says n_gpus {seen}, --gpus was {n}', 3)
+        sys.stdout.write(js[0] if js[0].endswith('\n') else js[0] + '\n')
+        sys.stdout.flush()
+    return rc
+
+
+def ranks_seen_by_collective(dist, dev):
+    """How many ranks the process group REALLY holds: every rank contributes 1 to a sum all-reduce
+    (RCCL under backend nccl), plus the set of distinct (host, GPU) pairs from an all-gather."""
+    one = torch.ones(1, device=dev, dtype=torch.float32)
+    dist.all_reduce(one)
+    ident = [None] * dist.get_world_size()
+    me = (os.uname().nodename,
+          str(getattr(torch.cuda.get_device_properties(dev), 'uuid', None) or torch.cuda.current_device())
+          if dev.type == 'cuda' else f'cpu{dist.get_rank()}')
+    dist.all_gather_object(ident, me)
+    return int(round(one.item())), len(set(ident))
+
+
+def launch_probe(args):
+    """TG_BENCH_LAUNCH_PROBE=1: the launcher's plumbing on a box without a GPU (tests/test_bench_launch_cpu.py):
+    each child joins a gloo group on the CPU and rank 0 prints the launcher-level fields only."""
+    import torch.distributed as dist
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    if os.environ.get('TG_BENCH_PROBE_FAIL_RANK') == str(rank):
+        _die(f'rank {rank}: injected failure', 7)
+    dist.init_process_group(backend='gloo')
+    seen, distinct = ranks_seen_by_collective(dist, torch.device('cpu'))
+    assert seen == dist.get_world_size() == world == args.gpus, (seen, world, args.gpus)
+    if rank == 0:
+        print(json.dumps({'probe': True, 'n_gpus': seen, 'ranks_seen': seen, 'distinct_devices': distinct,
+                          'steps': args.steps, 'warmup': args.warmup,
+                          'launched_by': os.environ.get('TG_BENCH_LAUNCHED_BY', 'torch.distributed.run')}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def kernel_table(net, plan, bufs, reps=20):
@@ -694,9 +799,18 @@ def ddp_train_leg(args, dev, rank, world, local_rank, dist_on):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        _die(f'--gpus {args.gpus}')
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args))          # plain `python bench.py --gpus N`: bring up the N ranks here
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        # never print a line whose n_gpus is not what --gpus asked for
+        _die(f'rank {rank}: --gpus {args.gpus} but WORLD_SIZE {world} in the environment')
+    if os.environ.get('TG_BENCH_LAUNCH_PROBE') == '1' and 'RANK' in os.environ:
+        return launch_probe(args)
     # under torch.distributed.run (RANK/WORLD_SIZE set) always go through the process group,
     # so the N = 1 launch exercises exactly the code the N > 1 launches use
     dist_on = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)
@@ -720,11 +834,22 @@ def main():
             from tecogan_pytorch_amd.models.networks.tecogan_nets import SRNet
             SRNet.chain_body = False
         else:
+            if local_rank >= torch.cuda.device_count():
+                _die(f'rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible')
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local_rank if dist_on else 0)
+    ranks_seen, distinct_gpus = 1, 1
+    if dist_on:
+        # the ranks RCCL itself carries (a sum all-reduce of ones) and the distinct GPUs behind them: `n_gpus` of the
+        # line is THIS number, and it must be what --gpus asked for
+        ranks_seen, distinct_gpus = ranks_seen_by_collective(dist, dev)
+        if ranks_seen != args.gpus or dist.get_world_size() != args.gpus:
+            _die(f'rank {rank}: the process group carries {ranks_seen} ranks (world {dist.get_world_size()}), --gpus {args.gpus}')
+        if distinct_gpus != args.gpus and os.environ.get('TG_BENCH_REHEARSAL') != '1':
+            _die(f'rank {rank}: {args.gpus} ranks on {distinct_gpus} distinct GPU(s)')
 
     from tecogan_pytorch_amd.models.networks import FRNet
     from tecogan_pytorch_amd import _lib as L
@@ -902,7 +1027,10 @@ def main():
             'metric': 'HR frames/sec/GPU at 4xSR 3x134x320 LR; Vid4 PSNR vs reference',
             'value': world * args.steps / elapsed,
             'unit': 'frames/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': ranks_seen, 'steps': args.steps, 'warmup': args.warmup,
+            'ranks_seen': ranks_seen, 'distinct_gpus': distinct_gpus,
+            'launched_by': (os.environ.get('TG_BENCH_LAUNCHED_BY', 'torch.distributed.run') if dist_on else 'plain process')
+                           + (' (TG_BENCH_REHEARSAL: every rank on cuda:0, gloo)' if os.environ.get('TG_BENCH_REHEARSAL') == '1' else ''),
             'ms_per_step': 1e3 * elapsed / args.steps,
             'timed_regions': len(times), 'ms_per_step_min': 1e3 * min(times) / args.steps,
             'ms_per_step_max': 1e3 * max(times) / args.steps, 'statistic': 'median of the timed regions',

@@ -171,3 +171,43 @@ def test_sync_bn_statistics_survive_a_large_mean_offset():
                                   invstd.data_ptr(), None, None, 8, st), 'merge')
     assert torch.allclose(mean, m1, rtol=0, atol=1e-4)
     assert torch.allclose(invstd, i1, rtol=1e-3)
+
+
+ROOT = os.path.dirname(HERE)
+
+
+def _bench_env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(kw)
+    return env
+
+
+def test_plain_bench_invocation_brings_up_two_ranks():
+    """plain `python bench.py --gpus 2 ...` (no launcher around it) spawns its own two ranks
+    and the line says n_gpus 2.  On a one-GPU box this is the rehearsal form (both ranks on cuda:0 over gloo); with
+    two GPUs it is the real thing over RCCL.  The gradient buckets on the line are the sizes DESIGN.md quotes."""
+    import json
+    env = _bench_env() if torch.cuda.device_count() >= 2 else _bench_env(TG_BENCH_REHEARSAL='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
+                        '--clips', '2', '--train-steps', '2', '--cpu-frames', '0', '--no-roofline', '--no-secondary',
+                        '--no-parity-check'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    js = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith('{')]
+    assert len(js) == 1, r.stdout[-2000:]
+    line = json.loads(js[0])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['launched_by'].startswith('bench.py')
+    assert line['value'] > 0 and line['steps'] == 4
+    t = line['train_ddp']
+    assert 'error' not in t, t
+    assert t['n_gpus'] == 2 and t['process_group']['world_seen_by_rank0'] == 2
+    assert t['allreduce_G']['bytes'] == 10357504 and t['allreduce_D']['bytes'] == 3278336
+    assert t['allreduce_G']['ms_per_call'] > 0 and t['allreduce_D']['ms_per_call'] > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 8, reason='the box really has 8 GPUs')
+def test_plain_bench_invocation_refuses_more_gpus_than_present():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1'],
+                       env=_bench_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith('{')]
+    assert '--gpus 8 requested but' in r.stderr
