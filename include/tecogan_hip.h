@@ -63,6 +63,11 @@ enum {
 #define TG_ABI_MAJOR 2
 int tg_version(void);
 const char* tg_last_error_string(void);
+/* How this library was built (a static string): "lab=<0|1> wres_lab_bits=<n> flags=<hipcc flags of csrc/build.sh>
+ * file_flags=<per-file TG_FILE_FLAGS>".  The in-tree library is lab=0 wres_lab_bits=0 by construction (build.sh
+ * refuses EXTRA_FLAGS / TG_LAB for it, the sources #error on a lab switch without TG_LAB); tests/test_abi_cpu.py
+ * asserts exactly that, so an ablation build can never pass for the product. */
+const char* tg_build_info(void);
 
 /* ------------------------------------------------------------------------
  * 3x3 stride-1 pad-1 convolution, fp32 MFMA implicit GEMM.

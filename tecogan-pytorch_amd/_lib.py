@@ -59,6 +59,7 @@ class LayerWeights(C.Structure):
 SIGNATURES = {
     'tg_version': (I, []),
     'tg_last_error_string': (C.c_char_p, []),
+    'tg_build_info': (C.c_char_p, []),
     'tg_conv3x3_pick_ocb': (I, [I]),
     'tg_conv3x3_packed_floats': (SZ, [I, I, I]),
     'tg_conv3x3_pack': (I, [P, P, I, I, I, I, P]),

@@ -17,6 +17,21 @@ void set_error(const char* fmt, ...) {
 extern "C" int tg_version(void) { return TG_ABI_MAJOR * 100 + 1; }
 extern "C" const char* tg_last_error_string(void) { return tg::g_err; }
 
+#ifndef TG_BUILD_FLAGS_STR
+#define TG_BUILD_FLAGS_STR "unknown (not built by csrc/build.sh)"
+#endif
+#ifndef TG_FILE_FLAGS_STR
+#define TG_FILE_FLAGS_STR ""
+#endif
+namespace tg { int wres_lab_bits(); }
+extern "C" const char* tg_build_info(void) {
+  static char s[1024];
+  if (!s[0])
+    snprintf(s, sizeof(s), "lab=%d wres_lab_bits=%d flags=%s file_flags=%s", (int)TG_LAB, tg::wres_lab_bits(),
+             TG_BUILD_FLAGS_STR, TG_FILE_FLAGS_STR);
+  return s;
+}
+
 // ---------------------------------------------------------------------------
 // FRNet.step plan (codes/models/networks/tecogan_nets.py:227-252): the launch
 // list of one recurrent frame, resolved once per (shape, weights).  Owns no

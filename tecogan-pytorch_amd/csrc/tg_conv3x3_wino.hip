@@ -36,6 +36,9 @@
 #define TG_WINO_LAB 0   // 1: ablation switches of tools/wino_abl.sh (TG_WINO_ABL) compiled in
 #endif
 #define WABL(bit) (TG_WINO_LAB && (a.abl & (bit)))
+#if !TG_LAB && TG_WINO_LAB
+#error "tg_conv3x3_wino.hip: TG_WINO_LAB needs -DTG_LAB=1 (lab builds only; csrc/build.sh refuses it for the in-tree library)"
+#endif
 
 namespace tg {
 

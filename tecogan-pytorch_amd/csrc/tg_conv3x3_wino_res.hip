@@ -34,6 +34,9 @@
 
 #include "tg_common.h"
 
+// ---- lab switches (A/B and ablation builds, tools/build_lab_libs.sh).  Every one of them needs -DTG_LAB=1, which
+// csrc/build.sh refuses for the in-tree library: the shipped translation unit is the DEFAULT column below and nothing
+// else (WR_FAKEBANK computes wrong results by design, timing only). ----
 #ifndef WR_POLL_SLEEP
 #define WR_POLL_SLEEP 2   // s_sleep units (64 cycles) between two polls of the ring
 #endif
@@ -59,13 +62,33 @@
 #ifndef WR_PREF
 #define WR_PREF 1       // 1: K step ks + 1's window is requested before K step ks's MFMAs (second register set)
 #endif
+#ifndef WR_PK
+#define WR_PK 0         // 1: the input transform on v_pk_add_f32 (measured)
+#endif
+#ifndef WR_UASM
+#define WR_UASM 1       // hand-written weight requests + exact vmcnt waits (round 5); 0: compiler-visible loads, for A/B
+#endif
+#ifndef WR_BRANCHY_U
+#define WR_BRANCHY_U 0
+#endif
+#define WR_LAB_BITS ((TG_WRES_LAB ? 1 : 0) | (WR_FAKEBANK ? 2 : 0) | (WR_RDFORM ? 4 : 0) | (WR_PREF != 1 ? 8 : 0) | \
+                     (WR_PK ? 16 : 0) | (WR_UASM != 1 ? 32 : 0) | (WR_BRANCHY_U ? 64 : 0) | (WR_USETS != 2 ? 128 : 0) | \
+                     (WR_PRIO_I || WR_PRIO_B ? 256 : 0) | (WR_POLL_SLEEP != 2 ? 512 : 0))
+#if !TG_LAB && WR_LAB_BITS
+#error "tg_conv3x3_wino_res.hip: a lab switch is set without -DTG_LAB=1 (the in-tree library ships the defaults only)"
+#endif
+#if WR_UASM && WR_PK
+#error "WR_PK's K step never waits for the hand-requested weight block (wait_u): -DWR_PK=1 needs -DWR_UASM=0"
+#endif
+#if WR_UASM && WR_USETS != 2
+#error "the hand-written waits assume two weight blocks in flight"
+#endif
 
 namespace tg {
 
+int wres_lab_bits() { return WR_LAB_BITS | (TG_LAB ? 1024 : 0); }    // tg_build_info(): 0 in the shipped library
+
 typedef float v2f __attribute__((ext_vector_type(2)));
-#ifndef WR_PK
-#define WR_PK 0   // 1: the input transform on v_pk_add_f32 (measured)
-#endif
 
 constexpr int WR_TH = 4, WR_TW = 12;             // Winograd tiles per block
 constexpr int WR_BH = 2 * WR_TH, WR_BW = 2 * WR_TW;   // 8 x 24 pixels
@@ -219,15 +242,8 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
   // stronger than needed as well.  The stream of blocks runs ACROSS the layers: the last two K steps of a layer
   // request the first two blocks of the next one (they arrive under the epilogue and the hand-over), so exactly two
   // blocks are in flight at every point of the launch and the epilogue issues no request of its own.
-#ifndef WR_UASM
-#define WR_UASM 1        // 0: compiler-visible loads (the round-4 form with -DWR_BRANCHY_U=1), for A/B
-#endif
-#if WR_UASM && WR_USETS != 2
-#error "the hand-written waits assume two weight blocks in flight"
-#endif
-#ifndef WR_BRANCHY_U
-#define WR_BRANCHY_U 0
-#endif
+  // (WR_UASM = 0: compiler-visible loads, the round-4 form with -DWR_BRANCHY_U=1; lab builds only.  Because the compiler
+  // cannot see these loads, csrc/build.sh FAILS the build if this kernel ever reports scratch or spilled registers.)
   const f32x4* un = nullptr;                   // WR_UASM: the next layer's blocks (the K loop runs on into them)
   auto load_u = [&](const f32x4* ub, int ks, int nks, f32x4 (&u)[4]) {
 #if WR_BRANCHY_U

@@ -114,6 +114,9 @@ __device__ __forceinline__ float warp_coord_c(int i, int n, float flow, float st
 #ifndef TG_WARP_ABL
 #define TG_WARP_ABL 0   // lab only (tools/warp_lab.py): 1 no stores, 2 one tap row instead of two, 4 no flow loads
 #endif
+#if !TG_LAB && TG_WARP_ABL
+#error "tg_warp.hip: TG_WARP_ABL needs -DTG_LAB=1 (lab builds only; the ablated kernels compute wrong results)"
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef TG_WARP_PF
 #define TG_WARP_PF 0    // 1: speculative touch of the previous frame under the flow loads for one-frame launches (see PF below);

@@ -313,6 +313,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
 #define WG_ABL 0      // compile-time ablation bits (tools/build_lab_libs.sh builds one library per value)
 #endif
 #define WGABL(bit) ((WG_ABL & (bit)) != 0)
+#if !TG_LAB && WG_ABL
+#error "tg_wgrad_mfma.hip: WG_ABL needs -DTG_LAB=1 (lab builds only; the ablated kernels compute wrong results)"
+#endif
   constexpr int NBV = G::S2 ? 9 : 6;         // shifted Q values one (row, group of 4 pixels) needs per tap row
   constexpr int QS = G::S2 ? 2 : 1;          // Q step per P pixel
   for (; tile < a.ntiles; tile += a.nsplit, ++it) {

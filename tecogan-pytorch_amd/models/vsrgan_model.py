@@ -188,6 +188,8 @@ class VSRGANModel(VSRModel):
         if upd_D:
             self.finish_grad_exchange(bucket_D, 'D')
             self.optim_D.step()
+            if getattr(self.optim_D, 'fault_slot', None) is not None:
+                scal[15:16].copy_(self.optim_D.fault_slot)      # read by took_back(): D's dropped update takes its count back
         for p in self.net_D.parameters():
             p.requires_grad = False
         d_in['tape'] = tape_G

@@ -178,3 +178,25 @@ def test_round4_host_side_shape_rules():
     assert lib.tg_conv3x3_wino_resident_ct_floats() == 16 * 4 * 3 * 64 * 4
     assert lib.tg_conv3x3_wino_resident_ct_pack(None, None, None) == -2
     assert lib.tg_backward_warp_s2d_fwd(None, None, None, 1, 3, 8, 8, 4, None) == -2
+
+
+def test_in_tree_library_is_not_a_lab_build():
+    """tg_build_info(): the library the package loads was built by csrc/build.sh with its fixed flags, no lab switch
+    compiled in (ablation switches -- one of them wrong-result by design -- sat in the shipped
+    translation unit behind -D flags an EXTRA_FLAGS could set)."""
+    info = L.lib().tg_build_info().decode()
+    assert info.startswith('lab=0 wres_lab_bits=0 flags=--offload-arch=gfx950 -O3 '), info
+    assert '-DTG_LAB' not in info and '-DWR_' not in info and '-DWG_ABL' not in info and '-DTG_W' not in info, info
+    assert 'tg_conv3x3_wino_res.hip: -fno-slp-vectorize' in info, info     # the per-file flag the resident kernel was tuned with
+
+
+def test_build_script_refuses_extra_flags_for_the_in_tree_library():
+    import subprocess
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tecogan-pytorch_amd', 'csrc', 'build.sh')],
+                       env=dict(os.environ, EXTRA_FLAGS='-DWR_FAKEBANK=1'), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'refused for the in-tree library' in r.stderr
+    r = subprocess.run(['bash', os.path.join(ROOT, 'tecogan-pytorch_amd', 'csrc', 'build.sh')],
+                       env=dict(os.environ, TG_LAB_BUILD='1', OUT=os.path.join(ROOT, 'tecogan-pytorch_amd', 'lab')),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'may not write into the package' in r.stderr
+    assert not os.path.isdir(os.path.join(ROOT, 'tecogan-pytorch_amd', 'lab')) or not os.listdir(os.path.join(ROOT, 'tecogan-pytorch_amd', 'lab'))

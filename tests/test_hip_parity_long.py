@@ -184,6 +184,7 @@ def _train_opt(crop, tempo, thr):
 # 1.2e-3 .. 3e-3): its gradient passes the warp's image scatter and the bicubic transpose, both fp32 ATOMIC sums
 # whose order changes from run to run, 18 times per clip, while ATen sums in a fixed order -- factor 4.
 FP64_FLOOR = 2e-4
+GRAD_ABS_CAP = 2e-2      # no watched gradient may be further than this (relative L2) from fp64 or from the oracle, whatever the ratio says
 
 
 def _fp64_factor(name):
@@ -199,9 +200,13 @@ def _rel_l2(a, b):
 def test_fullsize_tecogan_train_step_vs_oracle(crop, tag):
     """n=2, tempo 10 -> 19 ping-pong frames, the shipped TecoGAN losses, D updated
     (threshold 0.4, distance starts near 0).  Log dict 5e-4 relative (quantities evaluated
-    after D's Adam step 1e-2, see test_hip_train.py); every watched G / D gradient within
-    2e-2 relative L2 of the oracle's autograd gradient (19-frame BPTT in fp32 with atomics
-    in the warp / up-sample transposes)."""
+    after D's Adam step 1e-2, see test_hip_train.py).  Gradients: every watched G / D gradient is
+    triangulated against the SAME step in float64 (tests/golden/train_fp64_grads.npz): its relative L2
+    distance from fp64 may be at most FP64_FACTOR x the distance of the oracle's own fp32 autograd from
+    fp64 (+ FP64_FLOOR), never more than GRAD_ABS_CAP, and its direct distance from the oracle's fp32
+    gradient never more than GRAD_ABS_CAP either.  The step is run THREE times from the same state (the
+    warp / up-sample transposes accumulate with fp32 atomics in run-to-run order): every run must pass,
+    and the spread is what the FNet factor is set from."""
     from tecogan_pytorch_amd.models import define_model
     n, tempo, s, deg = 2, 10, 4, 'BD'
     gt = torch.stack([smooth_clip(tempo, 3, crop + 8, crop + 8, seed=900 + i, shift=1.0)
@@ -218,6 +223,17 @@ def test_fullsize_tecogan_train_step_vs_oracle(crop, tag):
     log = dict(m.log_dict)
     gG = {k: p.grad.detach().clone() for k, p in m.net_G.named_parameters() if k in WATCH_G}
     gD = {k: p.grad.detach().clone() for k, p in m.net_D.named_parameters() if k in WATCH_D}
+    reruns = []                          # the same iteration twice more from the same weights (atomics order differs)
+    for _ in range(2):
+        m2 = define_model(_train_opt(crop, tempo, 0.4))
+        m2.net_G.load_state_dict(sd_G, strict=True)
+        m2.net_D.load_state_dict(sd_D, strict=True)
+        m2.prepare_training_data({'gt': gt})
+        m2.train()
+        m2.sync_log()
+        reruns.append(({k: p.grad.detach().clone() for k, p in m2.net_G.named_parameters() if k in WATCH_G},
+                       {k: p.grad.detach().clone() for k, p in m2.net_D.named_parameters() if k in WATCH_D}))
+        del m2
 
     torch.set_num_threads(min(32, torch.get_num_threads()))
     sdg = {k: v.clone() for k, v in sd_G.items()}
@@ -245,23 +261,29 @@ def test_fullsize_tecogan_train_step_vs_oracle(crop, tag):
              'D': {k: vs64(gD[k], 'c%d_D_%s' % (crop, k)) for k in WATCH_D}}
     ora64 = {'G': {k: vs64(rG[k], 'c%d_G_%s' % (crop, k)) for k in WATCH_G},
              'D': {k: vs64(rD[k], 'c%d_D_%s' % (crop, k)) for k in WATCH_D}}
-    try:      # the measured values, for the record (DESIGN.md section 5 quotes them)
+    hip64_runs = [hip64] + [{'G': {k: vs64(rg[k], 'c%d_G_%s' % (crop, k)) for k in WATCH_G},
+                             'D': {k: vs64(rd[k], 'c%d_D_%s' % (crop, k)) for k in WATCH_D}} for rg, rd in reruns]
+    ratio = {net: {k: [r[net][k] / max(ora64[net][k], 1e-30) for r in hip64_runs] for k in hip64[net]} for net in ('G', 'D')}
+    rec = os.environ.get('TG_TEST_RECORD_DIR')        # the measured values, for the record (DESIGN.md section 5 quotes
+    if rec:                                           # them); tests write nowhere unless asked to
         import json
-        out = os.path.join(ROOT_DIR, 'gpurun_out')
-        os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, 'train_grad_rel_l2_crop%d.json' % crop), 'w') as f:
-            json.dump({'hip_vs_oracle_fp32': {'G': eG, 'D': eD}, 'hip_vs_fp64': hip64, 'oracle_fp32_vs_fp64': ora64,
+        os.makedirs(rec, exist_ok=True)
+        with open(os.path.join(rec, 'train_grad_rel_l2_crop%d.json' % crop), 'w') as f:
+            json.dump({'hip_vs_oracle_fp32': {'G': eG, 'D': eD}, 'hip_vs_fp64_three_runs': hip64_runs,
+                       'oracle_fp32_vs_fp64': ora64, 'hip_over_oracle_ratio_three_runs': ratio,
                        'note': 'relative L2 of the watched gradients; fp64 = oracle/tecogan_oracle.py::vsrgan_train_step '
-                               'in float64 on the same inputs (tests/golden/train_fp64_grads.npz)'}, f, indent=1)
-    except OSError:
-        pass
+                               'in float64 on the same inputs (tests/golden/train_fp64_grads.npz); three runs of the same '
+                               'iteration from the same state'}, f, indent=1)
     for net, names, e32 in (('G', WATCH_G, eG), ('D', WATCH_D, eD)):
         for k in names:
-            h, o = hip64[net][k], ora64[net][k]
-            assert h <= _fp64_factor(k) * o + FP64_FLOOR, (tag, 'grad' + net, k, 'HIP vs fp64', h, 'oracle-fp32 vs fp64', o)
-            # the direct comparison is what the triangle allows (the fixture holds a strided sample of the larger
-            # tensors, hence the 1.25)
-            assert e32[k] <= 1.25 * (h + o) + 1e-6, (tag, 'grad' + net, k, e32[k], h, o)
+            o = ora64[net][k]
+            for run, r in enumerate(hip64_runs):
+                h = r[net][k]
+                assert h <= min(_fp64_factor(k) * o + FP64_FLOOR, GRAD_ABS_CAP), \
+                    (tag, 'grad' + net, k, 'run', run, 'HIP vs fp64', h, 'oracle-fp32 vs fp64', o)
+            # and directly against the oracle's fp32 gradient: an absolute ceiling (the old second assert was
+            # the triangle inequality and could not fail)
+            assert e32[k] <= GRAD_ABS_CAP, (tag, 'grad' + net, k, 'HIP vs oracle fp32', e32[k])
     # BatchNorm running statistics after the iteration's three D passes.  The third pass runs
     # AFTER D's Adam step (every weight moved by lr * sign(g); weights whose summed gradient is
     # ~0 flip sign under fp32 re-association), so 0.1 x its batch statistics carry that

@@ -205,8 +205,11 @@ def test_guarded_adam_step_and_fault_slot():
     assert slot.item() == 2.0
 
 
-def test_training_step_with_chain_fault_drops_the_update_and_raises():
-    """A chained-launch fault during a training iteration (injected: negative poll limit) must NOT reach the
+@pytest.mark.parametrize('model_name', ['FRVSR', 'TecoGAN'])
+def test_training_step_with_chain_fault_drops_the_update_and_raises(model_name):
+    """(TecoGAN: the critic's guarded update is dropped as well and ITS step count is taken back -- ADVICE r5: the
+    fault slot of D was never copied into the scalars, so `optim_D.steps` stayed advanced.)
+    A chained-launch fault during a training iteration (injected: negative poll limit) must NOT reach the
     weights: the generator's Adam step is a no-op on the device (fault slot of the gradient bucket), the
     iteration's log (sync_log / log_dict / the next iteration's end) raises, and the next iteration runs one launch per layer from the
     unchanged weights.  (the check used to run after the optimiser step.)"""
@@ -220,7 +223,7 @@ def test_training_step_with_chain_fault_drops_the_update_and_raises():
         "from tecogan_pytorch_amd.models import define_model, train_graph as TG\n"
         "from tecogan_pytorch_amd import _lib\n"
         "from procedural_weights import generator_state_dict\n"
-        "opt = make_opt('FRVSR'); opt['dataset']['train']['crop_size'] = 128     # 2 x 32 x 32 LR frames: the chained body's production shape\n"
+        "opt = make_opt(%r, thr=1e9); opt['dataset']['train']['crop_size'] = 128     # 2 x 32 x 32 LR frames: the chained body's production shape; D updates every step\n"
         "m = define_model(opt)\n"
         "m.net_G.load_state_dict(generator_state_dict(scale=4, degradation='BD'), strict=True)\n"
         "m.prepare_training_data({'gt': torch.stack([smooth_clip(4, 3, 136, 136, seed=11 + i, shift=1.0) for i in range(2)])})\n"
@@ -229,6 +232,9 @@ def test_training_step_with_chain_fault_drops_the_update_and_raises():
         "before = {k: v.detach().clone() for k, v in m.net_G.state_dict().items()}\n"
         "mom = [(a.clone(), b.clone()) for a, b in (m.optim_G.state[id(p)] for p in m.optim_G.params)]\n"
         "steps0 = m.optim_G.steps\n"
+        "D = getattr(m, 'net_D', None)\n"
+        "beforeD = {k: v.detach().clone() for k, v in D.state_dict().items()} if D is not None else {}\n"
+        "stepsD0 = m.optim_D.steps if D is not None else 0\n"
         "TG._ChainState.poll_limit = -1               # every waiting workgroup gives up at once\n"
         "try:                                        # the fault surfaces with the scalars: at the end of train() or on the first look at the log\n"
         "    m.train(); m.sync_log(); raise SystemExit('no error reported')\n"
@@ -239,11 +245,17 @@ def test_training_step_with_chain_fault_drops_the_update_and_raises():
         "assert all(torch.equal(a, c) and torch.equal(b, d) for (a, b), (c, d) in zip(mom, (m.optim_G.state[id(p)] for p in m.optim_G.params))), 'Adam moments moved'\n"
         "assert TG._ChainState.disabled\n"
         "assert m.optim_G.steps == steps0, 'a dropped update advanced the bias-correction step count (ADVICE r4)'\n"
+        "if D is not None:\n"
+        "    afterD = D.state_dict()\n"
+        "    assert all(torch.equal(beforeD[k], afterD[k]) for k in beforeD if 'running_' not in k and 'num_batches' not in k), 'critic weights moved although the step faulted'\n"
+        "    assert m.optim_D.steps == stepsD0, ('the critic\\'s dropped update advanced its step count (ADVICE r5)', m.optim_D.steps, stepsD0)\n"
         "TG._ChainState.poll_limit = 1 << 21\n"
         "m.train(); m.sync_log()                     # one launch per layer from the unchanged weights; nothing left to report\n"
         "assert any(not torch.equal(before[k], v) for k, v in m.net_G.state_dict().items())\n"
         "assert m.optim_G.steps == steps0 + 1\n"
-        "print('DROP-OK')\n" % (root, os.path.join(root, 'tests', 'golden')))
+        "if D is not None:\n"
+        "    assert m.optim_D.steps == stepsD0 + 1\n"
+        "print('DROP-OK')\n" % (root, os.path.join(root, 'tests', 'golden'), model_name))
     r = subprocess.run([sys.executable, '-c', script], timeout=900, capture_output=True, text=True)
     assert r.returncode == 0 and 'DROP-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 

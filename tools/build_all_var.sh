@@ -6,7 +6,7 @@ OUT=../../tools/_lab_libs/objs_$1; mkdir -p $OUT
 PIDS=()
 for f in tg_*.hip; do
   FF=$(sed -n "s/^\/\/ TG_FILE_FLAGS: *//p" $f | head -1)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=on $FF $2 -c $f -o $OUT/${f%.hip}.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -ffp-contract=on -DTG_LAB=1 $FF $2 -c $f -o $OUT/${f%.hip}.o &
   PIDS+=($!)
 done
 for p in "${PIDS[@]}"; do wait $p; done
