@@ -798,6 +798,17 @@ void tg_frnet_plan_destroy(tg_frnet_plan* plan);
  * (fault injection for tests of the host's error path). */
 int tg_frnet_plan_chain_status(tg_frnet_plan* plan, int* faults_total, int* chain_active);
 int tg_frnet_plan_set_chain_poll_limit(tg_frnet_plan* plan, int poll_limit);
+/* Recovery from a transient fault (round 6).  "For good" above is the round-5 behaviour and what
+ * first_after_frames = 0 selects.  By default (64) the plan counts the frames it enqueues on the per-layer
+ * fallback; after that many -- and once the GPU has passed the first of them (a hipEvent the plan creates on its
+ * first fault and owns) with no new fault counted -- the one-launch body is armed again (its flags / exchange
+ * buffers are re-zeroed in stream order).  A fault of the re-armed body is reported like the first one and
+ * DOUBLES the wait (capped at 2^20 frames): a permanent co-tenant costs one invalid clip per back-off period,
+ * a transient one costs 64 slower frames.  Results are bit-identical on either path.
+ * tg_frnet_plan_chain_rearms: *rearms = how often the body was armed again, *current_wait_frames = the
+ * back-off in force (0 before the first fault). */
+int tg_frnet_plan_set_chain_rearm(tg_frnet_plan* plan, int first_after_frames);
+int tg_frnet_plan_chain_rearms(const tg_frnet_plan* plan, int* rearms, int* current_wait_frames);
 /* hr_out may alias nothing else; lr_curr/lr_prev (n,c,h,w), hr_prev/hr_out (n,c,s*h,s*w).
  * u8_out (optional): (n, s*h, s*w, c) uint8 quantised frames (n > 1 needs the fused HR stage:
  * out_nc <= 3, nf <= 64). */

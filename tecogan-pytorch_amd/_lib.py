@@ -186,6 +186,8 @@ SIGNATURES = {
     'tg_frnet_plan_destroy': (None, [P]),
     'tg_frnet_plan_chain_status': (I, [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'tg_frnet_plan_set_chain_poll_limit': (I, [P, I]),
+    'tg_frnet_plan_set_chain_rearm': (I, [P, I]),
+    'tg_frnet_plan_chain_rearms': (I, [P, P, P]),
     'tg_frnet_step': (I, [P, P, P, P, P, P, P]),
     'tg_frnet_step_phase': (I, [P, I, I, P, P, P, P, P, P]),
     'tg_frnet_plan_launches': (I, [P]),

@@ -53,9 +53,16 @@ struct tg_frnet_plan {
   // fail-safe of the chained launch: fault counter in pinned host memory (the kernel adds to it
   // with system scope), looked at by every later call on the plan
   int32_t* chain_err;               // hipHostMalloc, 64 bytes; null when the allocation failed (chain then off)
-  bool chain_disabled;              // a fault was reported: one launch per layer from then on
+  bool chain_disabled;              // a fault was reported: one launch per layer until the plan re-arms (below)
   int chain_faults;                 // faults reported so far
   int chain_poll_limit;
+  // Recovery from a TRANSIENT fault (a co-tenant that kept a workgroup off the GPU for a moment):
+  // after `rearm_wait` clean per-layer frames the one-launch body is tried again; a fault of the re-armed body doubles
+  // the wait (exponential back-off, capped), a permanent co-tenant therefore costs one faulted clip every 2^k * first
+  // frames and never more.  rearm_first == 0: never re-arm (the round-5 behaviour).
+  int rearm_first, rearm_wait, clean_frames, rearms;
+  hipEvent_t rearm_fence;           // recorded behind the first per-layer frame after a report: the re-arm waits until the
+  bool fence_set;                   // GPU has passed it, so a late fault of a PRE-report launch is never blamed on the re-armed body
   int fh, fw, launches;
   int st_launch[24];
   double st_flops[24], st_bytes[24];
@@ -80,10 +87,35 @@ static int chain_poll(tg_frnet_plan* p) {
   // not reported again -- everything enqueued since the report uses one launch per layer.
   if (p->chain_disabled) return TG_OK;
   p->chain_disabled = true;
+  p->clean_frames = 0;
+  p->rearm_wait = p->rearm_wait ? (p->rearm_wait < (1 << 20) ? 2 * p->rearm_wait : p->rearm_wait) : p->rearm_first;
+  p->fence_set = false;
   tg::set_error("chained SRNet launch: %d workgroup(s) timed out waiting for a producer tile; the frames "
                 "enqueued on this plan since the previous successful check are INVALID.  The plan now runs "
-                "one launch per layer (TG_WINO_CHAIN=0 selects that from the start)", pending);
+                "one launch per layer (TG_WINO_CHAIN=0 selects that from the start)%s", pending,
+                p->rearm_first > 0 ? " and tries the one-launch body again after a back-off of clean frames" : "");
   return TG_E_HIP;
+}
+
+// Called once per frame enqueued through phase 2 while the one-launch body is off: counts clean frames, and re-arms the
+// body once the back-off has passed, no new fault has arrived, and the GPU is past the first per-layer frame.
+static void chain_rearm_tick(tg_frnet_plan* p, tg_stream_t st) {
+  if (!p->chain_disabled || !p->chain_err || p->rearm_first <= 0) return;
+  if (!p->fence_set) {
+    if (!p->rearm_fence && hipEventCreateWithFlags(&p->rearm_fence, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError(); p->rearm_fence = nullptr; p->rearm_first = 0; return;     // no fence -> never re-arm
+    }
+    if (hipEventRecord(p->rearm_fence, (hipStream_t)st) != hipSuccess) { (void)hipGetLastError(); return; }
+    p->fence_set = true;
+    return;
+  }
+  if (++p->clean_frames < p->rearm_wait) return;
+  if (hipEventQuery(p->rearm_fence) != hipSuccess) { (void)hipGetLastError(); return; }   // not there yet: ask again next frame
+  if (__atomic_load_n(p->chain_err, __ATOMIC_RELAXED) != 0) return;                        // (chain_poll counts it first)
+  p->chain_disabled = false;
+  p->res_ready = false;             // exchange buffers / flags are zeroed again in front of the next one-launch body
+  p->chain_ready = false;
+  p->rearms += 1;
 }
 
 static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
@@ -169,6 +201,7 @@ extern "C" int tg_frnet_plan_create(const tg_frnet_cfg* cfg, const tg_layer_weig
   p->RESWS = workspace + off[13]; p->res_ready = false;
   p->CHAINF = reinterpret_cast<int32_t*>(workspace + off[12]); p->chain_ready = false; p->epoch = 0; p->chain_layers = 0;
   p->chain_err = nullptr; p->chain_disabled = false; p->chain_faults = 0; p->chain_poll_limit = tg::TG_CHAIN_POLL_LIMIT_DEFAULT;
+  p->rearm_first = 64; p->rearm_wait = 0; p->clean_frames = 0; p->rearms = 0; p->rearm_fence = nullptr; p->fence_set = false;
   if (!cfg->fnet_only) {
     void* hp = nullptr;
     if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hp) {
@@ -202,6 +235,7 @@ extern "C" void tg_frnet_plan_destroy(tg_frnet_plan* plan) {
   // (a chained launch still in flight may yet add to the counter: the caller synchronises before
   // destroying a plan, as for the workspace it owns)
   if (plan->chain_err) (void)hipHostFree(plan->chain_err);
+  if (plan->rearm_fence) (void)hipEventDestroy(plan->rearm_fence);
   delete plan;
 }
 extern "C" int tg_frnet_plan_launches(const tg_frnet_plan* plan) { return plan ? plan->launches : 0; }
@@ -270,6 +304,7 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
   int li = 0;
   float *A = p->FA, *B = p->FB;
   int rc = TG_OK;
+  if (!dry && (phases & 2) && mask == 0xFFFFFFFFu) chain_rearm_tick(p, st);
   // account + (unless dry / masked out) launch
   auto go = [&](int kind, double flops, double bytes, auto&& fn) {
     if (rc != TG_OK) return;
@@ -603,6 +638,20 @@ extern "C" int tg_frnet_plan_chain_status(tg_frnet_plan* p, int* faults_total, i
 extern "C" int tg_frnet_plan_set_chain_poll_limit(tg_frnet_plan* p, int poll_limit) {
   TG_REQUIRE(p, TG_E_ARG, "frnet_plan_set_chain_poll_limit: null plan");
   p->chain_poll_limit = poll_limit;
+  return TG_OK;
+}
+
+extern "C" int tg_frnet_plan_set_chain_rearm(tg_frnet_plan* p, int first_after_frames) {
+  TG_REQUIRE(p && first_after_frames >= 0, TG_E_ARG, "frnet_plan_set_chain_rearm: bad argument");
+  p->rearm_first = first_after_frames;
+  if (p->chain_disabled && p->rearm_wait == 0) p->rearm_wait = first_after_frames;
+  return TG_OK;
+}
+
+extern "C" int tg_frnet_plan_chain_rearms(const tg_frnet_plan* p, int* rearms, int* current_wait_frames) {
+  TG_REQUIRE(p, TG_E_ARG, "frnet_plan_chain_rearms: null plan");
+  if (rearms) *rearms = p->rearms;
+  if (current_wait_frames) *current_wait_frames = p->rearm_wait;
   return TG_OK;
 }
 

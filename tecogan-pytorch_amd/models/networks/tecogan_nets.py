@@ -275,7 +275,8 @@ class _StepPlan:
         built on stale data).  A host read of a pinned counter -- no synchronisation; after a
         synchronisation it covers everything enqueued so far.  Every tg_frnet_step* call makes the
         same check on entry, so a fault also surfaces on the NEXT call of any kind on this plan;
-        the plan then runs one launch per layer for the rest of its life."""
+        the plan then runs one launch per layer until it re-arms (set_chain_rearm: after 64 clean frames by default,
+        the wait doubling with every fault of a re-armed body)."""
         L.check(L.lib().tg_frnet_plan_chain_status(self.handle, None, None), 'chained SRNet launch')
 
     def chain_state(self):
@@ -283,6 +284,17 @@ class _StepPlan:
         f, a = ctypes.c_int(0), ctypes.c_int(0)
         L.lib().tg_frnet_plan_chain_status(self.handle, ctypes.byref(f), ctypes.byref(a))
         return f.value, bool(a.value)
+
+    def set_chain_rearm(self, first_after_frames):
+        """Frames on the per-layer fallback before a faulted one-launch body is tried again (0: never; default 64,
+        doubled by every fault of a re-armed body) -- tg_frnet_plan_set_chain_rearm."""
+        L.check(L.lib().tg_frnet_plan_set_chain_rearm(self.handle, int(first_after_frames)), 'tg_frnet_plan_set_chain_rearm')
+
+    def rearm_state(self):
+        """(times the one-launch body was armed again, back-off in force in frames)."""
+        r, w = ctypes.c_int(0), ctypes.c_int(0)
+        L.check(L.lib().tg_frnet_plan_chain_rearms(self.handle, ctypes.byref(r), ctypes.byref(w)), 'tg_frnet_plan_chain_rearms')
+        return r.value, w.value
 
     def __del__(self):
         try:
@@ -371,10 +383,13 @@ class FRNet(nn.Module):
         on_fault: what happens when a one-launch SRNet body (the LDS-resident / chained launch, whose workgroups wait
         for each other and therefore need the GPU to themselves) recorded a fault in this clip -- another tenant or a
         co-running stream kept part of the grid from starting.  The plan has then fallen back to one launch per layer
-        for good.  'rerun' (default): warn and compute the clip again on that path -- the caller gets correct frames,
+        (until it re-arms, _StepPlan.set_chain_rearm).  'rerun' (default): warn and compute the clip again on that path -- the caller gets correct frames,
         as from the reference, which has no such failure mode; 'raise': TecoganHipError.  With
         return_device_tensor=True nothing is synchronised, so a fault can only be REPORTED (at the next call's entry
-        or by check_faults() after the caller's own synchronisation): that mode always raises."""
+        or by check_faults() after the caller's own synchronisation): that mode always raises -- including here, at the
+        entry of the NEXT clip, whatever its on_fault says: the invalid device tensor is already in the caller's hands
+        (it used to be downgraded to this clip's rerun warning)."""
+        self.check_faults()          # a fault that belongs to an EARLIER clip is never this clip's to repair
         try:
             return self._infer_sequence(lr_data, device, pipeline, return_device_tensor)
         except L.TecoganHipError as e:

@@ -559,6 +559,64 @@ def test_resident_launch_fault_surfaces_and_falls_back(tmp_path):
     assert r.returncode == 0 and 'FAILSAFE-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+def test_resident_launch_recovers_from_a_transient_fault(tmp_path):
+    """VERDICT r5 item 7 / ADVICE r4 item 3: ONE injected fault (a transient co-tenant) must not cost the one-launch
+    body for the life of the process.  The plan falls back to one launch per layer, counts clean frames, arms the
+    resident launch again after the back-off (here 6 frames instead of the default 64), and a second fault doubles
+    the wait.  Frames are bit-identical on either path (TG_WINO_RES_CT=0: the first transposed conv a launch of its
+    own on both)."""
+    import subprocess
+    import sys
+    script = (
+        "import sys, torch, warnings; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from tests.test_hip_parity import make_net, smooth_clip\n"
+        "from tecogan_pytorch_amd import _lib\n"
+        "dev = torch.device('cuda', 0)\n"
+        "x = smooth_clip(5, 3, 40, 72, seed=5).cuda()\n"
+        "net, _ = make_net('BD', 4)\n"
+        "plan = net._get_plan(1, 40, 72, dev)\n"
+        "plan.set_chain_rearm(6)\n"
+        "limit = lambda v: _lib.check(_lib.lib().tg_frnet_plan_set_chain_poll_limit(plan.handle, v), 'limit')\n"
+        "ref = net.infer_sequence(x, dev)                       # healthy: resident body\n"
+        "assert plan.chain_state() == (0, True) and plan.rearm_state() == (0, 0)\n"
+        "def faulted_clip():\n"
+        "    limit(-1)\n"
+        "    with warnings.catch_warnings(record=True) as wl:\n"
+        "        warnings.simplefilter('always')\n"
+        "        y = net.infer_sequence(x, dev)                  # faults, is computed again on the fallback (5 clean frames)\n"
+        "    limit(1 << 21)\n"
+        "    assert any('computed again' in str(w_.message) for w_ in wl)\n"
+        "    return y\n"
+        "y = faulted_clip()\n"
+        "assert np.array_equal(y, ref), 'rerun differs'\n"
+        "f1, active = plan.chain_state(); assert f1 > 0 and not active, (f1, active)\n"
+        "assert plan.rearm_state() == (0, 6), plan.rearm_state()\n"
+        "y = net.infer_sequence(x, dev)                          # frames 6..10 on the fallback: the back-off passes inside this clip\n"
+        "assert np.array_equal(y, ref), 'fallback differs'\n"
+        "y = net.infer_sequence(x, dev)\n"
+        "assert np.array_equal(y, ref), 're-armed body differs'\n"
+        "f, active = plan.chain_state(); assert f == f1 and active, ('not re-armed', f, f1, active)\n"
+        "assert plan.rearm_state() == (1, 6), plan.rearm_state()\n"
+        "# the re-armed body really is the one launch again: a second injected fault is seen, and doubles the wait\n"
+        "y = faulted_clip()\n"
+        "assert np.array_equal(y, ref)\n"
+        "f2, active = plan.chain_state(); assert f2 > f1 and not active, (f2, f1, active)\n"
+        "assert plan.rearm_state() == (1, 12), plan.rearm_state()\n"
+        "for _ in range(2): assert np.array_equal(net.infer_sequence(x, dev), ref)     # 5 (rerun) + 10 clean frames >= 12\n"
+        "assert np.array_equal(net.infer_sequence(x, dev), ref)\n"
+        "assert plan.chain_state() == (f2, True) and plan.rearm_state() == (2, 12), (plan.chain_state(), plan.rearm_state())\n"
+        "# first_after_frames = 0: the round-5 behaviour, off for good\n"
+        "plan.set_chain_rearm(0)\n"
+        "y = faulted_clip()\n"
+        "for _ in range(8): assert np.array_equal(net.infer_sequence(x, dev), ref)\n"
+        "assert not plan.chain_state()[1] and plan.rearm_state()[0] == 2\n"
+        "print('REARM-OK')\n" % (ROOT_DIR, GOLDEN_DIR))
+    env = dict(os.environ, TG_WINO_RES='1', TG_CONV_WINO='1', TG_WINO_RES_CT='0')
+    r = subprocess.run([sys.executable, '-c', script], env=env, timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0 and 'REARM-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_chained_launch_fault_surfaces_on_every_path(tmp_path):
     """Fail-safe of the chained SRNet launch: with fault injection (negative poll limit: every waiting
     workgroup gives up at once) the error must surface (a) at infer_sequence's host-output exit,
