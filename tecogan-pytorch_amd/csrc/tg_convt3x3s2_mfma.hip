@@ -19,6 +19,7 @@
 // Replaces SRNet.conv_up (codes/models/networks/tecogan_nets.py:119-126).
 #include "tg_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace tg {
 
@@ -384,6 +385,338 @@ __global__ __launch_bounds__(512) void convt3x3s2_oneshot_kernel(ConvTArgs a) {
   }
 }
 
+
+// ---- Z mode on a large frame (inference's last up-sampling layer, 268x640 -> 536x1280): STREAMING form (round 6) ----
+// The tiled kernel above re-stages all 147 KB of weights through LDS for every 4-row x 32-pixel tile (1 340 times at
+// 268x640), meets at a barrier per 8-channel chunk, reduces the two output-channel halves through LDS behind two more
+// barriers, and quantises to 5.23 -> 6 tiles per CU: 149 us = 0.64 of the fp32-MFMA peak (22 % of the frame).
+// Here the 64x64x9 weights are LDS-RESIDENT for the whole launch (147 456 B of the 160 KB, copied once per CU, then
+// read-only: no barrier after the first) and every WAVE is an autonomous worker:
+//   * a work item = one input row x 32 pixels x ALL 64 output channels x one output-row parity py (the phase pair
+//     px = 0, 1): 4 accumulator tiles of 32x32 as before, but the two channel halves sit in the SAME wave, so the
+//     output conv's contraction (Z mode) needs no cross-wave reduction;
+//   * the B operand (input pixels) goes global -> registers (lanes 0-31 read 128 contiguous bytes of one channel,
+//     lanes 32-63 of the channel 4 above: the K permutation of the packed weights), prefetched one 8-channel chunk
+//     ahead; the A operand is one ds_read_b128 per (tap, channel half) of the resident weights, as in the tiled kernel;
+//   * items are pulled from an atomic counter, the 6-tap items (py = 1) first, the 3-tap items (py = 0) last: the
+//     tail of the launch is one small item, and a workgroup that starts late (LDS held by a co-running kernel of the
+//     flow stream) simply finds less work -- 10 720 items on 3 072 workers at 268x640;
+//   * per phase the same taps in the same order over the same ascending chunks as the tiled kernel, the two halves'
+//     contraction sums added in its order: results are BIT-IDENTICAL to convt3x3s2_mfma_kernel<.,.,true>.
+// The counter pair {next item, finished waves} lives in a device-global slot the host rotates per launch; the last wave
+// to finish puts the slot back to zero.
+#ifndef ZS_ABL
+#define ZS_ABL 0     // lab builds (TG_LAB), timing only: 1 no B loads after an item's first chunk, 2 no contraction / stores, 4 no A reads after the first tap
+#endif
+#if !TG_LAB && ZS_ABL
+#error "tg_convt3x3s2_mfma.hip: ZS_ABL needs -DTG_LAB=1 (lab builds only; the ablated kernel computes wrong results)"
+#endif
+constexpr int ZS_WAVES = 12;
+constexpr int ZS_THREADS = ZS_WAVES * 64;
+constexpr int ZS_W_FLOATS = 9 * 64 * 64;                  // the packed weights, verbatim: [chunk 8][tap 9][half 2][oc 64][4]
+constexpr int ZS_WZ_OFF = ZS_W_FLOATS;                    // [oc half 2][step 16][lane 64]
+constexpr int ZS_BIAS_OFF = ZS_WZ_OFF + 2 * 16 * 64;
+constexpr size_t ZS_LDS_BYTES = (size_t)(ZS_BIAS_OFF + 64) * sizeof(float);    // 155 904 of 163 840 (+ 2.2 KB static: the batch ring)
+constexpr int ZS_RING = 256;                              // batches a wave may lag behind the newest one
+constexpr int ZS_SLOTS = 64;
+__device__ unsigned g_zs_slot[ZS_SLOTS][2];
+
+template <int PY>
+__device__ __forceinline__ void zs_item(const ConvTArgs& a, const float* s_w, int n, int y, int x0, int lane) {
+  constexpr int NB = PY ? 4 : 2;                           // B vectors per chunk: b00 b01 (b10 b11)
+  const int lh = lane >> 5, ll = lane & 31;
+  const int hw = a.h * a.w;
+  const unsigned plane = (unsigned)hw * 4u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x + (long long)n * a.x_ns), 0, a.cin * hw * 4, 0x00020000);
+  // per-lane byte offsets of the window rows inside channel 4 lh of chunk 0 (out of the image: a zero).  Pixels x and
+  // x + 1 of a row come as ONE 8-byte load (b00 | b01, b10 | b11): half the load instructions of the first form; the
+  // x + 1 value of the image's last column would be the next row's first pixel and is zeroed by hand.
+  constexpr int NR = NB / 2;
+  unsigned vo[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int gy = y + i, gx = x0 + ll;
+    vo[i] = (gy < a.h && gx < a.w) ? (unsigned)(4 * lh) * plane + (unsigned)(gy * a.w + gx) * 4u : TOOB;
+  }
+  const bool edge = x0 + ll + 1 >= a.w;                    // this lane's x + 1 is outside the row
+  const bool edge_tile = x0 + TTW >= a.w;                  // uniform: only the last tile of a row has such lanes
+  f32x4 bq[3][NB];                                        // three chunks of the B operand in flight (see the K loop)
+  auto load_b = [&](int ch, f32x4 (&b)[NB]) {
+    const unsigned cb = (unsigned)(ch * CK) * plane;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(vo[i] + (unsigned)kk * plane), (int)cb, 0);
+        const unsigned v0 = v[0], v1 = v[1];
+        b[2 * i][kk] = __builtin_bit_cast(float, v0);
+        b[2 * i + 1][kk] = __builtin_bit_cast(float, v1);
+      }
+  };
+  auto fix_edge = [&](f32x4 (&b)[NB]) {
+    if (edge_tile) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b[2 * i + 1][kk] = edge ? 0.f : b[2 * i + 1][kk];
+    }
+  };
+  f32x16 acc[4];                                           // [phase px 0 | 1][oc half 0 | 1]
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  const float* sa = s_w + (lh * TOCB + ll) * 4;
+  // The A operand of tap t + 1 is requested before the MFMAs of tap t (two register sets): the compiler left to itself
+  // hoists all 12 reads of a chunk (48 registers) and spills.
+  auto lda = [&](const float* sw, int tap, f32x4 (&av)[2]) {
+    av[0] = *reinterpret_cast<const f32x4*>(sw + tap * (2 * TOCB * 4));
+    av[1] = *reinterpret_cast<const f32x4*>(sw + tap * (2 * TOCB * 4) + 32 * 4);
+  };
+  auto mm = [&](int q, const f32x4 (&av)[2], const f32x4& bv) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        acc[q * 2 + hf] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[hf][kk], bv[kk], acc[q * 2 + hf], 0, 0, 0);
+  };
+  f32x4 ab[2][2];                                          // [register set][oc half]
+  // (q, tap, B vector) in the tiled kernel's order per phase
+  constexpr int NT = PY ? 6 : 3;
+  constexpr int TQ[6] = {0, PY ? 0 : 1, 1, 1, 1, 1};
+  constexpr int TT[6] = {PY ? 1 : 4, PY ? 7 : 3, PY ? 0 : 5, 2, 6, 8};
+  constexpr int TB[6] = {PY ? 2 : 0, PY ? 0 : 1, PY ? 3 : 0, 2, 1, 0};
+  // PAR: the register set that holds this chunk's first tap on entry
+  auto chunk = [&](int ch, const f32x4 (&b)[NB], bool last, auto par) {
+    constexpr int PAR = decltype(par)::value;
+    const float* sw = sa + ch * (9 * CK * TOCB);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (ZS_ABL & 4) { if (ch == 0 && t == 0) lda(sw, TT[1], ab[1]); }
+      else if (t + 1 < NT) lda(sw, TT[t + 1], ab[(PAR + t + 1) & 1]);
+      else if (!last) lda(sw + 9 * CK * TOCB, TT[0], ab[(PAR + t + 1) & 1]);      // the next chunk's first tap
+      mm(TQ[t], ab[(PAR + t) & 1], b[TB[t]]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // The K loop, fully unrolled over the (at most 8) chunks with compile-time register sets.  The B operand is requested
+  // TWO chunks ahead: one chunk of a 3-tap item is only 24 MFMAs, and with the request one chunk ahead the waits for
+  // first-touch (HBM) lines cost 13 of the launch's 145 us (tools/abl_convtz.sh, round 6).
+  load_b(0, bq[0]);
+  if (1 < a.nchunk && !(ZS_ABL & 1)) load_b(1, bq[1]);
+  if ((ZS_ABL & 1)) { load_b(1, bq[1]); load_b(2, bq[2]); }
+  lda(sa, TT[0], ab[0]);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c < a.nchunk) {
+      if (c + 2 < a.nchunk && !(ZS_ABL & 1)) load_b(c + 2, bq[(c + 2) % 3]);
+      fix_edge(bq[c % 3]);
+      if ((c * NT) & 1) chunk(c, bq[c % 3], c + 1 >= a.nchunk, std::integral_constant<int, 1>{});
+      else chunk(c, bq[c % 3], c + 1 >= a.nchunk, std::integral_constant<int, 0>{});
+    }
+  }
+  // ---- bias + activation, the output conv's contraction over the 64 channels, 8-byte stores of the tap planes ----
+  const float slope = act_slope(a.act);
+  const float* s_wz = s_w + ZS_WZ_OFF + lane;
+  const float* s_b = s_w + ZS_BIAS_OFF + 4 * lh;
+  const int px = x0 + ll;
+  const bool inimg = px < a.w;
+  const int ow = 2 * a.w;
+  const int ohw = 4 * hw;
+  // One contraction chain per (phase, channel half) -- the halves added in the tiled kernel's order, wn 0 + wn 1 -- with
+  // the two chains of a phase interleaved (a chain's MFMAs depend on each other) and the operands of four MFMAs
+  // prepared ahead of them (VALU -> MFMA hazard distance).  Round-6 anatomy (tools/abl_convtz.sh): this epilogue cost
+  // 29 us of the launch's 145 for 18 us of MFMA work in its first form (one chain at a time, 4 VALU per element,
+  // sixteen divergent branches around the stores).
+  const bool relu = slope == 0.f;                          // launch-uniform
+  auto actv = [&](float t) { return relu ? fmaxf(t, 0.f) : (t >= 0.f ? t : t * slope + 0.f); };
+  // bias + activation in place (no new registers), then the chains straight out of the accumulators
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = actv(acc[p][r] + s_b[(p & 1) * 32 + (r & 3) + 8 * (r >> 2)]);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 zq[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    f32x16 za, zb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { za[r] = 0.f; zb[r] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      za = __builtin_amdgcn_mfma_f32_32x32x2f32(s_wz[r * 64], acc[q * 2][r], za, 0, 0, 0);
+      zb = __builtin_amdgcn_mfma_f32_32x32x2f32(s_wz[(16 + r) * 64], acc[q * 2 + 1][r], zb, 0, 0, 0);
+    }
+    zq[q] = za + zb;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    // 32-bit buffer offsets (the planes of one image are 32 x 4 hw floats < 4 GiB: checked by the launcher): the lane part
+    // once, the plane of step r as the instruction's scalar offset -- 64-bit addresses per plane cost 32 registers.  Rows
+    // past zrows and pixels past the image edge get an offset beyond the descriptor's range: the store is dropped.
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+        a.z + (long long)n * a.z_ns, 0, (int)(32u * (unsigned)ohw * 4u), 0x00020000);
+    const unsigned zo = inimg ? ((unsigned)(4 * lh) * (unsigned)ohw + (unsigned)((2 * y + PY) * ow + 2 * px)) * 4u : TOOB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mb = (r & 3) + 8 * (r >> 2);
+      if (mb >= 27) continue;                              // (step 15 holds rows 27 and 31: zrows <= 27, never stored)
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      // (locals first: __builtin_bit_cast of a vector ELEMENT expression reads element 0 whatever the index -- found
+      // in the ISA: sixteen stores of the same pair)
+      const float e0 = zq[0][r], e1 = zq[1][r];
+      const u32x2 v = {__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1)};
+      const unsigned off = (mb + 4 * lh < a.zrows) ? zo : TOOB;
+      __builtin_amdgcn_raw_buffer_store_b64(v, rz, (int)off, (int)((unsigned)mb * (unsigned)ohw * 4u), 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(ZS_THREADS) void convt3x3s2_z_stream_kernel(ConvTArgs a, int n_img, int slot, int* err,
+                                                                         int poll_limit) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];
+  __shared__ unsigned s_ring[ZS_RING][2];
+  __shared__ unsigned s_ready, s_done, s_prog[ZS_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the workgroup's first batch of items is requested before anything else: the round trip to the device-wide counter
+  // (microseconds when 256 workgroups start together) passes under the copy of the weights
+  unsigned first_gs = 0u;
+  if (slot >= 0 && tid == 0) {
+    unsigned size = (unsigned)(2 * n_img * a.h * a.tiles_x) / (3u * gridDim.x);
+    size = size < 4u ? 4u : (size > 24u ? 24u : size);
+    first_gs = (atomicAdd(g_zs_slot[slot], size) << 5) | size;
+  }
+  // ---- the resident operands: weights (zero-filled past nchunk), contraction operand, bias ----
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.wpk);
+    f32x4* dst = reinterpret_cast<f32x4*>(s_w);
+    const int nv = a.nchunk * (9 * CK * TOCB) / 4;
+    for (int i = tid; i < nv; i += ZS_THREADS) dst[i] = src[i];
+    for (int i = tid; i < 2 * 16 * 64; i += ZS_THREADS) s_w[ZS_WZ_OFF + i] = a.wz[i];
+    if (tid < 64) s_w[ZS_BIAS_OFF + tid] = (a.bias && tid < a.cout) ? a.bias[tid] : 0.f;
+    if (tid == 64) { s_ready = 0u; s_done = 0u; }
+    if (tid >= 128 && tid < 128 + ZS_WAVES) s_prog[tid - 128] = 0u;
+  }
+  __syncthreads();
+  const int per_par = n_img * a.h * a.tiles_x;             // items of one parity
+  const int nitems = 2 * per_par;
+  const int nwg = gridDim.x;
+  auto run = [&](int item) {
+    const int py = item < per_par ? 1 : 0;                 // the 6-tap items first
+    int r = item - (py ? 0 : per_par);
+    const int tx = r % a.tiles_x; r /= a.tiles_x;
+    const int y = r % a.h;
+    const int n = r / a.h;
+    if (py) zs_item<1>(a, s_w, n, y, tx * TTW, lane);
+    else zs_item<0>(a, s_w, n, y, tx * TTW, lane);
+  };
+  if (slot < 0) {
+    // static list, balanced per SIMD: the three waves of a SIMD share its matrix pipe, so what has to be equal is the
+    // SIMD's total.  6-tap items (7 cost units with their contraction) are dealt round-robin over the S SIMDs; the
+    // SIMDs that got one fewer of them receive one 3-tap item (4 units) each ahead of the round-robin deal of the
+    // rest, which also starts with them.  268x640 on 1024 SIMDs: 3712 / 3776 / 3520 MFMAs per SIMD (average 3685)
+    // instead of 3968 / 3776 / 3520 from a plain round-robin; a SIMD's list is dealt to its waves in turn.
+    const int S = nwg * 4, sig = blockIdx.x * 4 + ((tid >> 6) & 3), slot3 = tid >> 8;
+    const int nbig = per_par, nsmall = per_par;
+    const int X = nbig % S;                                // SIMDs [0, X) hold one 6-tap item more
+    const int comp = X ? S - X : 0;                        // compensation items, one per light SIMD
+    const int nb = (nbig - sig + S - 1) / S;               // this SIMD's 6-tap items
+    const bool light = X && sig >= X;
+    for (int p = slot3;; p += 3) {
+      int item;
+      if (p < nb) item = sig + S * p;
+      else {
+        int q = p - nb, j;
+        if (light && q == 0) j = sig - X;
+        else {
+          if (light) q -= 1;
+          j = comp + q * S + (sig - X + S) % S;
+        }
+        if (j >= nsmall) break;
+        item = nbig + j;
+      }
+      run(item);
+    }
+    return;
+  }
+  // ---- dynamic list.  A device-wide atomic costs microseconds on this part (measured: one per item, 10 720 of them,
+  // adds 55 us to the launch), so the counter hands out BATCHES of items to workgroups -- ~900 atomics per launch.
+  // Inside a workgroup a batch is dealt round-robin to the 12 waves (the deal continues across batches, so every
+  // wave gets the same number of items +- 1), without a barrier: batch k is published in an LDS ring by the wave
+  // (k mod 12), one batch AHEAD of its use (nobody waits for the round trip in steady state); a wave that reaches
+  // batch k before it is published polls the publication count.  Batch sizes shrink with the items left (guided
+  // self-scheduling, 4..24).  Every poll is bounded: on a time-out the wave counts a fault in pinned host memory and
+  // leaves (the launcher then reports TG_E_HIP at the next call and keeps to the tiled form).
+  const int wv = tid >> 6;
+  unsigned* const ctr = g_zs_slot[slot];
+  auto request = [&](unsigned lastg) -> unsigned {         // one batch from the device-wide counter: (start << 5) | size
+    const unsigned left = (unsigned)nitems > lastg ? (unsigned)nitems - lastg : 0u;
+    unsigned size = left / (3u * (unsigned)nwg);
+    size = size < 4u ? 4u : (size > 24u ? 24u : size);
+    return (atomicAdd(ctr, size) << 5) | size;
+  };
+  // ring entry k % ZS_RING: {start, size | (first wave of the deal) << 8 | terminal << 16}
+  auto publish = [&](int k, unsigned gs, unsigned rot) {
+    const unsigned g = gs >> 5, size = gs & 31u;
+    const bool term = g >= (unsigned)nitems;
+    const unsigned n_here = term ? 0u : ((g + size < (unsigned)nitems) ? size : (unsigned)nitems - g);
+    s_ring[k % ZS_RING][0] = g;
+    s_ring[k % ZS_RING][1] = n_here | (rot << 8) | ((term ? 1u : 0u) << 16);
+    __hip_atomic_store(&s_ready, (unsigned)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  if (tid == 0) publish(0, first_gs, 0u);
+  __syncthreads();
+  bool fault = false;
+  for (int k = 0; !fault; ++k) {
+    // batch k (published at the latest by the wave that is about to ask for batch k + 1 ... or by the prologue)
+    if (lane == 0) {
+      int polls = 0;
+      while (__hip_atomic_load(&s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= (unsigned)k) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++polls > poll_limit) { fault = true; break; }
+      }
+    }
+    fault = __builtin_amdgcn_readfirstlane((int)fault) != 0;
+    if (fault) break;
+    const unsigned g = s_ring[k % ZS_RING][0], meta = s_ring[k % ZS_RING][1];
+    const int n_here = (int)(meta & 255u), rot = (int)((meta >> 8) & 255u);
+    if (meta >> 16) break;                                 // the list is exhausted
+    // the wave whose turn it is asks for batch k + 1 before it works on batch k
+    if (wv == (k + 1) % ZS_WAVES) {
+      if (k + 1 >= ZS_RING && lane == 0) {                 // (never in practice: nobody may still be ZS_RING batches behind)
+        int polls = 0;
+        for (;;) {
+          unsigned lo = 0xFFFFFFFFu;
+          for (int w2 = 0; w2 < ZS_WAVES; ++w2) { const unsigned pv = __hip_atomic_load(&s_prog[w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); lo = pv < lo ? pv : lo; }
+          if ((unsigned)(k + 1) < lo + (unsigned)ZS_RING) break;
+          __builtin_amdgcn_s_sleep(8);
+          if (++polls > poll_limit) { fault = true; break; }
+        }
+      }
+      fault = __builtin_amdgcn_readfirstlane((int)fault) != 0;
+      if (fault) break;
+      unsigned gs = 0u;
+      if (lane == 0) gs = request(g);
+      gs = (unsigned)__builtin_amdgcn_readfirstlane((int)gs);
+      if (lane == 0) publish(k + 1, gs, (unsigned)((rot + n_here) % ZS_WAVES));
+    }
+    if (lane == 0) __hip_atomic_store(&s_prog[wv], (unsigned)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // this wave's share of batch k: positions p with (rot + p) % 12 == wv
+    for (int pos = (wv - rot + ZS_WAVES) % ZS_WAVES; pos < n_here; pos += ZS_WAVES) run((int)g + pos);
+  }
+  if (fault && lane == 0 && err) __hip_atomic_fetch_add(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // the last wave of the launch hands the counter slot back clean (one count per workgroup)
+  if (lane == 0 && __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == ZS_WAVES - 1) {
+    __threadfence();
+    if (atomicAdd(ctr + 1, 1u) == (unsigned)nwg - 1u) {
+      atomicExch(ctr, 0u);
+      atomicExch(ctr + 1, 0u);
+    }
+  }
+}
+
 // A operand of the Z-mode contraction: wz[(half*16 + r)*64 + l] = Wout[o][c][tap] for tap-plane
 // row m = l & 31 (m = tap*cz + o < 9*cz, else 0) and channel c = half*32 + (r&3) + 8*(r>>2) +
 // 4*(l>>5) (< nf, else 0).  Wout is the output conv's OIHW weight (cz, nf, 3, 3).
@@ -555,6 +888,15 @@ extern "C" int tg_convt3x3s2_z_fwd(const float* x, int64_t x_nstride, const floa
                                    const float* bias, const float* wz, int cz, float* z,
                                    int64_t z_nstride, int n, int cin, int cout, int h, int w, int act,
                                    tg_stream_t stream) {
+  static const int form_env = TG_LAB_ENV("TG_CONVTZ_FORM", -1);     // lab builds: A/B of the forms through the frame plan
+  return tg_convt3x3s2_z_fwd_form(x, x_nstride, w_packed, bias, wz, cz, z, z_nstride, n, cin, cout, h, w, act, form_env, stream);
+}
+
+extern "C" int tg_convt3x3s2_z_fwd_form(const float* x, int64_t x_nstride, const float* w_packed,
+                                        const float* bias, const float* wz, int cz, float* z,
+                                        int64_t z_nstride, int n, int cin, int cout, int h, int w, int act,
+                                        int form, tg_stream_t stream) {
+  TG_REQUIRE(form >= -1 && form <= 2, TG_E_ARG, "convt3x3s2_z_fwd_form: form=%d (-1 auto, 0 tiled, 1 streaming, 2 streaming with a static item list)", form);
   TG_REQUIRE(x && w_packed && wz && z, TG_E_ARG, "convt3x3s2_z_fwd: null pointer");
   TG_REQUIRE(n > 0 && cin > 0 && cout > 0 && cout <= 64 && h > 0 && w > 0 && cz >= 1 && 9 * cz <= 32,
              TG_E_SHAPE, "convt3x3s2_z_fwd: n=%d cin=%d cout=%d (<=64) h=%d w=%d cz=%d (<=3)", n, cin, cout, h, w, cz);
@@ -568,6 +910,52 @@ extern "C" int tg_convt3x3s2_z_fwd(const float* x, int64_t x_nstride, const floa
   constexpr int WN = 2;
   static const int rows_env = TG_LAB_ENV("TG_CONVTZ_ROWS", 0);
   a.tiles_x = cdiv(w, TTW); a.nocg = 1; a.nchunk = cdiv(cin, CK);
+  // the streaming form (weights LDS-resident, autonomous waves) wherever every wave of the chip finds a few items
+  {
+    const int stream_env = form;
+    static int ncu = -1;
+    static bool attr_ok = false;
+    if (ncu < 0) {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ncu = v;
+      else { (void)hipGetLastError(); ncu = 0; }
+      attr_ok = ncu > 0 && hipFuncSetAttribute(reinterpret_cast<const void*>(convt3x3s2_z_stream_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_LDS_BYTES) == hipSuccess;
+      if (!attr_ok) (void)hipGetLastError();
+    }
+    // fail-safe of the streaming form's polls: a fault counter in pinned host memory, looked at on entry
+    static int* zs_err = nullptr;
+    static bool zs_off = false;
+    if (attr_ok && !zs_err && !zs_off) {
+      void* hp = nullptr;
+      if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hp) { zs_err = static_cast<int*>(hp); *zs_err = 0; }
+      else { (void)hipGetLastError(); zs_off = true; }
+    }
+    if (zs_err && __atomic_load_n(zs_err, __ATOMIC_RELAXED) != 0) {
+      const int f = __atomic_exchange_n(zs_err, 0, __ATOMIC_RELAXED);
+      zs_off = true;
+      tg::set_error("convt3x3s2_z (streaming form): %d wave(s) timed out waiting for a batch of work items; the planes written "
+                    "by launches since the previous call are INVALID.  The tiled form is used from now on", f);
+      return TG_E_HIP;
+    }
+    const long long items = 2ll * n * h * a.tiles_x;
+    const bool fits = attr_ok && !zs_off && zs_err && cin <= 64 && cout <= 64 && items < (1ll << 30) && 32ll * 4 * h * w * 4 < (1ll << 31);
+    TG_REQUIRE(form < 1 || fits, TG_E_SHAPE, "convt3x3s2_z_fwd_form: the streaming form needs cin, cout <= 64 and 160 KB of LDS");
+    // The rule keeps the TILED form (round 6, EXPERIMENTS.md): stand-alone the streaming form with the static item list
+    // is 3 % faster at 268x640 (143.5 vs 148 us), through the whole frame it is +-0 (1463-1467 vs 1462 frames/s), and
+    // its dynamic list -- the form that is robust against a co-running kernel holding CUs -- is 12 % slower (the
+    // device-wide counter).  Both stay selectable (form 1 / 2) and are tested bit-identical to the tiled form.
+    const bool want = stream_env > 0;
+    (void)ncu;
+    if (fits && want) {
+      static unsigned seq = 0;
+      const int slot = form == 2 ? -1 : (int)(seq++ % ZS_SLOTS);
+      const int grid = (int)(items / ZS_WAVES < ncu ? cdiv((int)items, ZS_WAVES) : ncu);
+      hipLaunchKernelGGL(convt3x3s2_z_stream_kernel, dim3((unsigned)grid), dim3(ZS_THREADS), ZS_LDS_BYTES,
+                         (hipStream_t)stream, a, n, slot, zs_err, 1 << 20);
+      return check_launch("convt3x3s2_z_stream");
+    }
+  }
   // same balance rule as tg_convt3x3s2_fwd (at 268x640, 1340 four-row workgroups, the two-row form
   // measured 153 vs 148 us: more workgroups than slots are balanced by the dispatcher anyway)
   const long long wg4 = (long long)a.tiles_x * cdiv(h, 4) * n;

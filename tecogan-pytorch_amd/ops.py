@@ -232,6 +232,29 @@ def convt3x3s2(x, wpk, bias, cout, act=ACT_NONE, out=None):
     return out
 
 
+def convt_pack_wz(w_out_oihw):
+    """tg_convt_pack_wz: the output conv's (cz, nf, 3, 3) weight as the A operand of the Z-mode contraction."""
+    _chk(w_out_oihw, 'w_out')
+    cz, nf = w_out_oihw.shape[:2]
+    wz = torch.empty(2 * 16 * 64, dtype=torch.float32, device=w_out_oihw.device)
+    L.check(L.lib().tg_convt_pack_wz(w_out_oihw.data_ptr(), wz.data_ptr(), cz, nf, _stream()), 'tg_convt_pack_wz')
+    return wz
+
+
+def convt3x3s2_z(x, wpk, bias, wz, cz, cout, act=ACT_NONE, form=-1, out=None):
+    """tg_convt3x3s2_z_fwd_form: ConvTranspose2d(cin, cout, 3, 2, 1, 1) + act with the following 3x3 output conv's
+    channel contraction in the epilogue -> (n, 32, 2h, 2w) buffer whose first 9 * cz planes are the output conv's tap
+    planes (tecogan_nets.py:119-131).  form: -1 the library rule, 0 tiled, 1 streaming, 2 streaming with a static item list (all bit-identical)."""
+    _chk(x, 'x')
+    n, cin, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, 32, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tg_convt3x3s2_z_fwd_form(x.data_ptr(), cin * h * w, wpk.data_ptr(), _ptr(bias), wz.data_ptr(), cz,
+                                             out.data_ptr(), 32 * 4 * h * w, n, cin, cout, h, w, act, form, _stream()),
+            'tg_convt3x3s2_z_fwd_form')
+    return out
+
+
 def conv3x3_fewin_ok(x, cout, any_size=False):
     """whether tg_conv3x3_fewin_fwd takes the launch -- and pays: below one 4 x 64 tile per CU the MFMA
     kernel is faster (2 x 128 x 128: 8.7 against 11.2 us; 2 x 256 x 256: 27.9 against 18.8 us)"""

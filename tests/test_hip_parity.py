@@ -761,6 +761,35 @@ def test_convt3x3s2_mfma(ops, n, cin, cout, h, w):
     assert out.shape == ref.shape and err(out, ref) <= 1e-5, err(out, ref)
 
 
+@pytest.mark.parametrize('n,cin,cout,cz,h,w', [(1, 64, 64, 3, 12, 20), (2, 64, 64, 3, 7, 35), (1, 64, 64, 3, 33, 64),
+                                               (1, 40, 48, 2, 9, 33), (2, 64, 64, 1, 21, 70), (1, 64, 64, 3, 70, 130)])
+def test_convt_z_forms_are_bit_identical_and_match_the_composition(ops, n, cin, cout, cz, h, w):
+    """tg_convt3x3s2_z_fwd_form: the last up-sampling layer + the output conv's channel contraction (Z mode,
+    tecogan_nets.py:119-131).  The streaming form (round 6: weights LDS-resident, autonomous waves, atomic work
+    counter) must equal the tiled form BIT FOR BIT on ragged shapes (w not a multiple of 32, odd h, n = 2, fewer
+    channels), three launches in a row (the work counter's slot is handed back clean by the last wave), and both must be the
+    reference composition: plane[tap * cz + o] = sum_c Wout[o, c, tap] * relu(convT(x))[c]."""
+    import torch.nn.functional as F
+    x = rs(1, (n, cin, h, w), -1, 1)
+    wt = rs(2, (cin, cout, 3, 3), -1, 1) / (1.5 * cin ** 0.5)
+    b = rs(3, (cout,), -0.5, 0.5)
+    wo = rs(4, (cz, cout, 3, 3), -1, 1) / (3.0 * cout ** 0.5)
+    up = torch.relu(F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=2, padding=1, output_padding=1))
+    ref = torch.einsum('octk,nchw->ntkohw', wo.double().reshape(cz, cout, 3, 3), up).reshape(n, 9 * cz, 2 * h, 2 * w)
+    pk, _, _, _ = ops.pack_conv3x3(dev(wt), transposed=True)
+    wz = ops.convt_pack_wz(dev(wo))
+    xd, bd = dev(x), dev(b)
+    tiled = ops.convt3x3s2_z(xd, pk, bd, wz, cz, cout, act=1, form=0)
+    assert err(tiled[:, :9 * cz], ref) <= 1e-5, err(tiled[:, :9 * cz], ref)
+    for rep in range(4):
+        out = torch.full((n, 32, 2 * h, 2 * w), 7.0, device='cuda')
+        ops.convt3x3s2_z(xd, pk, bd, wz, cz, cout, act=1, form=2 if rep == 3 else 1, out=out)     # (2: static item list)
+        assert torch.equal(out[:, :9 * cz], tiled[:, :9 * cz]), (rep, (out[:, :9 * cz] - tiled[:, :9 * cz]).abs().max().item())
+        assert bool((out[:, 9 * cz:] == 7.0).all()), 'the streaming form wrote outside its planes'
+    auto = ops.convt3x3s2_z(xd, pk, bd, wz, cz, cout, act=1)
+    assert torch.equal(auto[:, :9 * cz], tiled[:, :9 * cz])
+
+
 @pytest.mark.parametrize('cin,cout,h,w,act,up', [
     (32, 2, 16, 40, 3, None), (64, 3, 48, 80, 0, ('BD', 4)), (64, 3, 44, 132, 0, ('BI', 2)),
     (64, 3, 20, 36, 0, ('BD', 2)), (9, 4, 7, 5, 1, None), (64, 1, 17, 70, 0, None)])
