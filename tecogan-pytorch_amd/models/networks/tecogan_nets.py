@@ -321,7 +321,8 @@ class FRNet(nn.Module):
         # under the rest of the sweep (train_graph.Tape.flush_deferred_async).  Off: the weight-gradient
         # kernel holds a whole CU per workgroup (464 registers, 107 KB LDS), so on one GPU nothing of
         # the sweep runs beside it and the second flush only adds launches (measured: 24.5 vs 24.8 ms).
-        self.wgrad_side_stream = False
+        # round 6: an int = that many hand-over points spread over the sweep (TG_WGRAD_SIDE, read at construction)
+        self.wgrad_side_stream = int(os.environ.get('TG_WGRAD_SIDE', '0') or 0)
 
     # -- plan cache ---------------------------------------------------------
     def _weights_key(self):
@@ -605,8 +606,10 @@ class FRNet(nn.Module):
         bi_fm = ops.upsample(lr_fm.view(t * n, c, h, w), s, self.srnet.up_mode()).view(t, n, c, s * h, s * w)
         hr_prev = self.srnet(lr_fm[0], zeros, tape=tape, bi=bi_fm[0])
         frames.append(hr_prev)
+        k_side = int(self.wgrad_side_stream) if tape.side is not None else 0
+        flush_at = {max(1, round(t * j / (k_side + 1))) for j in range(1, k_side + 1)} if k_side else set()
         for i in range(1, t):
-            if tape.side is not None and i == (t + 1) // 2:
+            if i in flush_at:
                 # recorded BEFORE frame i's nodes => runs right after frames t-1 .. i have been swept:
                 # their weight gradients start on the side stream under the sweep of frames i-1 .. 0
                 tape.record(tape.flush_deferred_async)

@@ -380,6 +380,14 @@ class _ChainState:
         return cls.parts(n, h, w) > 0
 
 
+def _distributed_world():
+    try:
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    except ImportError:
+        return 1
+
+
 def guard_available(optim):
     """The device-side guard of the chained launches' fail-safe exists for this optimiser: its flat gradient buffer
     (with the fault slot behind the last tensor) is still what the parameters' .grad views point into."""
@@ -402,6 +410,16 @@ def stamp_fault(optim):
     if guard_available(optim):
         ops.fault_to_slot(err, optim.fault_slot)
         return
+    # An optimiser that HAD its flat buffer at construction (every rank compared that: BaseModel.agreement_vector) and
+    # lost it on this rank only -- `p.grad = None`, a `net.to()` -- would enter the synchronous protocol below, whose
+    # max-all-reduce the other ranks never join: a hang.  A loud rank-local error instead (the peers then fail in RCCL's
+    # own time-out rather than waiting for ever).
+    if getattr(optim, 'fault_slot', None) is not None and _distributed_world() > 1:
+        from .. import _lib as L_
+        raise L_.TecoganHipError(
+            'an optimiser of a data-parallel run lost its flat gradient buffer on this rank (the .grad views were '
+            'replaced): the device-side fault guard and the one-collective gradient exchange are rank-symmetric by '
+            'construction -- rebuild the optimiser on every rank (Adam(..., flatten=True)) instead')
     if not _ChainState.dirty:
         return
     if torch.cuda.is_available():

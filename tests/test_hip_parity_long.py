@@ -141,6 +141,42 @@ def test_bench_path_fullsize_clip_vs_oracle(deg, s, h, w, frames):
         assert dp <= 1e-3, (t, dp)
 
 
+def test_resident_launch_with_convt_tail_fullsize_step_vs_oracle():
+    """VERDICT r5 item 8 (second half): the resident launch's transposed-conv tail at the FULL 134x320 frame against the
+    ORACLE (not against the stand-alone kernel): one FRNet.step through the frame plan in its default form -- the plan's
+    launch list must hold ONE resident launch and NO separate first transposed conv -- on a frame with real motion,
+    fp32 values within 2e-4 of oracle.frnet_step and |dPSNR| <= 1e-3 dB."""
+    import ctypes
+    from tecogan_pytorch_amd import _lib as L
+    from tecogan_pytorch_amd.models.networks import FRNet
+    deg, s, h, w = 'BD', 4, 134, 320
+    net = FRNet(3, 3, 64, 10, deg, s)
+    sd = generator_state_dict(scale=s, degradation=deg)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    clip = smooth_clip(2, 3, h, w, seed=57, shift=1.1)
+    hp = O.upsample(clip[0:1], s, deg)                       # a plausible previous HR frame
+    with torch.no_grad():
+        out = net.step(clip[1:2].cuda(), clip[0:1].cuda(), hp.cuda())
+    torch.cuda.synchronize()
+    net.check_faults()
+    plan = net._get_plan(1, h, w, torch.device('cuda', 0))
+    lib, names = L.lib(), {}
+    for k in range(lib.tg_frnet_plan_kinds()):
+        nl = ctypes.c_int()
+        L.check(lib.tg_frnet_plan_kind_stats(plan.handle, k, ctypes.byref(nl), None, None), 'kind_stats')
+        names[lib.tg_frnet_kind_name(k).decode()] = nl.value
+    assert names['conv3x3_wino_resident_kernel'] == 1, names
+    assert names['convt3x3s2_mfma_kernel'] == 0 and names['convt3x3s2_mfma_kernel<Z>'] == 1, names   # the first transposed conv rode on the resident launch
+    assert plan.chain_state() == (0, True)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = O.frnet_step(sd, clip[1:2], clip[0:1], hp, s, deg)
+    e = (out.cpu() - ref).abs().max().item()
+    assert e <= 2e-4, e
+    gt = O.upsample(clip[1:2], s, deg).numpy()
+    assert abs(O.psnr_float(out.cpu().numpy(), gt) - O.psnr_float(ref.numpy(), gt)) <= 1e-3
+
+
 # ---------------------------------------------------- full-size training step
 WATCH_G = ['fnet.encoder1.0.weight', 'fnet.decoder1.2.bias', 'fnet.flow.2.weight',
            'srnet.conv_in.0.weight', 'srnet.resblocks.4.conv.2.weight', 'srnet.conv_up.2.weight',
@@ -188,7 +224,11 @@ GRAD_ABS_CAP = 2e-2      # no watched gradient may be further than this (relativ
 
 
 def _fp64_factor(name):
-    return 4.0 if name.startswith('fnet.') else 2.0
+    # round 6: three runs of the same iteration agree to three digits (profiles/r06_train_grad_triangulation_crop*.json:
+    # ratios 2.07 ... 3.09 for FNet at both crops, identical run to run) -- the excess over the oracle is systematic
+    # (summation order of the flow path's transposes through 18 BPTT steps), not run-to-run noise; 3.5 = 13 % above the
+    # largest measured ratio
+    return 3.5 if name.startswith('fnet.') else 2.0
 
 
 def _rel_l2(a, b):
