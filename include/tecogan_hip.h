@@ -390,6 +390,13 @@ int tg_convout_tail(const float* z, int64_t z_nstride, int cz, const float* bias
                     const float* up_src, int up_mode, int up_scale, float* y,
                     int64_t y_nstride, uint8_t* u8_out, int n, int h, int w,
                     tg_stream_t stream);
+/* The same with the kernel form chosen by the caller: -1 the library's rule (four pixels per thread wherever w % 4 == 0
+ * and the planes are 16-byte aligned), 0 one HR pixel per thread, 1 four (TG_E_SHAPE if the shape does not allow it).
+ * Both forms accumulate every output in the same order: bit-identical (tests/test_hip_parity.py). */
+int tg_convout_tail_form(const float* z, int64_t z_nstride, int cz, const float* bias,
+                         const float* up_src, int up_mode, int up_scale, float* y,
+                         int64_t y_nstride, uint8_t* u8_out, int n, int h, int w, int form,
+                         tg_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * 3x3 conv with a tiny output-channel count (cout <= 4), direct fp32 VALU

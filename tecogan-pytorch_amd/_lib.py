@@ -76,6 +76,7 @@ SIGNATURES = {
     'tg_convt3x3s2_z_fwd': (I, [P, I64, P, P, P, I, P, I64, I, I, I, I, I, I, P]),
     'tg_convt3x3s2_z_fwd_form': (I, [P, I64, P, P, P, I, P, I64, I, I, I, I, I, I, I, P]),
     'tg_convout_tail': (I, [P, I64, I, P, P, I, I, P, I64, P, I, I, I, P]),
+    'tg_convout_tail_form': (I, [P, I64, I, P, P, I, I, P, I64, P, I, I, I, I, P]),
     'tg_conv3x3_small_fwd': (I, [P, I64, P, P, P, I, I, P, I64, I, I, I, I, I, I, P]),
     'tg_conv3x3_fewin_fwd': (I, [P, I64, P, P, I64, P, I64, I, I, I, I, I, P]),
     'tg_conv3x3_small_fwd_res': (I, [P, I64, P, P, P, I64, P, I64, I, I, I, I, I, I, P]),

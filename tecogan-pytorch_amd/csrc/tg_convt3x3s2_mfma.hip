@@ -821,6 +821,142 @@ __global__ __launch_bounds__(256) void convout_tail_kernel(const float* __restri
   }
 }
 
+
+// The same tail, FOUR horizontally adjacent HR pixels per thread (round 6; w % 4 == 0 and 16-byte aligned planes): a tap
+// plane is read as one (unaligned) 16-byte load instead of four 4-byte ones -- 27 loads per thread instead of 108 per
+// four threads (the texture path's cost is per lane and instruction, not per byte) --, the bicubic residual's vertical
+// pass is shared by the four pixels of an LR column, the fp32 frame leaves as 16-byte stores and the uint8 frame as one
+// 12-byte store.  Every output is accumulated in the scalar kernel's order: bit-identical.
+template <int CZ>
+__global__ __launch_bounds__(256) void convout_tail4_kernel(const float* __restrict__ z, long long z_ns,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ up, int up_mode,
+                                                            int up_scale, float* __restrict__ y,
+                                                            long long y_ns, uint8_t* __restrict__ u8,
+                                                            int n, int h, int w) {
+  const int X = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));
+  const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (X >= w || Y >= h) return;
+  const unsigned hw = (unsigned)h * (unsigned)w;
+  // one image's planes: 32-bit offsets against a buffer resource (out-of-range reads at the two ends of the buffer: 0)
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(z + (long long)b * z_ns), 0, (int)(9u * CZ * hw * 4u), 0x00020000);
+  float v[CZ][4];
+#pragma unroll
+  for (int o = 0; o < CZ; ++o)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[o][e] = 0.f;
+  const bool left = X == 0, right = X + 4 >= w;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = Y + ky - 1;
+    if (yy < 0 || yy >= h) continue;                       // (uniform: a wave covers one row)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const unsigned base = ((unsigned)yy * (unsigned)w + (unsigned)(X + kx - 1)) * 4u;     // X = 0, kx = 0: wraps to 0xFFFFFFFC -> out of range -> 0, fixed below anyway
+#pragma unroll
+      for (int o = 0; o < CZ; ++o) {
+        const unsigned pl = (unsigned)((ky * 3 + kx) * CZ + o) * hw * 4u;
+        f32x4 t;
+        if (kx == 0 && left) {                             // the row's first thread: elements X .. X + 2 only
+          t[0] = 0.f;
+#pragma unroll
+          for (int e = 1; e < 4; ++e)
+            t[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, (int)(base + 4u * e + pl), 0, 0));
+        } else {
+          t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, (int)(base + pl), 0, 0));
+          if (kx == 2 && right) t[3] = 0.f;                // X + 4 is the next row's first pixel: the conv's zero padding
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[o][e] += t[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < CZ; ++o) {
+    const float bb = bias ? bias[o] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[o][e] += bb;
+  }
+  if (up) {
+    const int lh = h / up_scale, lw = w / up_scale;
+    const float* src = up + (long long)b * CZ * lh * lw;
+    if (up_mode == TG_UP_BICUBIC) {
+      const int i = Y / up_scale, dy = Y - i * up_scale;
+      float kyw[4];
+      bicubic_w(dy, up_scale, kyw);
+      int ri[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) { int r = i - 1 + p; ri[p] = r < 0 ? 0 : (r > lh - 1 ? lh - 1 : r); }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = (X + e) / up_scale, dx = (X + e) - j * up_scale;
+        float kxw[4];
+        bicubic_w(dx, up_scale, kxw);
+        int ci[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { int c = j - 1 + p; ci[p] = c < 0 ? 0 : (c > lw - 1 ? lw - 1 : c); }
+#pragma unroll
+        for (int o = 0; o < CZ; ++o) {
+          const float* s_ = src + (long long)o * lh * lw;
+          float acc = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float vq = 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) vq += kyw[p] * s_[ri[p] * lw + ci[q]];
+            acc += kxw[q] * vq;
+          }
+          v[o][e] += acc;
+        }
+      }
+    } else {
+      int y0, y1; float ly0, ly1;
+      bilinear_src(Y, up_scale, lh, y0, y1, ly0, ly1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int x0, x1; float lx0, lx1;
+        bilinear_src(X + e, up_scale, lw, x0, x1, lx0, lx1);
+#pragma unroll
+        for (int o = 0; o < CZ; ++o) {
+          const float* s_ = src + (long long)o * lh * lw;
+          float top = lx0 * s_[y0 * lw + x0] + lx1 * s_[y0 * lw + x1];
+          float bot = lx0 * s_[y1 * lw + x0] + lx1 * s_[y1 * lw + x1];
+          v[o][e] += ly0 * top + ly1 * bot;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < CZ; ++o)
+    *reinterpret_cast<f32x4*>(y + (long long)b * y_ns + (long long)o * hw + (long long)Y * w + X) =
+        f32x4{v[o][0], v[o][1], v[o][2], v[o][3]};
+  if (u8) {
+    uint8_t q[4 * CZ];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 0; o < CZ; ++o) {
+        float r = rintf(v[o][e] * 255.0f);
+        r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
+        q[e * CZ + o] = (uint8_t)r;
+      }
+    uint8_t* dst = u8 + (((long long)b * h + Y) * w + X) * CZ;      // (n, h, w, cz): 4 * cz contiguous bytes
+    if constexpr (CZ == 3) {
+      unsigned w3[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        w3[k] = (unsigned)q[4 * k] | ((unsigned)q[4 * k + 1] << 8) | ((unsigned)q[4 * k + 2] << 16) | ((unsigned)q[4 * k + 3] << 24);
+      unsigned* d32 = reinterpret_cast<unsigned*>(dst);              // X % 4 == 0 -> 12-byte steps: 4-byte aligned
+      d32[0] = w3[0]; d32[1] = w3[1]; d32[2] = w3[2];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4 * CZ; ++k) dst[k] = q[k];
+    }
+  }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -977,13 +1113,35 @@ extern "C" int tg_convout_tail(const float* z, int64_t z_nstride, int cz, const 
                                const float* up_src, int up_mode, int up_scale, float* y,
                                int64_t y_nstride, uint8_t* u8_out, int n, int h, int w,
                                tg_stream_t stream) {
+  return tg_convout_tail_form(z, z_nstride, cz, bias, up_src, up_mode, up_scale, y, y_nstride, u8_out, n, h, w, -1, stream);
+}
+
+extern "C" int tg_convout_tail_form(const float* z, int64_t z_nstride, int cz, const float* bias,
+                                    const float* up_src, int up_mode, int up_scale, float* y,
+                                    int64_t y_nstride, uint8_t* u8_out, int n, int h, int w, int form,
+                                    tg_stream_t stream) {
   TG_REQUIRE(z && y, TG_E_ARG, "convout_tail: null pointer");
   TG_REQUIRE(n > 0 && h > 0 && w > 0 && cz >= 1 && cz <= 3, TG_E_SHAPE, "convout_tail: n=%d h=%d w=%d cz=%d", n, h, w, cz);
+  TG_REQUIRE(form >= -1 && form <= 1, TG_E_ARG, "convout_tail: form=%d (-1 the rule, 0 one pixel per thread, 1 four)", form);
   if (up_src)
     TG_REQUIRE((up_mode == TG_UP_BICUBIC || up_mode == TG_UP_BILINEAR) && up_scale >= 1 && h % up_scale == 0 &&
                    w % up_scale == 0, TG_E_SHAPE, "convout_tail: up_mode=%d up_scale=%d", up_mode, up_scale);
-  dim3 g(cdiv(w, 64), cdiv(h, 4), n), t(256);
   hipStream_t s = (hipStream_t)stream;
+  // four pixels per thread wherever rows and planes are 16-byte aligned (and the uint8 rows 4-byte aligned for cz = 3)
+  const bool vec_ok = (w % 4) == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)y % 16) == 0 && (z_nstride % 4) == 0 &&
+                      (y_nstride % 4) == 0 && (!u8_out || ((uintptr_t)u8_out % 4) == 0) &&
+                      9ll * cz * h * w * 4 < (1ll << 31);
+  TG_REQUIRE(form != 1 || vec_ok, TG_E_SHAPE, "convout_tail: the four-pixel form needs w %% 4 == 0 and 16-byte aligned planes");
+  if (form == 1 || (form == -1 && vec_ok)) {
+    dim3 g4(cdiv(w / 4, 64), cdiv(h, 4), n), t4(256);
+    switch (cz) {
+      case 1: hipLaunchKernelGGL(convout_tail4_kernel<1>, g4, t4, 0, s, z, (long long)z_nstride, bias, up_src, up_mode, up_scale, y, (long long)y_nstride, u8_out, n, h, w); break;
+      case 2: hipLaunchKernelGGL(convout_tail4_kernel<2>, g4, t4, 0, s, z, (long long)z_nstride, bias, up_src, up_mode, up_scale, y, (long long)y_nstride, u8_out, n, h, w); break;
+      default: hipLaunchKernelGGL(convout_tail4_kernel<3>, g4, t4, 0, s, z, (long long)z_nstride, bias, up_src, up_mode, up_scale, y, (long long)y_nstride, u8_out, n, h, w); break;
+    }
+    return check_launch("convout_tail4");
+  }
+  dim3 g(cdiv(w, 64), cdiv(h, 4), n), t(256);
   switch (cz) {
     case 1: hipLaunchKernelGGL(convout_tail_kernel<1>, g, t, 0, s, z, (long long)z_nstride, bias, up_src, up_mode, up_scale, y, (long long)y_nstride, u8_out, n, h, w); break;
     case 2: hipLaunchKernelGGL(convout_tail_kernel<2>, g, t, 0, s, z, (long long)z_nstride, bias, up_src, up_mode, up_scale, y, (long long)y_nstride, u8_out, n, h, w); break;

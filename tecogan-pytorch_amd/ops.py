@@ -255,6 +255,20 @@ def convt3x3s2_z(x, wpk, bias, wz, cz, cout, act=ACT_NONE, form=-1, out=None):
     return out
 
 
+def convout_tail(z, cz, bias, up_src=None, up_mode=UP_NONE, up_scale=1, want_u8=False, form=-1):
+    """tg_convout_tail_form: out[o] = bias[o] + sum_tap z[tap * cz + o] shifted by the tap (zero padding) [+ the
+    up-sampled residual of up_src] -> fp32 (n, cz, h, w) [and the uint8 (n, h, w, cz) frame].  z: (n, 32, h, w) planes
+    of tg_convt3x3s2_z_fwd.  form: -1 the library's rule, 0 one pixel per thread, 1 four (bit-identical)."""
+    _chk(z, 'z')
+    n, _, h, w = z.shape
+    y = torch.empty(n, cz, h, w, dtype=torch.float32, device=z.device)
+    u8 = torch.empty(n, h, w, cz, dtype=torch.uint8, device=z.device) if want_u8 else None
+    L.check(L.lib().tg_convout_tail_form(z.data_ptr(), z.shape[1] * h * w, cz, _ptr(bias), _ptr(up_src), up_mode, up_scale,
+                                         y.data_ptr(), cz * h * w, u8.data_ptr() if want_u8 else None, n, h, w, form,
+                                         _stream()), 'tg_convout_tail_form')
+    return (y, u8) if want_u8 else y
+
+
 def conv3x3_fewin_ok(x, cout, any_size=False):
     """whether tg_conv3x3_fewin_fwd takes the launch -- and pays: below one 4 x 64 tile per CU the MFMA
     kernel is faster (2 x 128 x 128: 8.7 against 11.2 us; 2 x 256 x 256: 27.9 against 18.8 us)"""

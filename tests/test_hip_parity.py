@@ -790,6 +790,36 @@ def test_convt_z_forms_are_bit_identical_and_match_the_composition(ops, n, cin, 
     assert torch.equal(auto[:, :9 * cz], tiled[:, :9 * cz])
 
 
+@pytest.mark.parametrize('n,cz,h,w,up', [(1, 3, 48, 80, ('BD', 4)), (2, 3, 44, 132, ('BI', 2)), (1, 3, 20, 36, ('BD', 2)),
+                                         (1, 1, 17, 72, None), (2, 2, 8, 4, None), (1, 3, 536, 1280, ('BD', 4))])
+def test_convout_tail_forms_are_bit_identical_and_match_the_reference(ops, n, cz, h, w, up):
+    """tg_convout_tail_form (conv_out's 9-tap shift-add of the Z planes + bias + `+= upsample_func(lr_curr)` +
+    float32_to_uint8; tecogan_nets.py:131,145, data_utils.py:80-87): the four-pixels-per-thread form (round 6) equals the
+    one-pixel form bit for bit -- fp32 AND uint8, rows of one and of several threads, both up-samplers -- and both
+    are the reference composition."""
+    import torch.nn.functional as F
+    z = rs(1, (n, 32, h, w), -1, 1)
+    b = rs(2, (cz,), -0.5, 0.5)
+    ref = torch.zeros(n, cz, h, w, dtype=torch.float64)
+    zp = F.pad(z.double(), (1, 1, 1, 1))
+    for ky in range(3):
+        for kx in range(3):
+            ref += zp[:, (ky * 3 + kx) * cz:(ky * 3 + kx + 1) * cz, ky:ky + h, kx:kx + w]
+    ref += b.double().view(1, cz, 1, 1)
+    kw = {}
+    if up:
+        deg, s_ = up
+        src = rs(3, (n, cz, h // s_, w // s_), 0, 1)
+        ref += O.upsample(src, s_, deg).double()
+        kw = dict(up_src=dev(src), up_mode=ops.UP_BICUBIC if deg == 'BD' else ops.UP_BILINEAR, up_scale=s_)
+    y0, u0 = ops.convout_tail(dev(z), cz, dev(b), want_u8=True, form=0, **kw)
+    y1, u1 = ops.convout_tail(dev(z), cz, dev(b), want_u8=True, form=1, **kw)
+    ya = ops.convout_tail(dev(z), cz, dev(b), **kw)
+    assert err(y0, ref) <= 2e-5, err(y0, ref)
+    assert torch.equal(y0, y1) and torch.equal(u0, u1) and torch.equal(ya, y0), ((y0 - y1).abs().max().item(), int((u0 != u1).sum()))
+    assert torch.equal(u0.cpu(), torch.from_numpy(O.float32_to_uint8(y0.cpu().numpy())).permute(0, 2, 3, 1))
+
+
 @pytest.mark.parametrize('cin,cout,h,w,act,up', [
     (32, 2, 16, 40, 3, None), (64, 3, 48, 80, 0, ('BD', 4)), (64, 3, 44, 132, 0, ('BI', 2)),
     (64, 3, 20, 36, 0, ('BD', 2)), (9, 4, 7, 5, 1, None), (64, 1, 17, 70, 0, None)])

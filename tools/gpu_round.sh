@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit that produces everything committed under profiles/ for a round:
 #   bash tools/gpu_round.sh r02      (from the repo root on the GPU box; writes gpurun_out/)
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
