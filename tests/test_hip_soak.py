@@ -7,6 +7,7 @@
 the same kernel code, 2e-5 relative for the row chain against the direct kernel) WHILE a second stream
 streams 256 MB copies through L2 / HBM: a stale halo, a lost flag or a torn granule shows as an O(1)
 mismatch, a missed wake-up as a fault count."""
+import os
 import pytest
 import torch
 
@@ -150,3 +151,41 @@ def test_soak_row_chain_training_frames_under_memory_pressure(ops):
             assert torch.equal(A2, ref), it
     torch.cuda.synchronize()
     assert chain.faults() == 0
+
+
+def test_resident_launch_cross_check_with_compiler_visible_weight_loads(tmp_path):
+    """the shipped resident kernel requests its weights in inline asm the compiler cannot see (WR_UASM = 1,
+    hand-written `vmcnt` waits).  Cross-check on every GPU run: the SAME source built with compiler-visible loads
+    (`-DWR_UASM=0 -DWR_BRANCHY_U=1`, the round-4 form; a lab build: -DTG_LAB=1) must pass the bit-identity test of the
+    resident launch against the per-layer launches -- which the product passes too, so the two forms are bit-identical
+    to each other.  Needs hipcc and the product's objects next to the sources (they travel with the snapshot)."""
+    import glob
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, 'tecogan-pytorch_amd', 'csrc')
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    objs = [o for o in glob.glob(os.path.join(csrc, 'tg_*.o')) if not o.endswith('tg_conv3x3_wino_res.o')]
+    if not os.path.isfile(hipcc) or len(objs) < 10:
+        pytest.skip('no hipcc / no product objects on this box')
+    src = os.path.join(csrc, 'tg_conv3x3_wino_res.hip')
+    file_flags = [ln.split(':', 1)[1].split() for ln in open(src) if ln.startswith('// TG_FILE_FLAGS:')][0]
+    obj, lib = str(tmp_path / 'wres_visible.o'), str(tmp_path / 'libtecogan_wres_visible.so')
+    base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-ffp-contract=on']
+    r = subprocess.run(base + file_flags + ['-DTG_LAB=1', '-DWR_UASM=0', '-DWR_BRANCHY_U=1', '-c', src, '-o', obj],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs + [obj, '-ldl'],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, TECOGAN_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_hip_parity.py'), '-q', '-m', 'gpu', '-x',
+                        '-k', 'test_winograd_resident_launch_equals_separate_launches or '
+                              'test_winograd_resident_launch_with_transposed_conv_tail'],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2500:] + r.stderr[-1500:]
+    info = subprocess.run([sys.executable, '-c', 'import sys; sys.path.insert(0, %r); import tecogan_pytorch_amd; '
+                           'from tecogan_pytorch_amd import _lib; print(_lib.lib().tg_build_info().decode())' % root],
+                          env=env, capture_output=True, text=True, timeout=120)
+    assert 'wres_lab_bits=' in info.stdout and 'wres_lab_bits=0 ' not in info.stdout, info.stdout     # it really was the other form
