@@ -441,7 +441,7 @@ __device__ __forceinline__ void zs_item(const ConvTArgs& a, const float* s_w, in
   }
   const bool edge = x0 + ll + 1 >= a.w;                    // this lane's x + 1 is outside the row
   const bool edge_tile = x0 + TTW >= a.w;                  // uniform: only the last tile of a row has such lanes
-  f32x4 bq[3][NB];                                        // three chunks of the B operand in flight (see the K loop)
+  f32x4 bq[2][NB];                                        // two chunks of the B operand in flight (see the K loop)
   auto load_b = [&](int ch, f32x4 (&b)[NB]) {
     const unsigned cb = (unsigned)(ch * CK) * plane;
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -501,20 +501,18 @@ __device__ __forceinline__ void zs_item(const ConvTArgs& a, const float* s_w, in
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // The K loop, fully unrolled over the (at most 8) chunks with compile-time register sets.  The B operand is requested
-  // TWO chunks ahead: one chunk of a 3-tap item is only 24 MFMAs, and with the request one chunk ahead the waits for
-  // first-touch (HBM) lines cost 13 of the launch's 145 us (tools/abl_convtz.sh, round 6).
+  // The K loop, fully unrolled over the (at most 8) chunks with compile-time register sets; the B operand is requested
+  // one chunk ahead (two chunks ahead -- three register sets -- measured +-0 and spilled: tools/abl_convtz.sh, round 6).
   load_b(0, bq[0]);
-  if (1 < a.nchunk && !(ZS_ABL & 1)) load_b(1, bq[1]);
-  if ((ZS_ABL & 1)) { load_b(1, bq[1]); load_b(2, bq[2]); }
+  if ((ZS_ABL & 1)) load_b(1, bq[1]);
   lda(sa, TT[0], ab[0]);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     if (c < a.nchunk) {
-      if (c + 2 < a.nchunk && !(ZS_ABL & 1)) load_b(c + 2, bq[(c + 2) % 3]);
-      fix_edge(bq[c % 3]);
-      if ((c * NT) & 1) chunk(c, bq[c % 3], c + 1 >= a.nchunk, std::integral_constant<int, 1>{});
-      else chunk(c, bq[c % 3], c + 1 >= a.nchunk, std::integral_constant<int, 0>{});
+      if (c + 1 < a.nchunk && !(ZS_ABL & 1)) load_b(c + 1, bq[(c + 1) % 2]);
+      fix_edge(bq[c % 2]);
+      if ((c * NT) & 1) chunk(c, bq[c % 2], c + 1 >= a.nchunk, std::integral_constant<int, 1>{});
+      else chunk(c, bq[c % 2], c + 1 >= a.nchunk, std::integral_constant<int, 0>{});
     }
   }
   // ---- bias + activation, the output conv's contraction over the 64 channels, 8-byte stores of the tap planes ----
