@@ -341,6 +341,29 @@ class _ChainState:
     supported = {}
     dirty = False           # chained launches were enqueued since the last SYNCHRONOUS look at the counter
     reported_epoch = 0      # launches up to this epoch are covered by a fault that has already been raised
+    # Recovery from a transient fault (round 6, as in the frame plan: tg_frnet_plan_set_chain_rearm): after `rearm_wait`
+    # clean ITERATIONS on the per-layer path (counted by chain_check, which every rank calls once per iteration, and a
+    # fault reaches every rank through the all-reduced slot: the count is rank-symmetric) the chained body launches are
+    # tried again; a fault of the re-armed launches doubles the wait.  rearm_first = 0: off for good (rounds 3-5).
+    rearm_first = 64
+    rearm_wait = 0
+    clean_iters = 0
+    rearms = 0
+
+    @classmethod
+    def note_fault(cls):
+        cls.disabled = True
+        cls.clean_iters = 0
+        cls.rearm_wait = min(2 * cls.rearm_wait, 1 << 20) if cls.rearm_wait else cls.rearm_first
+
+    @classmethod
+    def note_clean_iteration(cls):
+        if cls.disabled and cls.rearm_first > 0 and cls.rearm_wait > 0:
+            cls.clean_iters += 1
+            if cls.clean_iters >= cls.rearm_wait:
+                cls.disabled = False
+                cls.clean_iters = 0
+                cls.rearms += 1
 
     @classmethod
     def buffers(cls, nlayer, n, h, w, device):
@@ -425,7 +448,8 @@ def stamp_fault(optim):
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     _ChainState.dirty = False
-    _ChainState.disabled = True
+    _ChainState.disabled = True          # (for good: without the device-side guard every chained step would need this sync)
+    _ChainState.rearm_wait = 0
     local = int(err[0]) != 0
     anywhere = local
     try:
@@ -455,6 +479,8 @@ def chain_check(slot_value=0.0, counter=True, epoch=None):
     err = _ChainState.err
     local = counter and err is not None and int(err[0]) != 0
     if not (local or slot_value != 0.0):
+        if not counter:                  # (the per-iteration call of the training step)
+            _ChainState.note_clean_iteration()
         return False
     if not local and epoch is not None and epoch <= _ChainState.reported_epoch:
         return True
@@ -464,14 +490,16 @@ def chain_check(slot_value=0.0, counter=True, epoch=None):
     lost = int(err[0]) if err is not None else 0
     if err is not None:
         err.zero_()
-    _ChainState.disabled = True
+    _ChainState.note_fault()
     _ChainState.dirty = False
     _ChainState.reported_epoch = _ChainState.epoch     # everything enqueued so far has completed (synchronised above)
     raise L.TecoganHipError(
         'chained SRNet launch (training): %s timed out waiting for a neighbour tile; the results of this '
         'step are INVALID and its optimiser step was DROPPED on every rank (weights and Adam moments '
-        'untouched).  Later steps run one launch per layer.'
-        % (f'{lost} workgroup(s) of this rank' if lost else 'workgroups of another rank'))
+        'untouched).  Later steps run one launch per layer%s.'
+        % (f'{lost} workgroup(s) of this rank' if lost else 'workgroups of another rank',
+           f'; the chained launches are tried again after {_ChainState.rearm_wait} clean iterations'
+           if _ChainState.rearm_first > 0 else ''))
 
 
 def chain_epoch():

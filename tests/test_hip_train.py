@@ -236,6 +236,7 @@ def test_training_step_with_chain_fault_drops_the_update_and_raises(model_name):
         "beforeD = {k: v.detach().clone() for k, v in D.state_dict().items()} if D is not None else {}\n"
         "stepsD0 = m.optim_D.steps if D is not None else 0\n"
         "TG._ChainState.poll_limit = -1               # every waiting workgroup gives up at once\n"
+        "TG._ChainState.rearm_first = 3\n"
         "try:                                        # the fault surfaces with the scalars: at the end of train() or on the first look at the log\n"
         "    m.train(); m.sync_log(); raise SystemExit('no error reported')\n"
         "except _lib.TecoganHipError as e:\n"
@@ -255,6 +256,12 @@ def test_training_step_with_chain_fault_drops_the_update_and_raises(model_name):
         "assert m.optim_G.steps == steps0 + 1\n"
         "if D is not None:\n"
         "    assert m.optim_D.steps == stepsD0 + 1\n"
+        "# round 6: the chained launches come back after the back-off of clean iterations (3 here, 64 by default)\n"
+        "assert TG._ChainState.disabled and TG._ChainState.rearm_wait == 3 and TG._ChainState.rearms == 0, (TG._ChainState.rearm_wait, TG._ChainState.rearms)\n"
+        "for _ in range(3): m.train(); m.sync_log()\n"
+        "assert not TG._ChainState.disabled and TG._ChainState.rearms == 1, (TG._ChainState.disabled, TG._ChainState.clean_iters)\n"
+        "ep0 = TG.chain_epoch(); m.train(); m.sync_log()\n"
+        "assert TG.chain_epoch() > ep0, 'the re-armed step did not use the chained launches'\n"
         "print('DROP-OK')\n" % (root, os.path.join(root, 'tests', 'golden'), model_name))
     r = subprocess.run([sys.executable, '-c', script], timeout=900, capture_output=True, text=True)
     assert r.returncode == 0 and 'DROP-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
