@@ -137,6 +137,9 @@ def launch_ranks(args):
         except subprocess.TimeoutExpired:
             procs[r].kill()
     th.join(timeout=10)
+    for ln in lines:                       # whatever else rank 0 wrote to stdout stays visible, on stderr
+        if not ln.lstrip().startswith('{'):
+            sys.stderr.write(ln)
     if rc == 0:
         js = [ln for ln in lines if ln.lstrip().startswith('{')]
         if len(js) != 1:
