@@ -173,10 +173,20 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
   const float slope = act_slope(a.act);
   const int ocb0 = ocg * TOCB + wn * 32 + 4 * lh;
   float bv[16];
+  if constexpr (ZMODE) {
+    // (a channel past cout reads 0 here where the other branch reads bias[cout - 1]: its accumulator is 0 and its row of
+    // the contraction operand is 0, the contribution is 0 either way)
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.bias ? a.bias : a.wz), 0, a.bias ? a.cout * 4 : 0, 0x00020000);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    int oc = ocb0 + (r & 3) + 8 * (r >> 2);
-    bv[r] = a.bias ? a.bias[oc < a.cout ? oc : a.cout - 1] : 0.f;
+    for (int r = 0; r < 16; ++r)
+      bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (int)((unsigned)ocb0 * 4u + (unsigned)((r & 3) + 8 * (r >> 2)) * 4u), 0, 0));
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int oc = ocb0 + (r & 3) + 8 * (r >> 2);
+      bv[r] = a.bias ? a.bias[oc < a.cout ? oc : a.cout - 1] : 0.f;
+    }
   }
   if constexpr (ZMODE) {
     // The accumulator layout IS the B operand of the contraction over oc: register r of lane l
@@ -185,13 +195,31 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
     // was packed in exactly this order (tg_convt_pack_wz).  16 MFMAs per phase and wave; the two
     // oc-half waves of a row are summed through LDS (staging buffers are dead: the K loop ended
     // on a barrier), the wn == 0 wave stores the planes.
+    // Round 6: this epilogue was ~750 VALU instructions per wave and tile against 352 MFMAs -- and fp32 MFMA and
+    // VALU time ADD on a gfx950 SIMD (EXPERIMENTS.md).  Now: bias + activation in place (ReLU as one v_max), operands
+    // through buffer resources with immediate offsets (no 64-bit address arithmetic), the reduction buffer addressed
+    // by one base + immediates, 8-byte buffer stores with the plane as the scalar offset and an out-of-range offset
+    // instead of a branch for rows >= zrows.  Same arithmetic in the same order: bit-identical to the round-2 form.
+    const __amdgpu_buffer_rsrc_t rwz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wz), 0, 2 * 16 * 64 * 4, 0x00020000);
+    const unsigned wzo = (unsigned)(wn * 16 * 64 + lane) * 4u;
     float az[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) az[r] = a.wz[(wn * 16 + r) * 64 + lane];
-    float* red = smem;                          // [2 phases][WM][16][64]
+    for (int r = 0; r < 16; ++r)
+      az[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwz, (int)(wzo + (unsigned)r * 256u), 0, 0));
+    const bool relu = slope == 0.f;              // launch-uniform
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = acc[p][r] + bv[r];
+        acc[p][r] = relu ? fmaxf(t, 0.f) : (t >= 0.f ? t : t * slope + 0.f);
+      }
+    float* const red = smem + (wm * 16) * 64 + lane;      // [2 phases][WM][16][64]: + (q * WM * 16 + r) * 64
     const bool inimg = px < a.w && py < a.h;
     const int ow = 2 * a.w;
-    const long long ohw = 4ll * hw;
+    const unsigned ohw = 4u * (unsigned)hw;
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+        a.z + (long long)n * a.z_ns, 0, (int)(32u * ohw * 4u), 0x00020000);
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {            // phase pairs (py = pp; px = 0, 1)
       f32x16 z[2];
@@ -200,29 +228,33 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[q][r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float t = acc[pp * 2 + q][r] + bv[r];
-          t = t >= 0.f ? t : t * slope + 0.f;
-          z[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(az[r], t, z[q], 0, 0, 0);
-        }
+        for (int r = 0; r < 16; ++r)
+          z[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(az[r], acc[pp * 2 + q][r], z[q], 0, 0, 0);
       }
       if (wn == 1) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) red[((q * WM + wm) * 16 + r) * 64 + lane] = z[q][r];
+          for (int r = 0; r < 16; ++r) red[(q * WM * 16 + r) * 64] = z[q][r];
       }
       __syncthreads();
-      if (wn == 0 && inimg) {
-        float* zb = a.z + (long long)n * a.z_ns + (long long)(2 * py + pp) * ow + 2 * px;
+      if (wn == 0) {
+        const unsigned zo = inimg ? ((unsigned)(4 * lh) * ohw + (unsigned)((2 * py + pp) * ow + 2 * px)) * 4u : TOOB;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < a.zrows) {
-            float2 v;
-            v.x = z[0][r] + red[((0 * WM + wm) * 16 + r) * 64 + lane];
-            v.y = z[1][r] + red[((1 * WM + wm) * 16 + r) * 64 + lane];
-            *reinterpret_cast<float2*>(zb + (long long)m * ohw) = v;
+          const int mb = (r & 3) + 8 * (r >> 2);
+          if (mb >= 27) continue;                // (step 15 holds rows 27 and 31: zrows <= 27, never stored)
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          // (locals first: __builtin_bit_cast of a vector ELEMENT expression reads element 0 whatever the index)
+          float e0 = z[0][r] + red[(0 * WM * 16 + r) * 64];
+          asm volatile("" : "+v"(e0));           // (keeps the SLP vectorizer from pairing the two adds: v_pk_add_f32 + 3 v_mov)
+          const float e1 = z[1][r] + red[(1 * WM * 16 + r) * 64];
+          const u32x2 v = {__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e1)};
+          if (mb + 4 < a.zrows) {                // uniform: both lane halves' rows exist (12 of the 15 steps at zrows = 27)
+            __builtin_amdgcn_raw_buffer_store_b64(v, rz, (int)zo, (int)((unsigned)mb * ohw * 4u), 0);
+          } else {
+            const unsigned off = (mb + 4 * lh < a.zrows) ? zo : TOOB;
+            __builtin_amdgcn_raw_buffer_store_b64(v, rz, (int)off, (int)((unsigned)mb * ohw * 4u), 0);
           }
         }
       }
@@ -1036,7 +1068,8 @@ extern "C" int tg_convt3x3s2_z_fwd_form(const float* x, int64_t x_nstride, const
              TG_E_SHAPE, "convt3x3s2_z_fwd: n=%d cin=%d cout=%d (<=64) h=%d w=%d cz=%d (<=3)", n, cin, cout, h, w, cz);
   TG_REQUIRE(act >= TG_ACT_NONE && act <= TG_ACT_LRELU02, TG_E_ARG, "convt_z: act=%d", act);
   TG_REQUIRE((z_nstride % 2) == 0 && ((uintptr_t)z % 8) == 0, TG_E_ARG, "convt3x3s2_z_fwd: z must be 8-byte aligned");
-  TG_REQUIRE((long long)(cin + CK) * h * w * 4 < (1ll << 31), TG_E_SHAPE, "convt3x3s2_z_fwd: one batch item must be < 2 GiB");
+  TG_REQUIRE((long long)(cin + CK) * h * w * 4 < (1ll << 31) && 32ll * 4 * h * w * 4 < (1ll << 31), TG_E_SHAPE,
+             "convt3x3s2_z_fwd: one batch item (input and the 32 planes) must be < 2 GiB");
   ConvTArgs a{};
   a.x = x; a.wpk = w_packed; a.bias = bias; a.y = nullptr; a.x_ns = x_nstride; a.y_ns = 0;
   a.cin = cin; a.cout = cout; a.h = h; a.w = w; a.act = act;
