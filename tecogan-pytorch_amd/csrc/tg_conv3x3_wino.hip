@@ -359,8 +359,8 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& a, int tx, int ty, int
       float v1 = ((sr[i][1] - sr[i][2]) - sr[i][3]) + bz;
       if (a.act == TG_ACT_TANH24) { v0 = apply_act(v0, a.act); v1 = apply_act(v1, a.act); }
       else {      // max(x, 0) + slope * min(x, 0): the piecewise-linear activations without v_cndmask (see tg_conv3x3_wino_res.hip)
-        v0 = __builtin_fmaf(slope, __builtin_fminf(v0, 0.f), __builtin_fmaxf(v0, 0.f));
-        v1 = __builtin_fmaf(slope, __builtin_fminf(v1, 0.f), __builtin_fmaxf(v1, 0.f));
+        v0 = __builtin_fmaxf(v0, slope * v0);      // (round 6: 2 VALU instead of max(x, 0) + slope * min(x, 0); slope in [0, 1])
+        v1 = __builtin_fmaxf(v1, slope * v1);
       }
       const size_t o = (size_t)oc * hw + (size_t)oy * a.w + ox;
       const bool two = ox + 1 < a.w;

@@ -471,8 +471,14 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
 #pragma unroll
     for (int r = 0; r < 4; ++r) bz[r] = s_act[WR_BIAS_OFF + L * WR_NC + oc_base + r];
     float v[4][2][2];                         // [channel r][row i][column j]
-    auto epilogue = [&](auto has_res) {
+    // ACTK (round 6): 0 = no activation (conv2 of a residual block: nothing to do), 2 = the generic form, 2 VALU per
+    // output: max(x, slope * x) = x >= 0 ? x : x * slope for every slope in [0, 1] (ReLU 0, LeakyReLU 0.2, none 1) -- the
+    // round-4 form max(x, 0) + slope * min(x, 0) was 3; on this SIMD VALU time adds to the matrix time.  (Further
+    // instantiations -- ReLU as one v_max, nothing at all for act none -- spill: 165 of 168 registers are taken, and this
+    // kernel must not spill: csrc/build.sh.)
+    auto epilogue = [&](auto has_res, auto act_k) {
       constexpr bool RES = decltype(has_res)::value;
+      constexpr int ACTK = decltype(act_k)::value;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float sr[2][4];
@@ -487,8 +493,10 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
           float v1 = ((sr[i][1] - sr[i][2]) - sr[i][3]) + bz[r];
           // x >= 0 ? x : x * slope without a conditional move (v_cndmask_b32: ~23 cycles per wave instruction
           // on gfx950, tools/valu_lab.hip): max(x, 0) + slope * min(x, 0) -- same value for every finite x
-          v0 = __builtin_fmaf(slope, __builtin_fminf(v0, 0.f), __builtin_fmaxf(v0, 0.f));
-          v1 = __builtin_fmaf(slope, __builtin_fminf(v1, 0.f), __builtin_fmaxf(v1, 0.f));
+          if constexpr (ACTK == 2) {
+            v0 = __builtin_fmaxf(v0, slope * v0);
+            v1 = __builtin_fmaxf(v1, slope * v1);
+          }
           if constexpr (RES) {                // the residual input: what the destination buffer still holds
             v0 += dst[wb + r * WR_CS + i * WR_RS];
             v1 += dst[wb + r * WR_CS + i * WR_RS + 1];
@@ -497,7 +505,12 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
         }
       }
     };
-    if (lay.res) epilogue(std::true_type{}); else epilogue(std::false_type{});
+    {
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+      (void)sizeof(I1);
+      (void)sizeof(I0);
+      if (lay.res) epilogue(std::true_type{}, I2{}); else epilogue(std::false_type{}, I2{});      // layer-uniform
+    }
     // the next layer's first weights travel under the hand-over
 #if !WR_UASM
     {   // (branch-free for the same reason as load_u: behind the last layer the last layer's blocks are requested again)
@@ -747,7 +760,7 @@ __global__ __launch_bounds__(WR_THREADS, 3) void conv3x3_wino_resident_kernel(WR
 #pragma unroll
             for (int e = 0; e < 4; ++e) {     // columns 4 tx' + e = (pixel b = e >> 1, phase px = e & 1)
               float v = ca[(pa * 2 + (e >> 1)) * 4 + py * 2 + (e & 1)][r] + bz;
-              o4[e] = __builtin_fmaf(cslope, __builtin_fminf(v, 0.f), __builtin_fmaxf(v, 0.f));
+              o4[e] = __builtin_fmaxf(v, cslope * v);
             }
             *reinterpret_cast<float4*>(yo + (size_t)(2 * pa + py) * ow) = make_float4(o4[0], o4[1], o4[2], o4[3]);
           }
