@@ -120,7 +120,12 @@ def launch_ranks(args):
     th = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
     th.start()
     rc, live = 0, set(range(n))
+    deadline = time.time() + float(os.environ.get('TG_BENCH_LAUNCH_TIMEOUT', '3600'))     # a hung rank must not hang the caller for ever
     while live and rc == 0:
+        if time.time() > deadline:
+            rc = 4
+            print(f'bench.py: ranks {sorted(live)} still running after TG_BENCH_LAUNCH_TIMEOUT; stopping them', file=sys.stderr, flush=True)
+            break
         for r in sorted(live):
             c = procs[r].poll()
             if c is not None:
