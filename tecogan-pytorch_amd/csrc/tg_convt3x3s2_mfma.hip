@@ -1093,7 +1093,7 @@ extern "C" int tg_convt3x3s2_z_fwd_form(const float* x, int64_t x_nstride, const
     // fail-safe of the streaming form's polls: a fault counter in pinned host memory, looked at on entry
     static int* zs_err = nullptr;
     static bool zs_off = false;
-    if (attr_ok && !zs_err && !zs_off) {
+    if (form >= 1 && attr_ok && !zs_err && !zs_off) {      // (only a caller that asks for the streaming form pays for its 64 pinned bytes)
       void* hp = nullptr;
       if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hp) { zs_err = static_cast<int*>(hp); *zs_err = 0; }
       else { (void)hipGetLastError(); zs_off = true; }
@@ -1106,7 +1106,7 @@ extern "C" int tg_convt3x3s2_z_fwd_form(const float* x, int64_t x_nstride, const
       return TG_E_HIP;
     }
     const long long items = 2ll * n * h * a.tiles_x;
-    const bool fits = attr_ok && !zs_off && zs_err && cin <= 64 && cout <= 64 && items < (1ll << 30) && 32ll * 4 * h * w * 4 < (1ll << 31);
+    const bool fits = attr_ok && !zs_off && (zs_err || form < 1) && cin <= 64 && cout <= 64 && items < (1ll << 30) && 32ll * 4 * h * w * 4 < (1ll << 31);
     TG_REQUIRE(form < 1 || fits, TG_E_SHAPE, "convt3x3s2_z_fwd_form: the streaming form needs cin, cout <= 64 and 160 KB of LDS");
     // The rule keeps the TILED form (round 6, EXPERIMENTS.md): stand-alone the streaming form with the static item list
     // is 3 % faster at 268x640 (143.5 vs 148 us), through the whole frame it is +-0 (1463-1467 vs 1462 frames/s), and
