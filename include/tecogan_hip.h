@@ -807,7 +807,7 @@ void tg_frnet_plan_destroy(tg_frnet_plan* plan);
  * bytes of hipHostMalloc memory, the only allocation a plan makes) and carries on, so the launch
  * always ends.  EVERY later tg_frnet_step* / tg_frnet_replay call on the plan looks at that counter
  * first (a host read, no synchronisation): the first call that sees it non-zero returns TG_E_HIP
- * ("frames since the fault are invalid") and switches the plan to one launch per layer for good;
+ * ("frames since the fault are invalid") and switches the plan to one launch per layer (until it re-arms: see below);
  * calls after that run normally on the fallback.  tg_frnet_plan_chain_status does the same check
  * on demand (call it after a synchronisation: it then covers everything enqueued so far):
  * returns TG_OK / TG_E_HIP as above, *faults_total = faults since creation, *chain_active = 1
