@@ -374,12 +374,14 @@ int tg_convt3x3s2_z_fwd(const float* x, int64_t x_nstride, const float* w_packed
                         const float* bias, const float* wz, int cz, float* z,
                         int64_t z_nstride, int n, int cin, int cout, int h, int w, int act,
                         tg_stream_t stream);
-/* The same with the kernel form chosen by the caller: -1 = the library's rule (what tg_convt3x3s2_z_fwd does: the tiled
- * form), 0 = the tiled form (one workgroup per 4-row x 32-pixel tile, weights staged through LDS chunk by chunk),
+/* The same with the kernel form chosen by the caller: -1 = the library's rule (what tg_convt3x3s2_z_fwd does: a tiled
+ * form, 0 or 3), 0 = the tiled form (one workgroup per 4-row x 32-pixel tile, weights staged through LDS chunk by chunk),
  * 1 / 2 = the streaming form of round 6 (weights LDS-resident for the whole launch, every wave an autonomous worker
  * on (row, 32 pixels, row parity) items; 1: items handed out in batches from a device-wide counter, polls bounded,
  * a time-out is reported as TG_E_HIP by the NEXT call and turns the form off; 2: a static, per-SIMD balanced item
- * list; needs cin, cout <= 64).  All forms produce BIT-IDENTICAL planes (same taps in the same order per phase).
+ * list; needs cin, cout <= 64), 3 = tiled with a split tail (whole rounds of four-row workgroups, the remaining rows as
+ * two-row workgroups in a second launch; what the rule picks for one 268x640-class frame).  All forms produce
+ * BIT-IDENTICAL planes (same taps in the same order per phase).
  * Measured at 268x640 (MI355X): tiled 148 us, streaming static 143.5 us, streaming dynamic 164 us; through the
  * frame +-0, hence the rule (EXPERIMENTS.md, round 6). */
 int tg_convt3x3s2_z_fwd_form(const float* x, int64_t x_nstride, const float* w_packed,

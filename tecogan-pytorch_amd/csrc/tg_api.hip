@@ -521,6 +521,7 @@ static int step_impl(tg_frnet_plan* p, const float* lr_curr, const float* lr_pre
       zin = p->U1;
     }
     const tg_layer_weights lw_last = s == 4 ? lw_up2 : lw_up1;
+    if (dry && tg::convt_z_split_rule(n, zh, zw, -1)) p->st_launch[K_CONVT_Z] += 1;   // (two launches: split tail, round 6)
     go(K_CONVT_Z, 2.0 * nf * 9 * nf * n * zh * zw + 2.0 * nf * 9 * c.out_nc * hpx,
        4.0 * n * zh * zw * nf + 4.0 * hpx * 9 * c.out_nc, [&] {
          return tg_convt3x3s2_z_fwd(zin, (int64_t)nf * zh * zw, lw_last.w, lw_last.b, p->WZ, c.out_nc, zbuf,

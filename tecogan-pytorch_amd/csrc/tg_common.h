@@ -44,6 +44,9 @@ inline int check_launch(const char* what) {
     }                               \
   } while (0)
 
+// whether tg_convt3x3s2_z_fwd_form(form) runs as two launches (whole rounds of 4-row workgroups + a 2-row tail)
+bool convt_z_split_rule(int n, int h, int w, int form);
+
 // split-K halves of tg_conv3x3_splitk_fwd (the plan accounts them as separate kernel classes)
 int conv3x3_splitk_conv(const float* x, int64_t x_nstride, int c1, const float* x2,
                         int64_t x2_nstride, const float* w_packed, int ocb, int n, int cin,

@@ -37,6 +37,7 @@ struct ConvTArgs {
   long long x_ns, y_ns;
   int cin, cout, h, w, act;
   int tiles_x, tiles_y, nchunk, nocg;
+  int y_base;          // first input row of this launch's tile grid (0 but for the split Z launch, round 6)
   // Z mode (the LAST up-sampling layer of SRNet, inference): instead of the 64-channel HR
   // tensor the kernel emits the 9*cz "tap planes" of the following 3x3 output conv,
   //   z[tap*cz + o][Y][X] = sum_oc  Wout[o][oc][tap] * act(convT(x)[oc][Y][X] + bias[oc]),
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs 
   const int ty = b % a.tiles_y; b /= a.tiles_y;
   const int ocg = b % a.nocg;
   const int n = b / a.nocg;
-  const int x0 = tx * TTW, y0 = ty * WM;
+  const int x0 = tx * TTW, y0 = a.y_base + ty * WM;
   const int hw = a.h * a.w;
 
   unsigned voff[I_PER_T];
@@ -987,6 +988,24 @@ __global__ __launch_bounds__(256) void convout_tail4_kernel(const float* __restr
   }
 }
 
+
+// The Z-mode launcher's split-tail rule (also asked by the frame plan's launch accounting): 4-row workgroups, one image,
+// at least one whole round of the 2-per-CU resident slots, and a last round between a quarter and 95 % full (form 3: always
+// when a whole round exists; form 0: never).
+bool convt_z_split_rule(int n, int h, int w, int form) {
+  if (n != 1 || !(form == 3 || form == -1)) return false;
+  const long long tiles_x = cdiv(w, TTW);
+  const long long wg4 = tiles_x * cdiv(h, 4) * n;
+  if (wg4 < 512) return false;                       // (the launcher uses 2-row workgroups there)
+  static int ncu_s = 0;
+  if (!ncu_s) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu_s, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); ncu_s = 256; } }
+  const long long slots = 2ll * ncu_s, rem = wg4 % slots;
+  if (wg4 < slots) return false;
+  const long long ty4 = (wg4 / slots) * slots / tiles_x;
+  if (ty4 < 1 || ty4 >= cdiv(h, 4)) return false;
+  return form == 3 || (4 * rem >= slots && 100 * rem <= 95 * slots);
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -1062,7 +1081,7 @@ extern "C" int tg_convt3x3s2_z_fwd_form(const float* x, int64_t x_nstride, const
                                         const float* bias, const float* wz, int cz, float* z,
                                         int64_t z_nstride, int n, int cin, int cout, int h, int w, int act,
                                         int form, tg_stream_t stream) {
-  TG_REQUIRE(form >= -1 && form <= 2, TG_E_ARG, "convt3x3s2_z_fwd_form: form=%d (-1 auto, 0 tiled, 1 streaming, 2 streaming with a static item list)", form);
+  TG_REQUIRE(form >= -1 && form <= 3, TG_E_ARG, "convt3x3s2_z_fwd_form: form=%d (-1 auto, 0 tiled, 1 streaming, 2 streaming with a static item list, 3 tiled with a split tail)", form);
   TG_REQUIRE(x && w_packed && wz && z, TG_E_ARG, "convt3x3s2_z_fwd: null pointer");
   TG_REQUIRE(n > 0 && cin > 0 && cout > 0 && cout <= 64 && h > 0 && w > 0 && cz >= 1 && 9 * cz <= 32,
              TG_E_SHAPE, "convt3x3s2_z_fwd: n=%d cin=%d cout=%d (<=64) h=%d w=%d cz=%d (<=3)", n, cin, cout, h, w, cz);
@@ -1079,7 +1098,7 @@ extern "C" int tg_convt3x3s2_z_fwd_form(const float* x, int64_t x_nstride, const
   a.tiles_x = cdiv(w, TTW); a.nocg = 1; a.nchunk = cdiv(cin, CK);
   // the streaming form (weights LDS-resident, autonomous waves) wherever every wave of the chip finds a few items
   {
-    const int stream_env = form;
+    const int stream_env = form == 3 ? 0 : form;
     static int ncu = -1;
     static bool attr_ok = false;
     if (ncu < 0) {
@@ -1131,6 +1150,29 @@ extern "C" int tg_convt3x3s2_z_fwd_form(const float* x, int64_t x_nstride, const
   size_t lds = 2 * (size_t)((rows + 1) * 2 * TRS * 4 + 9 * CK * TOCB) * sizeof(float);   // >= 2*rows*16*64*4 B
   long long blocks = (long long)a.tiles_x * a.tiles_y * n;
   TG_REQUIRE(blocks > 0 && blocks < (1ll << 31), TG_E_SHAPE, "convt_z: grid %lld", blocks);
+  // Split tail (round 6): 1 340 four-row workgroups are 2.62 rounds of the 512 resident slots, i.e. 3 -- so the whole
+  // rounds run as four-row workgroups and the REMAINING rows as two-row workgroups (4 resident per CU: a finer last
+  // round) in a second launch behind the first.  Same kernels, same arithmetic per output: bit-identical; 144.7 -> 141.2 us
+  // at 268x640 (tools/convtz_lab.py).  The rule takes it when at least one whole round exists and the last round is
+  // between a quarter and 95 % full; form 0 never splits, form 3 always does when a whole round exists.
+  const bool split = convt_z_split_rule(n, h, w, form);
+  if (split) {
+    int ncu3 = 256;
+    { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu3, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); ncu3 = 256; } }
+    const int slots = 2 * ncu3;
+    const int full_rounds = (int)(blocks / slots);
+    const int ty4 = full_rounds * slots / a.tiles_x;             // tile rows of the first launch
+    if (full_rounds >= 1 && ty4 >= 1 && ty4 < a.tiles_y) {
+      ConvTArgs a4 = a; a4.tiles_y = ty4; a4.y_base = 0;
+      hipLaunchKernelGGL((convt3x3s2_mfma_kernel<4, WN, true>), dim3((unsigned)(a.tiles_x * ty4)), dim3(4 * WN * 64), lds,
+                         (hipStream_t)stream, a4);
+      ConvTArgs a2 = a; a2.y_base = 4 * ty4; a2.tiles_y = cdiv(h - 4 * ty4, 2);
+      const size_t lds2 = 2 * (size_t)((2 + 1) * 2 * TRS * 4 + 9 * CK * TOCB) * sizeof(float);
+      hipLaunchKernelGGL((convt3x3s2_mfma_kernel<2, WN, true>), dim3((unsigned)(a.tiles_x * a2.tiles_y)), dim3(2 * WN * 64), lds2,
+                         (hipStream_t)stream, a2);
+      return check_launch("convt3x3s2_z(split)");
+    }
+  }
   if (rows == 2)
     hipLaunchKernelGGL((convt3x3s2_mfma_kernel<2, WN, true>), dim3((unsigned)blocks), dim3(2 * WN * 64), lds,
                        (hipStream_t)stream, a);

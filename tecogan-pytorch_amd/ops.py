@@ -244,7 +244,7 @@ def convt_pack_wz(w_out_oihw):
 def convt3x3s2_z(x, wpk, bias, wz, cz, cout, act=ACT_NONE, form=-1, out=None):
     """tg_convt3x3s2_z_fwd_form: ConvTranspose2d(cin, cout, 3, 2, 1, 1) + act with the following 3x3 output conv's
     channel contraction in the epilogue -> (n, 32, 2h, 2w) buffer whose first 9 * cz planes are the output conv's tap
-    planes (tecogan_nets.py:119-131).  form: -1 the library rule, 0 tiled, 1 streaming, 2 streaming with a static item list (all bit-identical)."""
+    planes (tecogan_nets.py:119-131).  form: -1 the library rule, 0 tiled, 1 streaming, 2 streaming with a static item list, 3 tiled with a split tail (all bit-identical)."""
     _chk(x, 'x')
     n, cin, h, w = x.shape
     if out is None:

@@ -790,6 +790,26 @@ def test_convt_z_forms_are_bit_identical_and_match_the_composition(ops, n, cin, 
     assert torch.equal(auto[:, :9 * cz], tiled[:, :9 * cz])
 
 
+def test_convt_z_split_tail_is_bit_identical_at_the_frame_size(ops):
+    """tg_convt3x3s2_z_fwd_form 3 (round 6, what the rule picks at this size): whole rounds of four-row workgroups and a
+    second launch of two-row workgroups for the remaining rows -- against the single-launch tiled form (0) and the
+    streaming form with the static list (2), bit for bit, at the 268x640 -> 536x1280 shape of the inference frame; rows
+    that the first launch does not cover must not be touched by it (the buffer is pre-filled)."""
+    n, cin, cout, cz, h, w = 1, 64, 64, 3, 268, 640
+    x = dev(rs(1, (n, cin, h, w), -1, 1))
+    wt = rs(2, (cin, cout, 3, 3), -1, 1) / (1.5 * cin ** 0.5)
+    b = dev(rs(3, (cout,), -0.5, 0.5))
+    wo = rs(4, (cz, cout, 3, 3), -1, 1) / (3.0 * cout ** 0.5)
+    pk, _, _, _ = ops.pack_conv3x3(dev(wt), transposed=True)
+    wz = ops.convt_pack_wz(dev(wo))
+    ref = ops.convt3x3s2_z(x, pk, b, wz, cz, cout, act=1, form=0)
+    for form in (3, -1, 2):
+        out = torch.full((n, 32, 2 * h, 2 * w), 7.0, device='cuda')
+        ops.convt3x3s2_z(x, pk, b, wz, cz, cout, act=1, form=form, out=out)
+        assert torch.equal(out[:, :27], ref[:, :27]), (form, (out[:, :27] - ref[:, :27]).abs().max().item())
+        assert bool((out[:, 27:] == 7.0).all()), form
+
+
 @pytest.mark.parametrize('n,cz,h,w,up', [(1, 3, 48, 80, ('BD', 4)), (2, 3, 44, 132, ('BI', 2)), (1, 3, 20, 36, ('BD', 2)),
                                          (1, 1, 17, 72, None), (2, 2, 8, 4, None), (1, 3, 536, 1280, ('BD', 4))])
 def test_convout_tail_forms_are_bit_identical_and_match_the_reference(ops, n, cz, h, w, up):

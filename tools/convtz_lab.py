@@ -16,7 +16,7 @@ wz = ops.convt_pack_wz(wo)
 outs = {}
 gflop = (2.0 * 64 * 9 * 64 * h * w + 2.0 * 64 * 27 * 4 * h * w) / 1e9
 for rep in range(2):
-    for form in (0, 1, 2):
+    for form in (0, 1, 2, 3):
         out = torch.empty(1, 32, 2 * h, 2 * w, device='cuda')
         for _ in range(5):
             ops.convt3x3s2_z(x, pk, b, wz, 3, 64, act=1, form=form, out=out)
@@ -29,6 +29,6 @@ for rep in range(2):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 50
         outs[form] = out[:, :27].clone()
-        print(f'form {form} ({("tiled", "streaming", "streaming, static list")[form]}): {us:7.1f} us  {gflop / us * 1e3:6.1f} TFLOP/s '
+        print(f'form {form} ({("tiled", "streaming", "streaming, static list", "tiled, split tail")[form]}): {us:7.1f} us  {gflop / us * 1e3:6.1f} TFLOP/s '
               f'({gflop / us * 1e3 / 157.3:.2f} of peak)', flush=True)
-print('bit-identical:', torch.equal(outs[0], outs[1]), torch.equal(outs[0], outs[2]), 'max diff', (outs[0] - outs[1]).abs().max().item())
+print('bit-identical:', torch.equal(outs[0], outs[1]), torch.equal(outs[0], outs[2]), torch.equal(outs[0], outs[3]), 'max diff', (outs[0] - outs[1]).abs().max().item())
