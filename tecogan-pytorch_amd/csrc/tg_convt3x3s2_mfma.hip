@@ -49,7 +49,7 @@ struct ConvTArgs {
 };
 
 template <int WM, int WN, bool ZMODE = false>
-__global__ __launch_bounds__(WM* WN * 64) void convt3x3s2_mfma_kernel(ConvTArgs a) {
+__global__ __launch_bounds__(WM* WN * 64, ZMODE ? 4 : 1) void convt3x3s2_mfma_kernel(ConvTArgs a) {      // (4 waves per SIMD: without the second argument the 2-row form takes 118 + 64 AGPRs and runs 2)
   static_assert(WN * 32 == TOCB, "WN waves x 32 oc must cover the 64-oc block");
   constexpr int NTHREADS = WM * WN * 64;
   constexpr int PH = WM + 1;
