@@ -559,8 +559,10 @@ def test_resident_launch_fault_surfaces_and_falls_back(tmp_path):
     assert r.returncode == 0 and 'FAILSAFE-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-def test_resident_launch_recovers_from_a_transient_fault(tmp_path):
-    """VERDICT r5 item 7 / ADVICE r4 item 3: ONE injected fault (a transient co-tenant) must not cost the one-launch
+@pytest.mark.parametrize('kind,k,h,w', [('resident', 1, 40, 72), ('chain', 2, 26, 40)])
+def test_resident_launch_recovers_from_a_transient_fault(tmp_path, kind, k, h, w):
+    """(kind 'chain': the same protocol for the chained Winograd launch of a 2-clip plan.)
+    VERDICT r5 item 7 / ADVICE r4 item 3: ONE injected fault (a transient co-tenant) must not cost the one-launch
     body for the life of the process.  The plan falls back to one launch per layer, counts clean frames, arms the
     resident launch again after the back-off (here 6 frames instead of the default 64), and a second fault doubles
     the wait.  Frames are bit-identical on either path (TG_WINO_RES_CT=0: the first transposed conv a launch of its
@@ -573,9 +575,10 @@ def test_resident_launch_recovers_from_a_transient_fault(tmp_path):
         "from tests.test_hip_parity import make_net, smooth_clip\n"
         "from tecogan_pytorch_amd import _lib\n"
         "dev = torch.device('cuda', 0)\n"
-        "x = smooth_clip(5, 3, 40, 72, seed=5).cuda()\n"
+        "K, H, W = %d, %d, %d\n"
+        "x = smooth_clip(5, 3, H, W, seed=5).cuda() if K == 1 else torch.from_numpy(np.stack([smooth_clip(5, 3, H, W, seed=5 + i) for i in range(K)])).cuda()\n"
         "net, _ = make_net('BD', 4)\n"
-        "plan = net._get_plan(1, 40, 72, dev)\n"
+        "plan = net._get_plan(K, H, W, dev)\n"
         "plan.set_chain_rearm(6)\n"
         "limit = lambda v: _lib.check(_lib.lib().tg_frnet_plan_set_chain_poll_limit(plan.handle, v), 'limit')\n"
         "ref = net.infer_sequence(x, dev)                       # healthy: resident body\n"
@@ -611,8 +614,9 @@ def test_resident_launch_recovers_from_a_transient_fault(tmp_path):
         "y = faulted_clip()\n"
         "for _ in range(8): assert np.array_equal(net.infer_sequence(x, dev), ref)\n"
         "assert not plan.chain_state()[1] and plan.rearm_state()[0] == 2\n"
-        "print('REARM-OK')\n" % (ROOT_DIR, GOLDEN_DIR))
-    env = dict(os.environ, TG_WINO_RES='1', TG_CONV_WINO='1', TG_WINO_RES_CT='0')
+        "print('REARM-OK')\n" % (ROOT_DIR, GOLDEN_DIR, k, h, w))
+    env = dict(os.environ, TG_WINO_RES='1', TG_CONV_WINO='1', TG_WINO_RES_CT='0') if kind == 'resident' else \
+        dict(os.environ, TG_CONV_WINO='1', TG_WINO_CHAIN='1')
     r = subprocess.run([sys.executable, '-c', script], env=env, timeout=600, capture_output=True, text=True)
     assert r.returncode == 0 and 'REARM-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
